@@ -1,0 +1,45 @@
+"""Builds libcrychic_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+    python -m crychic_renderer_amd.build [--force]
+
+-ffp-contract=off is part of the numerical contract: the kernels' arithmetic is defined without
+implicit fused multiply-add so that results are bit-identical to the CPU oracle.
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libcrychic_hip.so")
+SOURCES = ["kernels.hip", "api.cpp", "host_constants.cpp"]
+HEADERS = ["devmath.hpp", "ssao_core.hpp", "light_core.hpp", "kernels.hpp"]
+FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
+         "-Wall", "-Wno-unused-function"]
+
+
+def _stale():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS] + [os.path.join(ROOT, "include", "crychic_hip.h"), __file__]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=True):
+    if not force and not _stale():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
+    for s in SOURCES:
+        cmd += ["-x", "hip", os.path.join(CSRC, s)]
+    cmd += ["-o", LIB]
+    if verbose:
+        print("[crychic build]", " ".join(cmd), flush=True)
+    subprocess.run(cmd, check=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

@@ -1,0 +1,308 @@
+// api.cpp -- the extern "C" surface of libcrychic_hip.so (include/crychic_hip.h): argument validation, the
+// stream-ordered pass sequencing of Ssao::ComputeSsao (Ssao.cpp:185-243) and of the hot part of
+// CRYCHIC::Draw (CRYCHIC.cpp:220-221,238-279), and per-pass HIP-event timing.  No CPU compute path exists
+// here: every compute entry point needs a context bound to a HIP device.
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include "crychic_hip.h"
+#include "kernels.hpp"
+#include "light_core.hpp"
+#include "ssao_core.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define CRY_HIP(expr)                                                                                  \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess) return fail(CRYCHIC_E_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+int check_dims(uint32_t W, uint32_t H)
+{
+    if (W == 0 || H == 0 || (W & 1u) || (H & 1u))
+        return fail(CRYCHIC_E_INVALID_ARG, "frame size %ux%u must be non-zero and even (half-res maps are W/2 x H/2)", W, H);
+    if ((uint64_t)W * H > 0x7FFFFFFFull) return fail(CRYCHIC_E_UNSUPPORTED, "frame %ux%u exceeds 2^31 pixels", W, H);
+    return 0;
+}
+
+}  // namespace
+
+struct crychic_ctx {
+    int device;
+    char name[256];
+    bool profiling;
+    bool times_valid;
+    hipEvent_t ev[4];  // start, after ssao, after blur, after light
+};
+
+namespace {
+
+int bind(crychic_ctx* ctx)
+{
+    if (!ctx) return fail(CRYCHIC_E_INVALID_ARG, "null context");
+    CRY_HIP(hipSetDevice(ctx->device));
+    return 0;
+}
+
+void clamp_rows(uint32_t limit, int64_t lo, int64_t hi, uint32_t* row0, uint32_t* rows)
+{
+    if (lo < 0) lo = 0;
+    if (hi > (int64_t)limit) hi = limit;
+    if (hi < lo) hi = lo;
+    *row0 = (uint32_t)lo;
+    *rows = (uint32_t)(hi - lo);
+}
+
+int ssao_compute_impl(crychic_ctx* ctx, const crychic_ssao_constants* cb, const void* normal, const uint32_t* depth,
+                      const uint8_t* randvec, uint16_t* ambient0, uint16_t* ambient1, void* edge, uint32_t W,
+                      uint32_t H, int blurCount, uint32_t row0, uint32_t rows, hipStream_t stream, hipEvent_t afterSsao)
+{
+    const uint32_t h2 = H / 2;
+    if (row0 > h2 || rows > h2 - row0) return fail(CRYCHIC_E_INVALID_ARG, "rows [%u,+%u) outside the %u-row ambient map", row0, rows, h2);
+    if (blurCount < 0) return fail(CRYCHIC_E_INVALID_ARG, "blurCount %d < 0", blurCount);
+    if (blurCount > 0 && (!ambient1 || !edge)) return fail(CRYCHIC_E_INVALID_ARG, "blurCount > 0 needs ambient1 and the edge workspace");
+    // Vertical sweeps reach 5 rows (gBlurRadius, SsaoBlur.hlsl:48): recompute a halo instead of exchanging it.
+    uint32_t r0, rn;
+    clamp_rows(h2, (int64_t)row0 - 5 * blurCount, (int64_t)row0 + rows + 5 * blurCount, &r0, &rn);
+    CRY_HIP(cry::launch_ssao(*cb, normal, depth, randvec, ambient0, blurCount > 0 ? edge : nullptr, W, H, r0, rn, true, stream));
+    if (afterSsao) CRY_HIP(hipEventRecord(afterSsao, stream));
+    for (int i = 0; i < blurCount; ++i) {
+        clamp_rows(h2, (int64_t)row0 - 5 * (blurCount - i), (int64_t)row0 + rows + 5 * (blurCount - i), &r0, &rn);
+        CRY_HIP(cry::launch_blur(*cb, edge, ambient0, ambient1, W, H, true, r0, rn, stream));   // Ssao.cpp:240
+        clamp_rows(h2, (int64_t)row0 - 5 * (blurCount - 1 - i), (int64_t)row0 + rows + 5 * (blurCount - 1 - i), &r0, &rn);
+        CRY_HIP(cry::launch_blur(*cb, edge, ambient1, ambient0, W, H, false, r0, rn, stream));  // Ssao.cpp:241
+    }
+    return 0;
+}
+
+int fill_light_params(cry::LightParams& P, const crychic_pass_constants* cb, const uint32_t* const shadow[4],
+                      uint32_t shadowDim, uint32_t cubeDim, uint32_t W, uint32_t H, int numDirLights,
+                      float pcfSearchRadius, uint32_t flags)
+{
+    if (numDirLights < 0 || numDirLights > CRYCHIC_MAX_LIGHTS)
+        return fail(CRYCHIC_E_INVALID_ARG, "numDirLights %d outside [0,%d]", numDirLights, CRYCHIC_MAX_LIGHTS);
+    if (shadowDim == 0 || cubeDim == 0) return fail(CRYCHIC_E_INVALID_ARG, "shadowDim/cubeDim must be non-zero");
+    if (!(pcfSearchRadius >= 0.0f)) return fail(CRYCHIC_E_INVALID_ARG, "pcfSearchRadius must be >= 0");
+    memcpy(P.ViewProjTex, cb->ViewProjTex, sizeof P.ViewProjTex);
+    memcpy(P.ShadowTransforms, cb->ShadowTransforms, sizeof P.ShadowTransforms);  // cascades 0..3
+    memcpy(P.InvProj, cb->InvProj, sizeof P.InvProj);
+    memcpy(P.InvView, cb->InvView, sizeof P.InvView);
+    memcpy(P.EyePosW, cb->EyePosW, sizeof P.EyePosW);
+    P.pcfSearchRadius = pcfSearchRadius;
+    memcpy(P.AmbientLight, cb->AmbientLight, sizeof P.AmbientLight);
+    memcpy(P.Lights, cb->Lights, sizeof P.Lights);
+    for (int i = 0; i < 4; ++i) {
+        if (!shadow[i]) return fail(CRYCHIC_E_INVALID_ARG, "shadow cascade %d is null", i);
+        P.shadow[i] = shadow[i];
+    }
+    P.shadowDim = shadowDim;
+    P.cubeDim = cubeDim;
+    P.W = W;
+    P.H = H;
+    P.numDirLights = numDirLights;
+    P.flags = flags;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* crychic_last_error(void) { return g_err; }
+const char* crychic_version(void) { return "crychic-hip 0.1 (gfx950)"; }
+
+int crychic_ctx_create(int device_ordinal, crychic_ctx** out)
+{
+    if (!out) return fail(CRYCHIC_E_INVALID_ARG, "out is null");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count <= 0)
+        return fail(CRYCHIC_E_NO_DEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count is 0" : hipGetErrorString(e));
+    if (device_ordinal < 0 || device_ordinal >= count)
+        return fail(CRYCHIC_E_NO_DEVICE, "device ordinal %d outside [0,%d)", device_ordinal, count);
+    CRY_HIP(hipSetDevice(device_ordinal));
+    hipDeviceProp_t prop;
+    CRY_HIP(hipGetDeviceProperties(&prop, device_ordinal));
+    crychic_ctx* ctx = new (std::nothrow) crychic_ctx();
+    if (!ctx) return fail(CRYCHIC_E_HIP, "out of host memory");
+    ctx->device = device_ordinal;
+    snprintf(ctx->name, sizeof ctx->name, "%s %s", prop.gcnArchName, prop.name);
+    ctx->profiling = false;
+    ctx->times_valid = false;
+    for (auto& ev : ctx->ev) {
+        hipError_t ee = hipEventCreate(&ev);
+        if (ee != hipSuccess) { delete ctx; return fail(CRYCHIC_E_HIP, "hipEventCreate failed: %s", hipGetErrorString(ee)); }
+    }
+    *out = ctx;
+    return 0;
+}
+
+void crychic_ctx_destroy(crychic_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    for (auto& ev : ctx->ev) (void)hipEventDestroy(ev);
+    delete ctx;
+}
+
+const char* crychic_ctx_device_name(crychic_ctx* ctx) { return ctx ? ctx->name : nullptr; }
+
+size_t crychic_edge_plane_bytes(uint32_t W, uint32_t H) { return cry::edge_plane_bytes(W, H); }
+
+int crychic_ssao(crychic_ctx* ctx, const crychic_ssao_constants* cb, const void* normal_dev, const uint32_t* depth_dev,
+                 const uint8_t* randvec_dev, uint16_t* ambient_out_dev, void* edge_dev, uint32_t W, uint32_t H,
+                 uint32_t row0, uint32_t rows, void* stream)
+{
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = check_dims(W, H)) return rc;
+    if (!cb || !normal_dev || !depth_dev || !randvec_dev || !ambient_out_dev) return fail(CRYCHIC_E_INVALID_ARG, "null argument");
+    if (row0 > H / 2 || rows > H / 2 - row0) return fail(CRYCHIC_E_INVALID_ARG, "rows [%u,+%u) outside the %u-row ambient map", row0, rows, H / 2);
+    CRY_HIP(cry::launch_ssao(*cb, normal_dev, depth_dev, randvec_dev, ambient_out_dev, edge_dev, W, H, row0, rows, true,
+                             (hipStream_t)stream));
+    return 0;
+}
+
+int crychic_ssao_edges(crychic_ctx* ctx, const crychic_ssao_constants* cb, const void* normal_dev,
+                       const uint32_t* depth_dev, void* edge_dev, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows,
+                       void* stream)
+{
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = check_dims(W, H)) return rc;
+    if (!cb || !normal_dev || !depth_dev || !edge_dev) return fail(CRYCHIC_E_INVALID_ARG, "null argument");
+    if (row0 > H / 2 || rows > H / 2 - row0) return fail(CRYCHIC_E_INVALID_ARG, "rows [%u,+%u) outside the %u-row ambient map", row0, rows, H / 2);
+    CRY_HIP(cry::launch_ssao(*cb, normal_dev, depth_dev, nullptr, nullptr, edge_dev, W, H, row0, rows, false, (hipStream_t)stream));
+    return 0;
+}
+
+int crychic_ssao_blur(crychic_ctx* ctx, const crychic_ssao_constants* cb, const void* edge_dev,
+                      const uint16_t* ambient_in_dev, uint16_t* ambient_out_dev, uint32_t W, uint32_t H, int horizontal,
+                      uint32_t row0, uint32_t rows, void* stream)
+{
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = check_dims(W, H)) return rc;
+    if (!cb || !edge_dev || !ambient_in_dev || !ambient_out_dev) return fail(CRYCHIC_E_INVALID_ARG, "null argument");
+    if (ambient_in_dev == ambient_out_dev) return fail(CRYCHIC_E_INVALID_ARG, "blur cannot run in place (the reference ping-pongs, Ssao.cpp:253-266)");
+    if (row0 > H / 2 || rows > H / 2 - row0) return fail(CRYCHIC_E_INVALID_ARG, "rows [%u,+%u) outside the %u-row ambient map", row0, rows, H / 2);
+    CRY_HIP(cry::launch_blur(*cb, edge_dev, ambient_in_dev, ambient_out_dev, W, H, horizontal != 0, row0, rows, (hipStream_t)stream));
+    return 0;
+}
+
+int crychic_ssao_compute(crychic_ctx* ctx, const crychic_ssao_constants* cb, const void* normal_dev,
+                         const uint32_t* depth_dev, const uint8_t* randvec_dev, uint16_t* ambient0_dev,
+                         uint16_t* ambient1_dev, void* edge_dev, uint32_t W, uint32_t H, int blurCount, uint32_t row0,
+                         uint32_t rows, void* stream)
+{
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = check_dims(W, H)) return rc;
+    if (!cb || !normal_dev || !depth_dev || !randvec_dev || !ambient0_dev) return fail(CRYCHIC_E_INVALID_ARG, "null argument");
+    return ssao_compute_impl(ctx, cb, normal_dev, depth_dev, randvec_dev, ambient0_dev, ambient1_dev, edge_dev, W, H,
+                             blurCount, row0, rows, (hipStream_t)stream, nullptr);
+}
+
+int crychic_deferred_light(crychic_ctx* ctx, const crychic_pass_constants* cb, const float* g0_dev, const float* g1_dev,
+                           const float* g2_dev, const uint32_t* depth_dev, const uint16_t* ambient_dev,
+                           const uint32_t* const shadow_dev[4], uint32_t shadowDim, const uint8_t* cube_dev,
+                           uint32_t cubeDim, uint8_t* out_rgba8_dev, float* radiance_out_dev, uint32_t W, uint32_t H,
+                           uint32_t row0, uint32_t rows, int numDirLights, float pcfSearchRadius, uint32_t flags,
+                           void* stream)
+{
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = check_dims(W, H)) return rc;
+    if (!cb || !g0_dev || !g1_dev || !g2_dev || !depth_dev || !shadow_dev || !cube_dev || !out_rgba8_dev)
+        return fail(CRYCHIC_E_INVALID_ARG, "null argument");
+    if (row0 > H || rows > H - row0) return fail(CRYCHIC_E_INVALID_ARG, "rows [%u,+%u) outside the %u-row frame", row0, rows, H);
+    cry::LightParams P;
+    if (int rc = fill_light_params(P, cb, shadow_dev, shadowDim, cubeDim, W, H, numDirLights, pcfSearchRadius, flags)) return rc;
+    CRY_HIP(cry::launch_light(P, g0_dev, g1_dev, g2_dev, depth_dev, ambient_dev, cube_dev, out_rgba8_dev, radiance_out_dev,
+                              row0, rows, (hipStream_t)stream));
+    return 0;
+}
+
+int crychic_draw_hot_path(crychic_ctx* ctx, const crychic_ssao_constants* ssaoCB, const crychic_pass_constants* passCB,
+                          const crychic_frame_desc* f, void* stream_)
+{
+    if (int rc = bind(ctx)) return rc;
+    if (!ssaoCB || !passCB || !f) return fail(CRYCHIC_E_INVALID_ARG, "null argument");
+    if (int rc = check_dims(f->W, f->H)) return rc;
+    const uint32_t W = f->W, H = f->H;
+    if (f->row0 > H || f->rows > H - f->row0 || (f->row0 & 1u) || ((f->rows & 1u) && f->row0 + f->rows != H))
+        return fail(CRYCHIC_E_INVALID_ARG, "strip [%u,+%u) must lie inside the frame and start on an even row", f->row0, f->rows);
+    if (!f->depth_dev || !f->g0_dev || !f->g1_dev || !f->g2_dev || !f->cube_dev || !f->out_rgba8_dev)
+        return fail(CRYCHIC_E_INVALID_ARG, "null plane in frame descriptor");
+    const bool ssaoOn = f->blurCount >= 0;
+    if (ssaoOn && (!f->normal_dev || !f->randvec_dev || !f->ambient0_dev)) return fail(CRYCHIC_E_INVALID_ARG, "SSAO planes missing");
+    hipStream_t stream = (hipStream_t)stream_;
+    cry::LightParams P;
+    if (int rc = fill_light_params(P, passCB, f->shadow_dev, f->shadowDim, f->cubeDim, W, H, f->numDirLights,
+                                   f->pcfSearchRadius, f->flags)) return rc;
+    const bool prof = ctx->profiling;
+    if (prof) { ctx->times_valid = false; CRY_HIP(hipEventRecord(ctx->ev[0], stream)); }
+    if (ssaoOn) {
+        // The lighting pass filters the half-res AO map bilinearly at (about) its own pixel centre
+        // (DeferredShading.hlsl:40-42): rows row0/2 - 1 .. (row0+rows)/2; keep one more row of slack.
+        uint32_t a0, an;
+        clamp_rows(H / 2, (int64_t)(f->row0 / 2) - 2, (int64_t)((f->row0 + f->rows + 1) / 2) + 2, &a0, &an);
+        if (int rc = ssao_compute_impl(ctx, ssaoCB, f->normal_dev, f->depth_dev, f->randvec_dev, f->ambient0_dev,
+                                       f->ambient1_dev, f->edge_dev, W, H, f->blurCount, a0, an, stream,
+                                       prof ? ctx->ev[1] : nullptr)) return rc;
+    } else if (prof) {
+        CRY_HIP(hipEventRecord(ctx->ev[1], stream));
+    }
+    if (prof) CRY_HIP(hipEventRecord(ctx->ev[2], stream));
+    CRY_HIP(cry::launch_light(P, f->g0_dev, f->g1_dev, f->g2_dev, f->depth_dev, ssaoOn ? f->ambient0_dev : nullptr,
+                              f->cube_dev, f->out_rgba8_dev, nullptr, f->row0, f->rows, stream));
+    if (prof) { CRY_HIP(hipEventRecord(ctx->ev[3], stream)); ctx->times_valid = true; }
+    return 0;
+}
+
+int crychic_ctx_set_profiling(crychic_ctx* ctx, int enabled)
+{
+    if (!ctx) return fail(CRYCHIC_E_INVALID_ARG, "null context");
+    ctx->profiling = enabled != 0;
+    ctx->times_valid = false;
+    return 0;
+}
+
+int crychic_ctx_last_pass_times(crychic_ctx* ctx, crychic_pass_times* out)
+{
+    if (int rc = bind(ctx)) return rc;
+    if (!out) return fail(CRYCHIC_E_INVALID_ARG, "out is null");
+    if (!ctx->times_valid) return fail(CRYCHIC_E_INVALID_ARG, "no profiled frame recorded (enable profiling, then draw)");
+    CRY_HIP(hipEventSynchronize(ctx->ev[3]));
+    CRY_HIP(hipEventElapsedTime(&out->ssao_ms, ctx->ev[0], ctx->ev[1]));
+    CRY_HIP(hipEventElapsedTime(&out->blur_ms, ctx->ev[1], ctx->ev[2]));
+    CRY_HIP(hipEventElapsedTime(&out->light_ms, ctx->ev[2], ctx->ev[3]));
+    CRY_HIP(hipEventElapsedTime(&out->total_ms, ctx->ev[0], ctx->ev[3]));
+    return 0;
+}
+
+int crychic_strip_rows(uint32_t H, int nranks, int rank, uint32_t* row0, uint32_t* rows)
+{
+    if (!row0 || !rows || nranks <= 0 || rank < 0 || rank >= nranks || (H & 1u))
+        return fail(CRYCHIC_E_INVALID_ARG, "bad strip request (H=%u nranks=%d rank=%d)", H, nranks, rank);
+    const uint32_t pairs = H / 2;                    // strips are whole half-res rows
+    const uint32_t per = pairs / (uint32_t)nranks;   // last rank takes the remainder
+    const uint32_t p0 = per * (uint32_t)rank;
+    const uint32_t p1 = (rank == nranks - 1) ? pairs : p0 + per;
+    *row0 = 2 * p0;
+    *rows = 2 * (p1 - p0);
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,190 @@
+// devmath.hpp -- arithmetic building blocks of the CRYCHIC hot-path kernels (gfx950).
+//
+// Every function is plain IEEE-754 binary32 with a fixed evaluation order; the translation units that
+// include this header are built with -ffp-contract=off so the compiler never fuses a*b+c.  The only fused
+// operations are the explicit fmaf() calls of the UNORM decoders below, which are proven (exhaustively, on
+// the host, tests/test_devmath_host.py) to equal the correctly rounded integer/constant divisions that D3D
+// format conversion specifies.  Transcendentals follow the fixed polynomial recurrences documented in
+// DESIGN.md ("deterministic transcendentals"), so results do not depend on a vendor math library.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#define CRY_HD __host__ __device__ __forceinline__
+#else
+#define CRY_HD inline
+#endif
+
+namespace cry {
+
+struct f3 { float x, y, z; };
+struct f4 { float x, y, z, w; };
+struct alignas(8) u2 { uint32_t x, y; };
+struct alignas(16) u4 { uint32_t x, y, z, w; };
+struct alignas(16) f4a { float x, y, z, w; };
+
+CRY_HD uint32_t f2u(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
+CRY_HD float u2f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
+
+CRY_HD float saturate(float x) { return (x > 0.0f) ? ((x < 1.0f) ? x : 1.0f) : 0.0f; }
+CRY_HD float maxnn(float x, float c) { return (x > c) ? x : c; }            // HLSL max(): NaN loses
+CRY_HD float signf(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }
+CRY_HD float lerpf(float a, float b, float t) { return a + t * (b - a); }
+CRY_HD float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+CRY_HD f3 normalize3(f3 v)
+{
+    float inv = 1.0f / __builtin_sqrtf(dot3(v, v));
+    return f3{ v.x * inv, v.y * inv, v.z * inv };
+}
+CRY_HD f3 reflect3(f3 i, f3 n)
+{
+    float d2 = 2.0f * dot3(n, i);
+    return f3{ i.x - d2 * n.x, i.y - d2 * n.y, i.z - d2 * n.z };
+}
+// HLSL mul(float4(v), M) for a matrix stored transposed (the reference's cbuffer layout): column j of the
+// row-vector matrix is mem[4j .. 4j+3].
+CRY_HD float mulcol(float x, float y, float z, float w, const float* col)
+{
+    return ((x * col[0] + y * col[1]) + z * col[2]) + w * col[3];
+}
+
+// ---- format decoders -------------------------------------------------------------------------------
+// D24 -> float == (float)u / 16777215.0f for every u in [0, 2^24): q = u * 2^-24 is exact and the quotient
+// is q * (1 + 2^-24 + ...), i.e. q plus a correction strictly between 0.5 and 1 ulp(q), so the correctly
+// rounded result is the next float above q.
+CRY_HD float d24_to_float(uint32_t texel)
+{
+    uint32_t u = texel & 0x00FFFFFFu;
+    float q = (float)u * 5.9604644775390625e-8f;
+    return u ? u2f(f2u(q) + 1u) : 0.0f;
+}
+// u / 65535.0f and u / 255.0f, correctly rounded, via one reciprocal multiply and one residual correction.
+CRY_HD float unorm16_to_float(uint32_t u)
+{
+    const float c = 1.0f / 65535.0f;
+    float a = (float)u;
+    float t = a * c;
+    float r = __builtin_fmaf(-t, 65535.0f, a);
+    return __builtin_fmaf(r, c, t);
+}
+CRY_HD float unorm8_to_float(uint32_t u)
+{
+    const float c = 1.0f / 255.0f;
+    float a = (float)u;
+    float t = a * c;
+    float r = __builtin_fmaf(-t, 255.0f, a);
+    return __builtin_fmaf(r, c, t);
+}
+CRY_HD uint32_t float_to_unorm16(float x) { return (uint32_t)(saturate(x) * 65535.0f + 0.5f); }
+CRY_HD uint32_t float_to_unorm8(float x) { return (uint32_t)(saturate(x) * 255.0f + 0.5f); }
+
+CRY_HD float half_to_float(uint16_t h)
+{
+    _Float16 v;
+    __builtin_memcpy(&v, &h, 2);
+    return (float)v;
+}
+
+// ---- deterministic transcendentals -------------------------------------------------------------------
+// sin/cos: 3-term Cody-Waite reduction by pi/2, degree-7 / degree-8 kernels on [-pi/4, pi/4].
+CRY_HD float det_sincos(float x, int want_cos)
+{
+    float ax = __builtin_fabsf(x);
+    if (!(ax < 8388608.0f)) return x - x;
+    float k = __builtin_rintf(x * 0.636619772367581343f);
+    float r = x - k * 1.5703125f;
+    r = r - k * 4.837512969970703125e-4f;
+    r = r - k * 7.54978995489188216e-8f;
+    int q = ((int)k + want_cos) & 3;
+    float r2 = r * r;
+    float s = ((-1.9515295891e-4f * r2 + 8.3321608736e-3f) * r2 - 1.6666654611e-1f) * r2 * r + r;
+    float c = ((2.443315711809948e-5f * r2 - 1.388731625493765e-3f) * r2 + 4.166664568298827e-2f) * r2 * r2
+              - 0.5f * r2 + 1.0f;
+    float v = (q & 1) ? c : s;
+    return (q & 2) ? -v : v;
+}
+CRY_HD float det_sin(float x) { return det_sincos(x, 0); }
+CRY_HD float det_cos(float x) { return det_sincos(x, 1); }
+
+CRY_HD float det_log2(float x)
+{
+    if (x != x) return x;
+    if (x < 0.0f) return u2f(0x7FC00000u);
+    if (x == 0.0f) return u2f(0xFF800000u);
+    if (x == u2f(0x7F800000u)) return x;
+    uint32_t u = f2u(x);
+    int e = (int)(u >> 23) - 126;
+    if ((u >> 23) == 0) {
+        x = x * 16777216.0f;
+        u = f2u(x);
+        e = (int)(u >> 23) - 126 - 24;
+    }
+    float m = u2f((u & 0x007FFFFFu) | 0x3F000000u);
+    if (m < 0.70710678118654752440f) { e -= 1; m = m + m - 1.0f; }
+    else { m = m - 1.0f; }
+    float z = m * m;
+    float y = ((((((((7.0376836292e-2f * m - 1.1514610310e-1f) * m + 1.1676998740e-1f) * m - 1.2420140846e-1f) * m
+                  + 1.4249322787e-1f) * m - 1.6668057665e-1f) * m + 2.0000714765e-1f) * m - 2.4999993993e-1f) * m
+               + 3.3333331174e-1f) * m * z;
+    y = y - 0.5f * z;
+    float r = y * 0.44269504088896340735992f;
+    r = r + m * 0.44269504088896340735992f;
+    r = r + y;
+    r = r + m;
+    r = r + (float)e;
+    return r;
+}
+
+CRY_HD float det_exp2(float x)
+{
+    if (x != x) return x;
+    if (x >= 128.0f) return u2f(0x7F800000u);
+    if (x < -126.0f) return 0.0f;
+    float n = __builtin_floorf(x + 0.5f);
+    float f = x - n;
+    float p = (((((1.535336188319500e-4f * f + 1.339887440266574e-3f) * f + 9.618437357674640e-3f) * f
+                 + 5.550332471162809e-2f) * f + 2.402264791363012e-1f) * f + 6.931472028550421e-1f) * f + 1.0f;
+    int ni = (int)n;
+    if (ni > 127) { p = p * 2.0f; ni = 127; }
+    return p * u2f((uint32_t)(ni + 127) << 23);
+}
+
+CRY_HD float det_pow(float x, float y)
+{
+    if (x != x) return x;
+    if (x < 0.0f) return u2f(0x7FC00000u);
+    if (x == 0.0f) return 0.0f;
+    return det_exp2(y * det_log2(x));
+}
+
+// ---- bilinear addressing --------------------------------------------------------------
+struct Bilin { int i0, j0; float fx, fy; };
+
+CRY_HD int texel_index(float fl, uint32_t dim)
+{
+    if (!(fl >= -2.0f)) return -2;
+    if (fl > (float)dim + 1.0f) return (int)dim + 1;
+    return (int)fl;
+}
+CRY_HD Bilin bilinear_setup(float u, float v, uint32_t w, uint32_t h)
+{
+    Bilin b;
+    float tx = u * (float)w - 0.5f;
+    float ty = v * (float)h - 0.5f;
+    float flx = __builtin_floorf(tx), fly = __builtin_floorf(ty);
+    b.fx = tx - flx;
+    b.fy = ty - fly;
+    b.i0 = texel_index(flx, w);
+    b.j0 = texel_index(fly, h);
+    if (!(b.fx == b.fx) || !(b.fy == b.fy)) { b.i0 = -2; b.j0 = -2; b.fx = 0.0f; b.fy = 0.0f; }
+    return b;
+}
+CRY_HD float bilerp(float t00, float t10, float t01, float t11, float fx, float fy)
+{
+    float top = lerpf(t00, t10, fx);
+    float bot = lerpf(t01, t11, fx);
+    return lerpf(top, bot, fy);
+}
+CRY_HD int clampi(int i, int lo, int hi) { return i < lo ? lo : (i > hi ? hi : i); }
+
+}  // namespace cry

@@ -1,0 +1,22 @@
+// kernels.hpp -- launcher interface between the C ABI (api.cpp) and the gfx950 kernels (kernels.hip).
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include "crychic_hip.h"
+
+namespace cry {
+
+struct LightParams;
+
+hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, const uint32_t* depth,
+                       const uint8_t* randvec, uint16_t* ambient, void* edge_base, uint32_t W, uint32_t H,
+                       uint32_t row0, uint32_t rows, bool emit_ao, hipStream_t stream);
+
+hipError_t launch_blur(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out,
+                       uint32_t W, uint32_t H, bool horizontal, uint32_t row0, uint32_t rows, hipStream_t stream);
+
+hipError_t launch_light(const LightParams& P, const float* g0, const float* g1, const float* g2,
+                        const uint32_t* depth, const uint16_t* ambient, const uint8_t* cube, uint8_t* out,
+                        float* radiance, uint32_t row0, uint32_t rows, hipStream_t stream);
+
+}  // namespace cry

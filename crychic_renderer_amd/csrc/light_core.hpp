@@ -1,0 +1,269 @@
+// light_core.hpp -- per-pixel body of the deferred lighting kernel: Shaders/DeferredShading.hlsl:23-101 with
+// GBuffer.hlsl:33-43, PBR.hlsl:4-107, LightingUtil.hlsl:52-60 and the rotated-Poisson cascade PCF of
+// Common.hlsl:167-183,263-317.  The reference's quirks are reproduced, not fixed.
+#pragma once
+#include "devmath.hpp"
+#include "crychic_hip.h"
+
+namespace cry {
+
+// The subset of cbPass (Common.hlsl:82-107) the pixel shader reads, in the reference's transposed layout.
+struct LightParams {
+    float ViewProjTex[16];
+    float ShadowTransforms[4][16];
+    float InvProj[16];
+    float InvView[16];
+    float EyePosW[3];
+    float pcfSearchRadius;
+    float AmbientLight[4];
+    crychic_light Lights[CRYCHIC_MAX_LIGHTS];
+    const uint32_t* shadow[4];
+    uint32_t shadowDim;
+    uint32_t cubeDim;
+    uint32_t W, H;
+    int numDirLights;
+    uint32_t flags;
+};
+
+// Common.hlsl:167-171 (noise is a scalar broadcast, so abs(noise.x + noise.y) * 0.5 == noise)
+CRY_HD float nrand(float u, float v)
+{
+    float d = u * (12.9898f * 2.0f) + v * (78.233f * 2.0f);
+    float s = det_sin(d) * 43758.5453f;
+    float noise = s - __builtin_floorf(s);
+    return __builtin_fabsf(noise + noise) * 0.5f;
+}
+
+// gsamShadow: LESS_EQUAL comparison on each texel, then bilinear; BORDER colour 0  (CRYCHIC.cpp:2649-2658)
+CRY_HD float shadow_texel_cmp(const uint32_t* __restrict__ s, uint32_t dim, int x, int y, float ref)
+{
+    bool in = ((uint32_t)x < dim) & ((uint32_t)y < dim);
+    float t = in ? d24_to_float(s[(uint32_t)y * dim + (uint32_t)x]) : 0.0f;
+    return (ref <= t) ? 1.0f : 0.0f;
+}
+CRY_HD float shadow_cmp_linear(const uint32_t* __restrict__ s, uint32_t dim, float u, float v, float ref)
+{
+    Bilin b = bilinear_setup(u, v, dim, dim);
+    float c00 = shadow_texel_cmp(s, dim, b.i0, b.j0, ref);
+    float c10 = shadow_texel_cmp(s, dim, b.i0 + 1, b.j0, ref);
+    float c01 = shadow_texel_cmp(s, dim, b.i0, b.j0 + 1, ref);
+    float c11 = shadow_texel_cmp(s, dim, b.i0 + 1, b.j0 + 1, ref);
+    return bilerp(c00, c10, c01, c11, b.fx, b.fy);
+}
+
+// Common.hlsl:173-183, interleaved x,y
+#define CRY_POISSON_TABLE                                                                                         \
+    { -0.94201624f, -0.39906216f, 0.94558609f, -0.76890725f, -0.094184101f, -0.92938870f, 0.34495938f, 0.29387760f, \
+      -0.91588581f, 0.45771432f, -0.81544232f, -0.87912464f, -0.38277543f, 0.27676845f, 0.97484398f, 0.75648379f,   \
+      0.44323325f, -0.97511554f, 0.53742981f, -0.47373420f, -0.26496911f, -0.41893023f, 0.79197514f, 0.19090188f,   \
+      -0.24188840f, 0.99706507f, -0.81409955f, 0.91437590f, 0.19984126f, 0.78641367f, 0.14383161f, -0.14100790f }
+
+// CalcCascadeShadowFactorWithPoisson  Common.hlsl:263-317
+CRY_HD float pcf_poisson(const uint32_t* __restrict__ s, uint32_t dim, float spx, float spy, float spz, float spw,
+                         float radius)
+{
+    const float x = spx / spw, y = spy / spw, depth = spz / spw;  // :266-269
+    float percentLit = 0.0f;
+    if (radius == 0.0f) {
+        // Common.hlsl:305 as written (uint division) gives radius 0: every one of the 16 taps is
+        // uv + (+-0) == uv, so one filtered fetch is accumulated 16 times -- bit-identical to the loop.
+        const float tap = shadow_cmp_linear(s, dim, x, y, depth);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) percentLit += tap;
+    } else {
+        const float theta = nrand(x, y);                          // :301
+        const float c = det_cos(theta), sn = det_sin(theta);      // :302-303
+        const float P[32] = CRY_POISSON_TABLE;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {                            // :308
+            const float px = P[2 * i] * c + P[2 * i + 1] * (-sn); // mul(poissonDisk[i], float2x2(c, s, -s, c))
+            const float py = P[2 * i] * sn + P[2 * i + 1] * c;
+            percentLit += shadow_cmp_linear(s, dim, x + px * radius, y + py * radius, depth);  // :311-313
+        }
+    }
+    return percentLit / 16.0f;                                    // :315
+}
+
+CRY_HD float pow5(float x) { float x2 = x * x, x4 = x2 * x2; return x4 * x; }
+
+#define CRY_PBR_PI 3.1415926f  // PBR.hlsl:2
+
+// One directional light of PBRShading (PBR.hlsl:99-106) with GetPBRDesc (:72-88) and GetBRDF (:45-70).
+CRY_HD void pbr_dir_light(const crychic_light& L, f3 albedo, float roughness, float metalness, f3 normal, f3 view,
+                          float shadow, f3& result)
+{
+    const f3 lightDir{ -L.Direction[0], -L.Direction[1], -L.Direction[2] };
+    const f3 halfVec = normalize3(f3{ view.x + lightDir.x, view.y + lightDir.y, view.z + lightDir.z });
+    const float hDotv = maxnn(dot3(halfVec, view), 0.001f);
+    const float nDotl = maxnn(dot3(normal, lightDir), 0.001f);
+    const float nDotv = maxnn(dot3(normal, view), 0.001f);
+    const float nDotvQ = hDotv;  // PBR.hlsl:58 (Q3)
+
+    // NDF_GGX :4-14
+    const float a2 = roughness * roughness;
+    const float nDoth = maxnn(dot3(normal, halfVec), 0.001f);
+    const float tt = (nDoth * nDoth) * (a2 - 1.0f) + 1.0f;
+    const float D = a2 * (1.0f / (CRY_PBR_PI * (tt * tt)));
+    // FresnelSchlick :40-43
+    const float fr = pow5(saturate(1.0f - nDotvQ));
+    // GeometrySmith :29-38 (true nDotv)
+    const float k = 0.125f * (roughness + 1.0f) * (roughness + 1.0f);
+    const float G = (nDotv / (nDotv * (1.0f - k) + k)) * (nDotl / (nDotl * (1.0f - k) + k));
+    const float s5 = pow5(shadow);  // :105
+    const float denom = nDotl * nDotvQ;
+    const float invPi = 1.0f / CRY_PBR_PI;
+    const float oneMinusMetal = 1.0f - metalness;
+
+    const float alb[3] = { albedo.x, albedo.y, albedo.z };
+    float res[3] = { result.x, result.y, result.z };
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+        const float f0 = lerpf(0.04f, alb[ch], metalness);
+        const float F = f0 + (1.0f - f0) * fr;
+        float fs = 0.25f * D * G * F;
+        fs = fs / denom;
+        const float fd = alb[ch] * invPi;
+        const float kd = (1.0f - F) * oneMinusMetal;
+        const float brdf = kd * fd + F * fs;  // ks = F (Q4)
+        const float irradiance = L.Strength[ch] * nDotl;
+        res[ch] += s5 * brdf * irradiance;
+    }
+    result = f3{ res[0], res[1], res[2] };
+}
+
+// TextureCube.Sample(gsamLinearWrap, r): D3D major-axis face selection (ties x >= y >= z), bilinear inside the
+// face with clamp-to-edge.  Faces +X,-X,+Y,-Y,+Z,-Z, RGBA8.
+CRY_HD f4 cube_linear(const uint32_t* __restrict__ cube, uint32_t dim, f3 r)
+{
+    const float ax = __builtin_fabsf(r.x), ay = __builtin_fabsf(r.y), az = __builtin_fabsf(r.z);
+    uint32_t face; float sc, tc, ma;
+    if (ax >= ay && ax >= az) { ma = ax; if (r.x >= 0.0f) { face = 0; sc = -r.z; tc = -r.y; } else { face = 1; sc = r.z; tc = -r.y; } }
+    else if (ay >= az)        { ma = ay; if (r.y >= 0.0f) { face = 2; sc = r.x; tc = r.z; } else { face = 3; sc = r.x; tc = -r.z; } }
+    else                      { ma = az; if (r.z >= 0.0f) { face = 4; sc = r.x; tc = -r.y; } else { face = 5; sc = -r.x; tc = -r.y; } }
+    const float u = 0.5f * (sc / ma + 1.0f);
+    const float v = 0.5f * (tc / ma + 1.0f);
+    const Bilin b = bilinear_setup(u, v, dim, dim);
+    const uint32_t x0 = (uint32_t)clampi(b.i0, 0, (int)dim - 1), x1 = (uint32_t)clampi(b.i0 + 1, 0, (int)dim - 1);
+    const uint32_t y0 = (uint32_t)clampi(b.j0, 0, (int)dim - 1), y1 = (uint32_t)clampi(b.j0 + 1, 0, (int)dim - 1);
+    const uint32_t* f = cube + face * dim * dim;
+    const uint32_t t00 = f[y0 * dim + x0], t10 = f[y0 * dim + x1], t01 = f[y1 * dim + x0], t11 = f[y1 * dim + x1];
+    f4 o;
+    o.x = bilerp(unorm8_to_float(t00 & 255u), unorm8_to_float(t10 & 255u), unorm8_to_float(t01 & 255u),
+                 unorm8_to_float(t11 & 255u), b.fx, b.fy);
+    o.y = bilerp(unorm8_to_float((t00 >> 8) & 255u), unorm8_to_float((t10 >> 8) & 255u),
+                 unorm8_to_float((t01 >> 8) & 255u), unorm8_to_float((t11 >> 8) & 255u), b.fx, b.fy);
+    o.z = bilerp(unorm8_to_float((t00 >> 16) & 255u), unorm8_to_float((t10 >> 16) & 255u),
+                 unorm8_to_float((t01 >> 16) & 255u), unorm8_to_float((t11 >> 16) & 255u), b.fx, b.fy);
+    o.w = bilerp(unorm8_to_float(t00 >> 24), unorm8_to_float(t10 >> 24), unorm8_to_float(t01 >> 24),
+                 unorm8_to_float(t11 >> 24), b.fx, b.fy);
+    return o;
+}
+
+// gsamLinearClamp on the half-res R16_UNORM ambient map  (CRYCHIC.cpp:2624-2629)
+CRY_HD float ambient_linear_clamp(const uint16_t* __restrict__ a, uint32_t w2, uint32_t h2, float u, float v)
+{
+    const Bilin b = bilinear_setup(u, v, w2, h2);
+    const uint32_t x0 = (uint32_t)clampi(b.i0, 0, (int)w2 - 1), x1 = (uint32_t)clampi(b.i0 + 1, 0, (int)w2 - 1);
+    const uint32_t y0 = (uint32_t)clampi(b.j0, 0, (int)h2 - 1), y1 = (uint32_t)clampi(b.j0 + 1, 0, (int)h2 - 1);
+    return bilerp(unorm16_to_float(a[y0 * w2 + x0]), unorm16_to_float(a[y0 * w2 + x1]),
+                  unorm16_to_float(a[y1 * w2 + x0]), unorm16_to_float(a[y1 * w2 + x1]), b.fx, b.fy);
+}
+
+// DeferredShading.hlsl:23-101 for one covered pixel.
+CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16_t* __restrict__ ambient,
+                      const uint32_t* __restrict__ cube)
+{
+    const f3 posW{ G0.x, G0.y, G0.z };                         // GBuffer.hlsl:37-41
+    const float metalness = G0.w;
+    const f3 albedo{ G1.x, G1.y, G1.z };
+    const float roughness = G1.w;
+    const f3 normalW = normalize3(f3{ G2.x, G2.y, G2.z });
+
+    const f3 toEye{ P.EyePosW[0] - posW.x, P.EyePosW[1] - posW.y, P.EyePosW[2] - posW.z };
+    const f3 view = normalize3(toEye);                          // :32
+    const f3 R0{ lerpf(0.04f, albedo.x, metalness), lerpf(0.04f, albedo.y, metalness),
+                 lerpf(0.04f, albedo.z, metalness) };           // :35
+
+    float ambientAccess = 1.0f;
+    if (ambient) {                                              // :40-42
+        const float sx = mulcol(posW.x, posW.y, posW.z, 1.0f, P.ViewProjTex + 0);
+        const float sy = mulcol(posW.x, posW.y, posW.z, 1.0f, P.ViewProjTex + 4);
+        const float sw = mulcol(posW.x, posW.y, posW.z, 1.0f, P.ViewProjTex + 12);
+        ambientAccess = ambient_linear_clamp(ambient, P.W / 2, P.H / 2, sx / sw, sy / sw);
+    }
+    const f3 amb{ ambientAccess * P.AmbientLight[0] * albedo.x, ambientAccess * P.AmbientLight[1] * albedo.y,
+                  ambientAccess * P.AmbientLight[2] * albedo.z };  // :44
+
+    // :53-76  cascade selection.  `abs(distance - radius[j] < 5.0f)` is abs(bool) (Q1), true whenever
+    // distance < radius[j]: every pixel nearer than 80 blends cascades j and j+1.
+    float shadow0 = 1.0f;
+    const float distance = __builtin_sqrtf(dot3(toEye, toEye));
+    int j = 4;
+    if (distance < 30.0f) j = 0;
+    else if (distance < 50.0f) j = 1;
+    else if (distance < 80.0f) j = 2;
+    else if (distance < 100.0f) j = 3;
+    if (j < 4) {
+        const float* T0 = P.ShadowTransforms[j];
+        const uint32_t* s0 = P.shadow[j];
+        const float a = pcf_poisson(s0, P.shadowDim, mulcol(posW.x, posW.y, posW.z, 1.0f, T0 + 0),
+                                    mulcol(posW.x, posW.y, posW.z, 1.0f, T0 + 4),
+                                    mulcol(posW.x, posW.y, posW.z, 1.0f, T0 + 8),
+                                    mulcol(posW.x, posW.y, posW.z, 1.0f, T0 + 12), P.pcfSearchRadius);
+        if (j < 3) {
+            const float* T1 = P.ShadowTransforms[j + 1];
+            const uint32_t* s1 = P.shadow[j + 1];
+            const float b = pcf_poisson(s1, P.shadowDim, mulcol(posW.x, posW.y, posW.z, 1.0f, T1 + 0),
+                                        mulcol(posW.x, posW.y, posW.z, 1.0f, T1 + 4),
+                                        mulcol(posW.x, posW.y, posW.z, 1.0f, T1 + 8),
+                                        mulcol(posW.x, posW.y, posW.z, 1.0f, T1 + 12), P.pcfSearchRadius);
+            shadow0 = 0.5f * (a + b);                           // :66
+        } else {
+            shadow0 = a;                                        // :73
+        }
+    }
+
+    const float shininess = (1.0f - roughness) * 1.0f;          // :84 (normalW.a == 1)
+
+    f3 direct{ 0.0f, 0.0f, 0.0f };
+    for (int i = 0; i < P.numDirLights; ++i)                    // PBR.hlsl:99-106; shadowFactors[i>0] == 1 (:46-51)
+        pbr_dir_light(P.Lights[i], albedo, roughness, metalness, normalW, view, i == 0 ? shadow0 : 1.0f, direct);
+
+    const float invGamma = 1.0f / 2.2f;
+    f4 lit;
+    lit.x = det_pow(direct.x / (direct.x + 1.0f), invGamma) + amb.x;  // :89-92
+    lit.y = det_pow(direct.y / (direct.y + 1.0f), invGamma) + amb.y;
+    lit.z = det_pow(direct.z / (direct.z + 1.0f), invGamma) + amb.z;
+
+    const f3 r = reflect3(f3{ -view.x, -view.y, -view.z }, normalW);  // :94
+    const f4 refl = cube_linear(cube, P.cubeDim, r);            // :95
+    const float f0 = 1.0f - saturate(dot3(normalW, r));         // LightingUtil.hlsl:54-57
+    const float f5 = f0 * f0 * f0 * f0 * f0;
+    lit.x += shininess * (R0.x + (1.0f - R0.x) * f5) * refl.x;  // :97
+    lit.y += shininess * (R0.y + (1.0f - R0.y) * f5) * refl.y;
+    lit.z += shininess * (R0.z + (1.0f - R0.z) * f5) * refl.z;
+    lit.w = 1.0f;                                               // :99
+    return lit;
+}
+
+// sky.hlsl:21-47 for an uncovered pixel: cubemap lookup along the pixel's view ray.
+CRY_HD f4 sky_pixel(const LightParams& P, const uint32_t* __restrict__ cube, uint32_t x, uint32_t y)
+{
+    const float u = ((float)x + 0.5f) / (float)P.W, v = ((float)y + 0.5f) / (float)P.H;
+    const float hx = 2.0f * u - 1.0f, hy = 1.0f - 2.0f * v;
+    const float phx = mulcol(hx, hy, 0.0f, 1.0f, P.InvProj + 0);
+    const float phy = mulcol(hx, hy, 0.0f, 1.0f, P.InvProj + 4);
+    const float phz = mulcol(hx, hy, 0.0f, 1.0f, P.InvProj + 8);
+    const float phw = mulcol(hx, hy, 0.0f, 1.0f, P.InvProj + 12);
+    const float vx = phx / phw, vy = phy / phw, vz = phz / phw;
+    const f3 d{ mulcol(vx, vy, vz, 0.0f, P.InvView + 0), mulcol(vx, vy, vz, 0.0f, P.InvView + 4),
+                mulcol(vx, vy, vz, 0.0f, P.InvView + 8) };
+    return cube_linear(cube, P.cubeDim, d);
+}
+
+CRY_HD uint32_t pack_rgba8(f4 c)
+{
+    return float_to_unorm8(c.x) | (float_to_unorm8(c.y) << 8) | (float_to_unorm8(c.z) << 16) | (float_to_unorm8(c.w) << 24);
+}
+
+}  // namespace cry

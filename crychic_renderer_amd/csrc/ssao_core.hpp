@@ -1,0 +1,214 @@
+// ssao_core.hpp -- per-pixel bodies of the SSAO and bilateral-blur kernels (Shaders/Ssao.hlsl:117-199,
+// Shaders/SsaoBlur.hlsl:85-146).  Host+device inline so the same text is checked on the CPU against the
+// oracle (tests/hostsim) before it ever runs on a GPU.
+#pragma once
+#include "devmath.hpp"
+#include "crychic_hip.h"
+
+namespace cry {
+
+// ---- edge workspace ------------------------------------------------------------------------------------
+// Everything a blur tap needs besides the ambient value is a function of the half-res pixel only
+// (SsaoBlur.hlsl:109-111,121-123): the point-sampled normal and the linearised bilinear depth.  The SSAO
+// kernel already computes both for its own pixel, so it stores them once per frame:
+//   nrm  [h2][w2]  8 B  (the fp16 texel (2x+1, 2y+1) verbatim)
+//   vz   [h2][w2]  4 B  (view-space depth, fp32)
+//   gcol [h2]      8 B  normal texel (0, 2y+1): CLAMP target of every horizontal tap with x + i < 0
+//   grow [w2]      8 B  normal texel (2x+1, 0): CLAMP target of every vertical tap with y + i < 0
+struct EdgePlane {
+    u2* nrm;
+    float* vz;
+    u2* gcol;
+    u2* grow;
+};
+CRY_HD size_t edge_plane_bytes(uint32_t W, uint32_t H)
+{
+    size_t w2 = W / 2, h2 = H / 2;
+    return w2 * h2 * 12 + (w2 + h2) * 8;
+}
+CRY_HD EdgePlane edge_plane_carve(void* base, uint32_t W, uint32_t H)
+{
+    size_t w2 = W / 2, h2 = H / 2, n = w2 * h2;
+    EdgePlane e;
+    e.nrm = (u2*)base;
+    e.vz = (float*)((char*)base + n * 8);
+    e.gcol = (u2*)((char*)base + n * 12);
+    e.grow = e.gcol + h2;
+    return e;
+}
+
+CRY_HD f3 unpack_normal(u2 t)
+{
+    return f3{ half_to_float((uint16_t)(t.x & 0xFFFFu)), half_to_float((uint16_t)(t.x >> 16)),
+               half_to_float((uint16_t)(t.y & 0xFFFFu)) };
+}
+
+// Ssao.hlsl:110-115; HLSL gProj[r][c] is mem[4c + r] in the transposed cbuffer layout.
+CRY_HD float ndc_to_view(const crychic_ssao_constants& cb, float z_ndc)
+{
+    return cb.Proj[4 * 2 + 3] / (z_ndc - cb.Proj[4 * 2 + 2]);
+}
+
+// gsamDepthMap: linear filter, BORDER (1.0) addressing  (CRYCHIC.cpp:1057-1066)
+CRY_HD float depth_texel(const uint32_t* __restrict__ depth, uint32_t W, uint32_t H, int x, int y)
+{
+    bool in = ((uint32_t)x < W) & ((uint32_t)y < H);
+    return in ? d24_to_float(depth[(uint32_t)y * W + (uint32_t)x]) : 1.0f;
+}
+CRY_HD float depth_linear_border(const uint32_t* __restrict__ depth, uint32_t W, uint32_t H, float u, float v)
+{
+    Bilin b = bilinear_setup(u, v, W, H);
+    float t00 = depth_texel(depth, W, H, b.i0, b.j0);
+    float t10 = depth_texel(depth, W, H, b.i0 + 1, b.j0);
+    float t01 = depth_texel(depth, W, H, b.i0, b.j0 + 1);
+    float t11 = depth_texel(depth, W, H, b.i0 + 1, b.j0 + 1);
+    return bilerp(t00, t10, t01, t11, b.fx, b.fy);
+}
+// The same sampler at the centre of half-res pixel (xi, yi) (even W, H): texels 2xi..2xi+1 x 2yi..2yi+1 with
+// weights 1/2; a pixel outside the half-res map only ever addresses border texels.
+CRY_HD float depth_at_half_pixel(const uint32_t* __restrict__ depth, uint32_t W, uint32_t H, int xi, int yi)
+{
+    float t00 = depth_texel(depth, W, H, 2 * xi, 2 * yi);
+    float t10 = depth_texel(depth, W, H, 2 * xi + 1, 2 * yi);
+    float t01 = depth_texel(depth, W, H, 2 * xi, 2 * yi + 1);
+    float t11 = depth_texel(depth, W, H, 2 * xi + 1, 2 * yi + 1);
+    return bilerp(t00, t10, t01, t11, 0.5f, 0.5f);
+}
+
+// gsamPointClamp on the full-res normal map at the centre of half-res pixel (xi, yi): texel
+// clamp(2xi+1), clamp(2yi+1) (the texel-edge tie is resolved as floor).
+CRY_HD u2 normal_texel_bits(const u2* __restrict__ normal, uint32_t W, uint32_t H, int xi, int yi)
+{
+    int tx = clampi(2 * xi + 1, 0, (int)W - 1);
+    int ty = clampi(2 * yi + 1, 0, (int)H - 1);
+    return normal[(uint32_t)ty * W + (uint32_t)tx];
+}
+
+// gsamLinearWrap on the 256x256 RGBA8 random-vector map  (CRYCHIC.cpp:1068-1073)
+CRY_HD f3 randvec_linear_wrap(const uint32_t* __restrict__ rv, float u, float v)
+{
+    float uw = u - __builtin_floorf(u), vw = v - __builtin_floorf(v);
+    Bilin b = bilinear_setup(uw, vw, 256, 256);
+    uint32_t x0 = (uint32_t)b.i0 & 255u, x1 = (uint32_t)(b.i0 + 1) & 255u;
+    uint32_t y0 = (uint32_t)b.j0 & 255u, y1 = (uint32_t)(b.j0 + 1) & 255u;
+    uint32_t t00 = rv[y0 * 256 + x0], t10 = rv[y0 * 256 + x1], t01 = rv[y1 * 256 + x0], t11 = rv[y1 * 256 + x1];
+    f3 o;
+    o.x = bilerp(unorm8_to_float(t00 & 255u), unorm8_to_float(t10 & 255u), unorm8_to_float(t01 & 255u),
+                 unorm8_to_float(t11 & 255u), b.fx, b.fy);
+    o.y = bilerp(unorm8_to_float((t00 >> 8) & 255u), unorm8_to_float((t10 >> 8) & 255u),
+                 unorm8_to_float((t01 >> 8) & 255u), unorm8_to_float((t11 >> 8) & 255u), b.fx, b.fy);
+    o.z = bilerp(unorm8_to_float((t00 >> 16) & 255u), unorm8_to_float((t10 >> 16) & 255u),
+                 unorm8_to_float((t01 >> 16) & 255u), unorm8_to_float((t11 >> 16) & 255u), b.fx, b.fy);
+    return o;
+}
+
+struct SsaoCentre {
+    u2 nrm_bits;  // raw fp16 normal texel
+    float vz;        // linear view depth at the pixel centre
+};
+
+CRY_HD SsaoCentre ssao_centre(const crychic_ssao_constants& cb, const u2* __restrict__ normal,
+                              const uint32_t* __restrict__ depth, uint32_t W, uint32_t H, int x, int y)
+{
+    SsaoCentre c;
+    c.nrm_bits = normal_texel_bits(normal, W, H, x, y);
+    c.vz = ndc_to_view(cb, depth_at_half_pixel(depth, W, H, x, y));
+    return c;
+}
+
+// Ssao.hlsl:117-199 for half-res pixel (x, y); returns the R16_UNORM ambient value.
+CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c,
+                           const uint32_t* __restrict__ depth, const uint32_t* __restrict__ randvec, uint32_t W,
+                           uint32_t H, uint32_t x, uint32_t y)
+{
+    const uint32_t w2 = W / 2, h2 = H / 2;
+    const float u = ((float)x + 0.5f) / (float)w2;
+    const float v = ((float)y + 0.5f) / (float)h2;
+
+    // VS :58-72 evaluated at the pixel centre
+    const float hx = 2.0f * u - 1.0f, hy = 1.0f - 2.0f * v;
+    const float phx = mulcol(hx, hy, 0.0f, 1.0f, cb.InvProj + 0);
+    const float phy = mulcol(hx, hy, 0.0f, 1.0f, cb.InvProj + 4);
+    const float phz = mulcol(hx, hy, 0.0f, 1.0f, cb.InvProj + 8);
+    const float phw = mulcol(hx, hy, 0.0f, 1.0f, cb.InvProj + 12);
+    const f3 PosV{ phx / phw, phy / phw, phz / phw };
+
+    const f3 n = normalize3(unpack_normal(c.nrm_bits));   // :125
+    const float pz = c.vz;                                // :126-127
+    const float t = pz / PosV.z;                          // :135
+    const f3 p{ t * PosV.x, t * PosV.y, t * PosV.z };
+
+    const f3 rv = randvec_linear_wrap(randvec, 4.0f * u, 4.0f * v);  // :138
+    const f3 randVec{ 2.0f * rv.x - 1.0f, 2.0f * rv.y - 1.0f, 2.0f * rv.z - 1.0f };
+
+    const float eps = cb.SurfaceEpsilon, fadeEnd = cb.OcclusionFadeEnd;
+    const float fadeLength = cb.OcclusionFadeEnd - cb.OcclusionFadeStart;  // :100
+
+    float occlusionSum = 0.0f;
+#pragma unroll 2
+    for (int i = 0; i < 14; ++i) {
+        const f3 o{ cb.OffsetVectors[i][0], cb.OffsetVectors[i][1], cb.OffsetVectors[i][2] };
+        const f3 offset = reflect3(o, randVec);                                  // :148
+        const float fr = signf(dot3(offset, n)) * cb.OcclusionRadius;            // :151,154
+        const f3 q{ p.x + fr * offset.x, p.y + fr * offset.y, p.z + fr * offset.z };
+        const float pqx = mulcol(q.x, q.y, q.z, 1.0f, cb.ProjTex + 0);           // :157
+        const float pqy = mulcol(q.x, q.y, q.z, 1.0f, cb.ProjTex + 4);
+        const float pqw = mulcol(q.x, q.y, q.z, 1.0f, cb.ProjTex + 12);
+        const float rz = ndc_to_view(cb, depth_linear_border(depth, W, H, pqx / pqw, pqy / pqw));  // :158-165
+        const float s = rz / q.z;                                                // :171
+        const f3 r{ s * q.x, s * q.y, s * q.z };
+        const float distZ = p.z - r.z;                                           // :185
+        const f3 dn = normalize3(f3{ r.x - p.x, r.y - p.y, r.z - p.z });
+        const float dp = maxnn(dot3(n, dn), 0.0f);                               // :186
+        float occ = 0.0f;                                                        // :76-108
+        if (distZ > eps) occ = saturate((fadeEnd - distZ) / fadeLength);
+        occlusionSum += dp * occ;                                                // :188-190
+    }
+    occlusionSum = occlusionSum / 14.0f;                                         // :193
+    const float access = 1.0f - occlusionSum;                                    // :195
+    const float a2 = access * access, a4 = a2 * a2;                              // :198 pow(access, 6)
+    return float_to_unorm16(a4 * a2);
+}
+
+// ---- bilateral blur (SsaoBlur.hlsl:85-146) ----------------------------------------------------------------
+struct BlurTap {
+    f3 n;     // raw (un-normalised) normal
+    float z;  // linear view depth
+    float a;  // ambient value
+};
+
+// Fetch the edge data + ambient for half-res position (xi, yi), which may lie outside the map along the
+// sweep axis: normal CLAMPs in full-res texel space, depth takes the BORDER value, ambient CLAMPs.
+CRY_HD BlurTap blur_fetch(const EdgePlane& e, const uint16_t* __restrict__ amb, float borderZ, int w2, int h2,
+                          int xi, int yi)
+{
+    BlurTap t;
+    const int cx = clampi(xi, 0, w2 - 1), cy = clampi(yi, 0, h2 - 1);
+    u2 nb;
+    if (xi < 0) nb = e.gcol[cy];
+    else if (yi < 0) nb = e.grow[cx];
+    else nb = e.nrm[(uint32_t)cy * (uint32_t)w2 + (uint32_t)cx];
+    t.n = unpack_normal(nb);
+    const bool inside = ((uint32_t)xi < (uint32_t)w2) & ((uint32_t)yi < (uint32_t)h2);
+    t.z = inside ? e.vz[(uint32_t)cy * (uint32_t)w2 + (uint32_t)cx] : borderZ;
+    t.a = unorm16_to_float(amb[(uint32_t)cy * (uint32_t)w2 + (uint32_t)cx]);
+    return t;
+}
+
+// One output pixel from its 11 taps, taps[5] being the centre.
+CRY_HD uint32_t blur_resolve(const float* __restrict__ w, const BlurTap* taps)
+{
+    float color = w[5] * taps[5].a;     // :106
+    float total = w[5];                 // :107
+    const f3 cn = taps[5].n;
+    const float cz = taps[5].z;
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {      // :113
+        if (i == 5) continue;
+        const bool ok = (dot3(taps[i].n, cn) >= 0.8f) & (__builtin_fabsf(taps[i].z - cz) <= 0.2f);  // :131-132
+        if (ok) { color += w[i] * taps[i].a; total += w[i]; }
+    }
+    return float_to_unorm16(color / total);  // :145
+}
+
+}  // namespace cry

@@ -1,0 +1,213 @@
+"""Python mirror of the reference's pass objects over the C ABI.
+
+Class and method names follow the reference (Ssao.h:10-125, DeferredShading.h:4-45, ShadowMap.h:4-47,
+CRYCHIC.h:56-190) so that the parity tests read like calls into the reference; D3D12 handles become torch
+tensors that own HBM (PyTorch is used for device memory and streams only -- every pixel is computed by
+libcrychic_hip.so).
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import FrameDesc, PassConstants, PassTimes, SsaoConstants, check, lib
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(None)
+
+
+def _stream(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+class Context:
+    """One GPU, one context (D3DApp::InitDirect3D, Common/d3dApp.cpp:415-479)."""
+
+    def __init__(self, device_ordinal=0):
+        self.handle = C.c_void_p()
+        check(lib.crychic_ctx_create(int(device_ordinal), C.byref(self.handle)))
+        self.device = torch.device("cuda", int(device_ordinal))
+
+    @property
+    def device_name(self):
+        return lib.crychic_ctx_device_name(self.handle).decode()
+
+    def close(self):
+        if self.handle:
+            lib.crychic_ctx_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Ssao:
+    """Ssao.h:10-125.  Owns the view-normal map, the two half-res ambient maps, the random-vector map and the
+    half-res edge workspace; ComputeSsao runs SSAO + blurCount x (H, V) blur on the caller's stream."""
+
+    MaxBlurRadius = 5  # Ssao.h:24
+
+    def __init__(self, ctx, width, height, randvec):
+        self.ctx = ctx
+        self.mRandomVectorMap = randvec
+        self.OnResize(width, height)
+
+    def OnResize(self, newWidth, newHeight):  # Ssao.cpp:164-183
+        if newWidth % 2 or newHeight % 2:
+            raise _lib.CrychicError(-1, "frame size must be even")
+        self.mRenderTargetWidth, self.mRenderTargetHeight = newWidth, newHeight
+        dev = self.ctx.device
+        w2, h2 = newWidth // 2, newHeight // 2
+        self.mNormalMap = torch.zeros((newHeight, newWidth, 4), device=dev, dtype=torch.float16)
+        self.mNormalMap[..., 2] = 1.0  # clear (0,0,1,0), Ssao.cpp:317
+        self.mAmbientMap0 = torch.full((h2, w2), -1, device=dev, dtype=torch.int16)  # R16_UNORM 1.0, Ssao.cpp:333
+        self.mAmbientMap1 = torch.full((h2, w2), -1, device=dev, dtype=torch.int16)
+        self.mEdge = torch.zeros((int(lib.crychic_edge_plane_bytes(newWidth, newHeight)),), device=dev, dtype=torch.uint8)
+
+    def SsaoMapWidth(self):  # Ssao.cpp:22-25
+        return self.mRenderTargetWidth // 2
+
+    def SsaoMapHeight(self):  # Ssao.cpp:27-30
+        return self.mRenderTargetHeight // 2
+
+    @staticmethod
+    def CalcGaussWeights(sigma):  # Ssao.cpp:37-68
+        w = (C.c_float * 11)()
+        n = check(lib.crychic_calc_gauss_weights(float(sigma), w, 11))
+        return [w[i] for i in range(n)]
+
+    def NormalMap(self):  # Ssao.cpp:70-73
+        return self.mNormalMap
+
+    def AmbientMap(self):  # Ssao.cpp:75-78
+        return self.mAmbientMap0
+
+    def ComputeSsao(self, depth, ssao_cb, blurCount, row0=0, rows=None):  # Ssao.cpp:185-229
+        W, H = self.mRenderTargetWidth, self.mRenderTargetHeight
+        rows = H // 2 - row0 if rows is None else rows
+        check(lib.crychic_ssao_compute(self.ctx.handle, C.byref(ssao_cb), _ptr(self.mNormalMap), _ptr(depth),
+                                       _ptr(self.mRandomVectorMap), _ptr(self.mAmbientMap0), _ptr(self.mAmbientMap1),
+                                       _ptr(self.mEdge), W, H, int(blurCount), int(row0), int(rows),
+                                       _stream(self.ctx.device)))
+
+    def BlurAmbientMap(self, ssao_cb, horzBlur, row0=0, rows=None):  # Ssao.cpp:245-293
+        W, H = self.mRenderTargetWidth, self.mRenderTargetHeight
+        rows = H // 2 - row0 if rows is None else rows
+        src, dst = (self.mAmbientMap0, self.mAmbientMap1) if horzBlur else (self.mAmbientMap1, self.mAmbientMap0)
+        check(lib.crychic_ssao_blur(self.ctx.handle, C.byref(ssao_cb), _ptr(self.mEdge), _ptr(src), _ptr(dst), W, H,
+                                    1 if horzBlur else 0, int(row0), int(rows), _stream(self.ctx.device)))
+
+
+class DeferredShading:
+    """DeferredShading.h:4-45: owns the G-buffer planes (R32G32B32A32_FLOAT, CRYCHIC.cpp:56-58).  The reference
+    allocates four; GBuffer3 carries no information (GBuffer.hlsl:29) and is not allocated here."""
+
+    def __init__(self, ctx, width, height):
+        self.ctx = ctx
+        self.OnResize(width, height)
+
+    def OnResize(self, newWidth, newHeight):  # DeferredShading.cpp:79-93
+        self.mWidth, self.mHeight = newWidth, newHeight
+        self.mGBuffer = [torch.zeros((newHeight, newWidth, 4), device=self.ctx.device, dtype=torch.float32) for _ in range(3)]
+
+    def Width(self):
+        return self.mWidth
+
+    def Height(self):
+        return self.mHeight
+
+    def Resource(self, index):  # DeferredShading.cpp:30-33
+        return self.mGBuffer[index]
+
+
+class ShadowMap:
+    """ShadowMap.h:4-47: the cascade depth maps (D24 in uint32).  The reference allocates 12 x 12 slices of which
+    4 cascades are valid (CRYCHIC.cpp:644)."""
+
+    def __init__(self, ctx, width, height):
+        if width != height:
+            raise _lib.CrychicError(-1, "shadow maps are square")
+        self.ctx = ctx
+        self.mWidth, self.mHeight = width, height
+        self.mShadowMap = torch.full((4, height, width), 0xFFFFFF, device=ctx.device, dtype=torch.int32)  # depth 1.0
+
+    def Width(self):
+        return self.mWidth
+
+    def Height(self):
+        return self.mHeight
+
+    def Resource(self, index):
+        return self.mShadowMap[index]
+
+
+class Crychic:
+    """Headless CRYCHIC (CRYCHIC.h:56-190): Draw() issues the hot part of CRYCHIC::Draw's deferred branch
+    (CRYCHIC.cpp:220-221, 238-279) on this GPU's stream for the full-res rows [row0, row0 + rows)."""
+
+    def __init__(self, ctx, width, height, randvec, cube, shadow_dim=4096):
+        self.ctx = ctx
+        self.mClientWidth, self.mClientHeight = width, height
+        self.mShadowMap = ShadowMap(ctx, shadow_dim, shadow_dim)
+        self.mSsao = Ssao(ctx, width, height, randvec)
+        self.mDeferred = DeferredShading(ctx, width, height)
+        self.mCubeMap = cube
+        self.mDepthStencilBuffer = torch.full((height, width), 0xFFFFFF, device=ctx.device, dtype=torch.int32)
+        self.mBackBuffer = torch.zeros((height, width, 4), device=ctx.device, dtype=torch.uint8)
+        self.mMainPassCB = PassConstants()
+        self.mSsaoCB = SsaoConstants()
+        self.blurCount = 3           # CRYCHIC.cpp:221
+        self.numDirLights = 1        # NUM_DIR_LIGHTS of the deferred shader, Common.hlsl:6-8
+        self.pcfSearchRadius = lib.crychic_pcf_search_radius(shadow_dim, 1)  # Common.hlsl:305 as written
+        self.flags = 0
+        self._desc = None
+
+    def load_scene(self, planes):
+        """Install externally produced input planes (scene.make_scene) in place of the producer passes."""
+        self.mDepthStencilBuffer = planes["depth"]
+        self.mSsao.mNormalMap = planes["normal"]
+        self.mDeferred.mGBuffer = [planes["g0"], planes["g1"], planes["g2"]]
+        self.mShadowMap.mShadowMap = planes["shadow"]
+        self.mCubeMap = planes["cube"]
+        self.mSsao.mRandomVectorMap = planes["randvec"]
+        self.mMainPassCB = planes["consts"].pass_cb
+        self.mSsaoCB = planes["consts"].ssao_cb
+        self._desc = None
+
+    def frame_desc(self, row0=0, rows=None):
+        W, H = self.mClientWidth, self.mClientHeight
+        f = FrameDesc()
+        f.W, f.H = W, H
+        f.blurCount, f.numDirLights = int(self.blurCount), int(self.numDirLights)
+        f.pcfSearchRadius, f.flags = float(self.pcfSearchRadius), int(self.flags)
+        f.row0, f.rows = int(row0), int(H - row0 if rows is None else rows)
+        f.normal_dev = self.mSsao.mNormalMap.data_ptr()
+        f.depth_dev = self.mDepthStencilBuffer.data_ptr()
+        f.randvec_dev = self.mSsao.mRandomVectorMap.data_ptr()
+        f.g0_dev, f.g1_dev, f.g2_dev = (g.data_ptr() for g in self.mDeferred.mGBuffer)
+        for i in range(4):
+            f.shadow_dev[i] = self.mShadowMap.mShadowMap[i].data_ptr()
+        f.shadowDim = self.mShadowMap.Width()
+        f.cube_dev, f.cubeDim = self.mCubeMap.data_ptr(), int(self.mCubeMap.shape[1])
+        f.ambient0_dev = self.mSsao.mAmbientMap0.data_ptr()
+        f.ambient1_dev = self.mSsao.mAmbientMap1.data_ptr()
+        f.edge_dev = self.mSsao.mEdge.data_ptr()
+        f.out_rgba8_dev = self.mBackBuffer.data_ptr()
+        return f
+
+    def Draw(self, row0=0, rows=None):  # CRYCHIC.cpp:172-306 (hot part)
+        f = self.frame_desc(row0, rows)
+        check(lib.crychic_draw_hot_path(self.ctx.handle, C.byref(self.mSsaoCB), C.byref(self.mMainPassCB), C.byref(f),
+                                        _stream(self.ctx.device)))
+
+    def set_profiling(self, enabled):
+        check(lib.crychic_ctx_set_profiling(self.ctx.handle, 1 if enabled else 0))
+
+    def last_pass_times(self):
+        t = PassTimes()
+        check(lib.crychic_ctx_last_pass_times(self.ctx.handle, C.byref(t)))
+        return {"ssao_ms": t.ssao_ms, "blur_ms": t.blur_ms, "light_ms": t.light_ms, "total_ms": t.total_ms}

@@ -1,0 +1,239 @@
+/*
+ * crychic_hip.h -- C ABI of libcrychic_hip.so, the MI355X (gfx950) backend for CRYCHIC's per-pixel
+ * hot path: G-buffer -> 14-tap SSAO -> bilateral blur -> deferred PBR lighting with cascaded-shadow PCF.
+ *
+ * The reference (UnlimitedRainWorks/CRYCHIC-RENDERER) has no FFI: the seam is the public surface of its
+ * pass objects (Ssao.h:10-125, DeferredShading.h:4-45, ShadowMap.h:4-47), FrameResource.h and
+ * CRYCHIC::Draw (CRYCHIC.cpp:172-306).  Every entry point below cites the reference code it replaces.
+ * The C++ veneer in include/crychic/ keeps the reference's class and method names on top of this ABI.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every `*_dev` pointer is DEVICE memory (hipMalloc or equivalent),
+ *     every constant-buffer pointer is HOST memory and is copied at call time (the caller may reuse
+ *     it immediately, like an UploadBuffer slot guarded by the frame fence, CRYCHIC.cpp:135-146);
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all work is
+ *     stream-ordered and asynchronous, there is no host synchronisation inside any entry point;
+ *   - every function returns 0 on success or a negative crychic_status; crychic_last_error()
+ *     returns a thread-local description (the reference throws DxException, Common/d3dUtil.h:132-144);
+ *   - there is NO CPU fallback: without a usable HIP device every compute entry point fails.
+ *
+ * Plane layouts (row-major, pitch = width * texel size, no tiling)
+ *   depth    uint32  D24 in bits 0..23 (stencil bits ignored)           W x H
+ *   normal   4 x fp16 view-space normal (DrawNormals.hlsl:93)            W x H
+ *   ambient  uint16 R16_UNORM (Ssao.h:21)                                (W/2) x (H/2)
+ *   randvec  4 x uint8 R8G8B8A8_UNORM (Ssao.cpp:362)                     256 x 256
+ *   g0,g1,g2 4 x fp32 (GBuffer.hlsl:22-31)                               W x H
+ *   shadow   uint32 D24 per cascade (ShadowMap.cpp:83,94)                shadowDim x shadowDim
+ *   cube     4 x uint8 RGBA, faces +X,-X,+Y,-Y,+Z,-Z                     6 x cubeDim x cubeDim
+ *   out      4 x uint8 R8G8B8A8_UNORM back buffer (Common/d3dApp.h:124)  W x H
+ *   edge     opaque half-res workspace, crychic_edge_plane_bytes(W,H) bytes (see crychic_ssao)
+ * W and H must be even (the half-res maps are W/2 x H/2, Ssao.cpp:22-30).
+ */
+#ifndef CRYCHIC_HIP_H
+#define CRYCHIC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRYCHIC_MAX_LIGHTS 16 /* Common/d3dUtil.h:226 */
+
+typedef enum crychic_status {
+    CRYCHIC_OK = 0,
+    CRYCHIC_E_INVALID_ARG = -1,   /* null pointer, odd/zero size, bad range */
+    CRYCHIC_E_NO_DEVICE = -2,     /* no HIP device / wrong ordinal */
+    CRYCHIC_E_HIP = -3,           /* a HIP runtime call failed (see crychic_last_error) */
+    CRYCHIC_E_UNSUPPORTED = -4,
+    CRYCHIC_E_COMM = -5           /* RCCL failure */
+} crychic_status;
+
+/* Common/d3dUtil.h:216-224 (48 B) */
+typedef struct crychic_light {
+    float Strength[3];
+    float FalloffStart;
+    float Direction[3];
+    float FalloffEnd;
+    float Position[3];
+    float SpotPower;
+} crychic_light;
+
+/* FrameResource.h:29-51 == cbPass Shaders/Common.hlsl:82-107 (2048 B).  Matrices are stored as the
+ * reference stores them: XMMatrixTranspose of the row-vector matrix (CRYCHIC.cpp:843-849). */
+typedef struct crychic_pass_constants {
+    float View[16];
+    float InvView[16];
+    float Proj[16];
+    float InvProj[16];
+    float ViewProj[16];
+    float InvViewProj[16];
+    float ViewProjTex[16];
+    float ShadowTransforms[12][16];
+    float EyePosW[3];
+    float cbPerObjectPad1;
+    float RenderTargetSize[2];
+    float InvRenderTargetSize[2];
+    float NearZ;
+    float FarZ;
+    float TotalTime;
+    float DeltaTime;
+    float AmbientLight[4];
+    crychic_light Lights[CRYCHIC_MAX_LIGHTS];
+} crychic_pass_constants;
+
+/* FrameResource.h:53-67 == cbSsao Shaders/Ssao.hlsl:5-22 (496 B) */
+typedef struct crychic_ssao_constants {
+    float Proj[16];
+    float InvProj[16];
+    float ProjTex[16];
+    float OffsetVectors[14][4];
+    float BlurWeights[3][4];
+    float RenderTargetSize[2];
+    float InvRenderTargetSize[2];
+    float OcclusionRadius;
+    float OcclusionFadeStart;
+    float OcclusionFadeEnd;
+    float SurfaceEpsilon;
+} crychic_ssao_constants;
+
+/* Camera state consumed by the constant builders (Common/Camera.h:20-97). */
+typedef struct crychic_camera {
+    float pos[3];
+    float look[3];
+    float up[3];
+    float fovY, aspect, nearZ, farZ;
+} crychic_camera;
+
+typedef struct crychic_ctx crychic_ctx;
+
+/* ---- context / errors ---------------------------------------------------------------------------- */
+/* Replaces D3DApp::InitDirect3D's device creation (Common/d3dApp.cpp:415-479): binds the context to one
+ * GPU.  One context per GPU, single-threaded, like the reference's one queue / one list. */
+int crychic_ctx_create(int device_ordinal, crychic_ctx** out);
+void crychic_ctx_destroy(crychic_ctx* ctx);
+const char* crychic_last_error(void);
+const char* crychic_version(void);
+/* Name of the device the context is bound to ("gfx950..."); NULL on error. */
+const char* crychic_ctx_device_name(crychic_ctx* ctx);
+
+/* ---- host-side constant builders (no GPU needed) --------------------------------------------------- */
+/* Ssao::CalcGaussWeights  Ssao.cpp:37-68.  Returns the number of weights written (2*ceil(2*sigma)+1) or a
+ * negative status if capacity is too small / radius > Ssao::MaxBlurRadius (the reference asserts). */
+int crychic_calc_gauss_weights(float sigma, float* weights, int capacity);
+/* MathHelper::RandF over the MSVC CRT rand() LCG the reference links against (Common/MathHelper.h:17-20). */
+int crychic_msvc_rand(uint32_t* state);
+/* Ssao::BuildOffsetVectors  Ssao.cpp:423-462 */
+void crychic_build_offset_vectors(uint32_t* rand_state, float offsets[14][4]);
+/* Ssao::BuildRandomVectorTexture  Ssao.cpp:392-402 (texel bytes as the shader samples them). */
+void crychic_build_random_vector_texture(uint32_t* rand_state, int args_right_to_left, uint8_t* rgba8_256x256);
+/* CRYCHIC::UpdateCascadeShadowTransform  CRYCHIC.cpp:634-815.  Outputs are the untransposed row-vector
+ * matrices (mLightViews / mLightProjs / mShadowTransforms). */
+int crychic_update_cascade_shadow_transform(const crychic_camera* cam, const float lightDir[3],
+                                            uint32_t shadowMapWidth, float lightView[4][16],
+                                            float lightProj[4][16], float shadowTransform[4][16]);
+/* CRYCHIC::UpdateMainPassCB  CRYCHIC.cpp:817-868 */
+int crychic_update_main_pass_cb(const crychic_camera* cam, uint32_t W, uint32_t H,
+                                const float shadowTransform[4][16], const float lightDirs[3][3],
+                                crychic_pass_constants* out);
+/* CRYCHIC::UpdateSsaoCB  CRYCHIC.cpp:903-937 */
+int crychic_update_ssao_cb(const crychic_camera* cam, uint32_t W, uint32_t H, const float offsets[14][4],
+                           crychic_ssao_constants* out);
+/* Common.hlsl:305 `5 / width / 2.0f`.  literal != 0 keeps the shader's unsigned integer division (radius 0
+ * for every width > 5: what the reference computes); literal == 0 gives the float division (2.5 texels). */
+float crychic_pcf_search_radius(uint32_t shadowMapWidth, int literal);
+
+/* ---- SSAO (Ssao.h / Ssao.cpp / Ssao.hlsl / SsaoBlur.hlsl) --------------------------------------------- */
+/* Bytes of the half-res edge workspace for a W x H frame. */
+size_t crychic_edge_plane_bytes(uint32_t W, uint32_t H);
+
+/* Ssao.hlsl:PS (Shaders/Ssao.hlsl:117-199) over half-res rows [row0, row0+rows): writes ambient_out and,
+ * when edge_dev is not NULL, the per-pixel centre normal / linear depth that every later blur sweep of
+ * this frame re-uses (SsaoBlur.hlsl:109-111,121-123 recompute them per tap). */
+int crychic_ssao(crychic_ctx* ctx, const crychic_ssao_constants* cb, const void* normal_dev,
+                 const uint32_t* depth_dev, const uint8_t* randvec_dev, uint16_t* ambient_out_dev,
+                 void* edge_dev, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows, void* stream);
+
+/* Builds only the edge workspace (for callers that blur an ambient map they produced elsewhere). */
+int crychic_ssao_edges(crychic_ctx* ctx, const crychic_ssao_constants* cb, const void* normal_dev,
+                       const uint32_t* depth_dev, void* edge_dev, uint32_t W, uint32_t H, uint32_t row0,
+                       uint32_t rows, void* stream);
+
+/* One sweep of SsaoBlur.hlsl:PS == Ssao::BlurAmbientMap(cmdList, bool horzBlur) (Ssao.cpp:245-293) over
+ * half-res rows [row0, row0+rows).  `horizontal` is the gHorizontalBlur root constant. */
+int crychic_ssao_blur(crychic_ctx* ctx, const crychic_ssao_constants* cb, const void* edge_dev,
+                      const uint16_t* ambient_in_dev, uint16_t* ambient_out_dev, uint32_t W, uint32_t H,
+                      int horizontal, uint32_t row0, uint32_t rows, void* stream);
+
+/* Ssao::ComputeSsao(cmdList, currFrame, blurCount)  Ssao.cpp:185-243: SSAO into ambient0, then blurCount x
+ * (H: 0->1, V: 1->0); the final AO is in ambient0 (Ssao.cpp:75-78).  Rows [row0, row0+rows) of the final
+ * map are guaranteed valid; the implementation recomputes a halo of 5 rows per remaining vertical sweep
+ * (multi-GPU strips need no exchange).  row0 = 0, rows = H/2 is the whole map. */
+int crychic_ssao_compute(crychic_ctx* ctx, const crychic_ssao_constants* cb, const void* normal_dev,
+                         const uint32_t* depth_dev, const uint8_t* randvec_dev, uint16_t* ambient0_dev,
+                         uint16_t* ambient1_dev, void* edge_dev, uint32_t W, uint32_t H, int blurCount,
+                         uint32_t row0, uint32_t rows, void* stream);
+
+/* ---- deferred lighting (DeferredShading.hlsl:PS, Shaders/DeferredShading.hlsl:23-101) ------------------ */
+#define CRYCHIC_LIGHT_SKY 1u /* fill uncovered pixels from the cubemap (sky.hlsl:21-47) instead of the clear colour */
+
+/* Full-screen replacement of the geometry re-draw at CRYCHIC.cpp:238-273 over full-res rows
+ * [row0, row0+rows): pixels with depth < 1.0 are lit, the others get Colors::LightSteelBlue
+ * (CRYCHIC.cpp:247) or the sky.  ambient_dev may be NULL (SSAO off, ambientAccess = 1); radiance_out_dev
+ * (optional, 4 floats per pixel) receives litColor before UNORM8 quantisation.  numDirLights is the
+ * shader's NUM_DIR_LIGHTS (1 in the reference build, Common.hlsl:6-8). */
+int crychic_deferred_light(crychic_ctx* ctx, const crychic_pass_constants* cb, const float* g0_dev,
+                           const float* g1_dev, const float* g2_dev, const uint32_t* depth_dev,
+                           const uint16_t* ambient_dev, const uint32_t* const shadow_dev[4], uint32_t shadowDim,
+                           const uint8_t* cube_dev, uint32_t cubeDim, uint8_t* out_rgba8_dev,
+                           float* radiance_out_dev, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows,
+                           int numDirLights, float pcfSearchRadius, uint32_t flags, void* stream);
+
+/* ---- whole hot path of CRYCHIC::Draw (CRYCHIC.cpp:220-221 + 238-279) -------------------------------------- */
+typedef struct crychic_frame_desc {
+    uint32_t W, H;
+    int blurCount;              /* CRYCHIC.cpp:221 passes 3; <0 = SSAO off */
+    int numDirLights;
+    float pcfSearchRadius;
+    uint32_t flags;             /* CRYCHIC_LIGHT_* */
+    uint32_t row0, rows;        /* full-res output rows owned by this GPU (0, H = whole frame) */
+    const void* normal_dev;
+    const uint32_t* depth_dev;
+    const uint8_t* randvec_dev;
+    const float* g0_dev;
+    const float* g1_dev;
+    const float* g2_dev;
+    const uint32_t* shadow_dev[4];
+    uint32_t shadowDim;
+    const uint8_t* cube_dev;
+    uint32_t cubeDim;
+    uint16_t* ambient0_dev;
+    uint16_t* ambient1_dev;
+    void* edge_dev;
+    uint8_t* out_rgba8_dev;
+} crychic_frame_desc;
+
+int crychic_draw_hot_path(crychic_ctx* ctx, const crychic_ssao_constants* ssaoCB,
+                          const crychic_pass_constants* passCB, const crychic_frame_desc* frame, void* stream);
+
+/* Per-kernel timing of the last crychic_draw_hot_path issued with profiling enabled (HIP events recorded
+ * on the caller's stream around each pass).  Times are milliseconds; blocks until the events complete. */
+typedef struct crychic_pass_times {
+    float ssao_ms;
+    float blur_ms;   /* all 2*blurCount sweeps */
+    float light_ms;
+    float total_ms;
+} crychic_pass_times;
+int crychic_ctx_set_profiling(crychic_ctx* ctx, int enabled);
+int crychic_ctx_last_pass_times(crychic_ctx* ctx, crychic_pass_times* out);
+
+/* ---- multi-GPU strip plan (pure host arithmetic) ---------------------------------------------- */
+/* Full-res rows [*row0, *row0 + *rows) owned by `rank` of `nranks` for an H-row frame: strips are multiples
+ * of 2 rows (half-res alignment); the last rank takes the remainder. */
+int crychic_strip_rows(uint32_t H, int nranks, int rank, uint32_t* row0, uint32_t* rows);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,254 @@
+/*
+ * or_light.c -- oracle restatement of Shaders/DeferredShading.hlsl:PS with PBR.hlsl, GBuffer.hlsl,
+ * LightingUtil.hlsl:52-60 and the cascaded-shadow Poisson PCF of Common.hlsl:167-183,263-317
+ * (TEST INFRASTRUCTURE, parity unpinned: see crychic_oracle.h).  Reference quirks Q1-Q6, Q13 of
+ * SURVEY.md are reproduced on purpose and marked below.
+ */
+#include "crychic_oracle.h"
+#include "or_samplers.h"
+
+#define OR_PI 3.1415926f /* PBR.hlsl:2 */
+
+/* Common.hlsl:167-171.  `noise` is a scalar broadcast to float2, so abs(noise.x + noise.y) * 0.5 == noise. */
+static inline float nrand(float u, float v)
+{
+    float d = u * (12.9898f * 2.0f) + v * (78.233f * 2.0f);
+    float noise = or_frac(or_det_sinf_(d) * 43758.5453f);
+    return fabsf(noise + noise) * 0.5f;
+}
+float or_nrand(float u, float v) { return nrand(u, v); }
+
+/* Common.hlsl:173-183 */
+static const float poissonDisk[16][2] = {
+    { -0.94201624f, -0.39906216f }, { 0.94558609f, -0.76890725f },
+    { -0.094184101f, -0.92938870f }, { 0.34495938f, 0.29387760f },
+    { -0.91588581f, 0.45771432f }, { -0.81544232f, -0.87912464f },
+    { -0.38277543f, 0.27676845f }, { 0.97484398f, 0.75648379f },
+    { 0.44323325f, -0.97511554f }, { 0.53742981f, -0.47373420f },
+    { -0.26496911f, -0.41893023f }, { 0.79197514f, 0.19090188f },
+    { -0.24188840f, 0.99706507f }, { -0.81409955f, 0.91437590f },
+    { 0.19984126f, 0.78641367f }, { 0.14383161f, -0.14100790f }
+};
+
+float or_pcf_search_radius(uint32_t width, int literal)
+{
+    /* Common.hlsl:305 `float search_radius = 5 / width / 2.0f;` with `uint width`: 5 / width is an
+     * unsigned integer division (quirk Q2). */
+    if (literal) return (float)(5u / width) / 2.0f;
+    return 5.0f / (float)width / 2.0f;
+}
+
+/* Common.hlsl:263-317 */
+static float pcf_poisson(const uint32_t* shadow, uint32_t dim, const float sp[4], float search_radius)
+{
+    float x = sp[0] / sp[3], y = sp[1] / sp[3], depth = sp[2] / sp[3];  /* :266-269 */
+    float theta = nrand(x, y);                                          /* :301 */
+    float cos_theta = or_det_cosf_(theta);
+    float sin_theta = or_det_sinf_(theta);
+    float percentLit = 0.0f;
+    for (int i = 0; i < 16; ++i) {                                      /* N_SAMPLE :21, :308 */
+        /* mul(poissonDisk[i], float2x2(c, s, -s, c))  :304,310 */
+        float px = poissonDisk[i][0] * cos_theta + poissonDisk[i][1] * (-sin_theta);
+        float py = poissonDisk[i][0] * sin_theta + poissonDisk[i][1] * cos_theta;
+        float ox = px * search_radius, oy = py * search_radius;        /* :311 */
+        percentLit += or_shadow_cmp_linear(shadow, dim, x + ox, y + oy, depth); /* :312-313 */
+    }
+    return percentLit / 16.0f;                                          /* :315 */
+}
+float or_pcf_poisson(const uint32_t* shadow, uint32_t dim, const float shadowPosH[4], float searchRadius)
+{
+    return pcf_poisson(shadow, dim, shadowPosH, searchRadius);
+}
+float or_sample_shadow_cmp(const uint32_t* shadow, uint32_t dim, float u, float v, float ref)
+{
+    return or_shadow_cmp_linear(shadow, dim, u, v, ref);
+}
+
+static inline float pow5(float x) { float x2 = x * x, x4 = x2 * x2; return x4 * x; }
+
+/* PBR.hlsl:4-14 */
+static inline float ndf_ggx(const float n[3], const float h[3], float a)
+{
+    float a2 = a * a;
+    float nDoth = or_max0(or_dot3(n, h), 0.001f);
+    float nDoth2 = nDoth * nDoth;
+    float t = nDoth2 * (a2 - 1.0f) + 1.0f;
+    float tmp = t * t;                      /* pow(x, 2) */
+    float bottom = OR_PI * tmp;
+    return a2 * (1.0f / bottom);            /* top * rcp(bottom) */
+}
+/* PBR.hlsl:16-21 */
+static inline float geometry_schlick_ggx(float nDotvec, float k) { return nDotvec / (nDotvec * (1.0f - k) + k); }
+
+/* One directional light: PBR.hlsl:72-88 (GetPBRDesc), :45-70 (GetBRDF), :99-106 (PBRShading loop body). */
+static void pbr_dir_light(const or_light* L, const float albedo[3], float roughness, float metalness,
+                          const float normal[3], const float view[3], float shadow, float result[3])
+{
+    float lightDir[3] = { -L->Direction[0], -L->Direction[1], -L->Direction[2] };
+    float vl[3] = { view[0] + lightDir[0], view[1] + lightDir[1], view[2] + lightDir[2] }, halfVec[3];
+    or_normalize3(vl, halfVec);
+    float hDotv = or_max0(or_dot3(halfVec, view), 0.001f);
+    float nDotl = or_max0(or_dot3(normal, lightDir), 0.001f);
+    float nDotv = or_max0(or_dot3(normal, view), 0.001f);
+
+    float nDotvQ = hDotv;                    /* quirk Q3: PBR.hlsl:58 `float nDotv = pbrDesc.hDotv;` */
+    float D = ndf_ggx(normal, halfVec, roughness);
+    float fr = pow5(or_saturate(1.0f - nDotvQ)); /* FresnelSchlick :40-43 */
+    float k = 0.125f * (roughness + 1.0f) * (roughness + 1.0f);
+    float G = geometry_schlick_ggx(nDotv, k) * geometry_schlick_ggx(nDotl, k); /* true nDotv :29-38 */
+    float s5 = pow5(shadow);                 /* pow(shadowFactor[i], 5.0f) :105 */
+    for (int c = 0; c < 3; ++c) {
+        float f0 = or_lerp(0.04f, albedo[c], metalness);
+        float F = f0 + (1.0f - f0) * fr;
+        float fs = 0.25f * D * G * F;
+        fs = fs / (nDotl * nDotvQ);
+        float fd = albedo[c] * (1.0f / OR_PI);
+        float ks = F;                         /* quirk Q4: F applied twice */
+        float kd = (1.0f - F) * (1.0f - metalness);
+        float brdf = kd * fd + ks * fs;
+        float irradiance = L->Strength[c] * nDotl;
+        result[c] += s5 * brdf * irradiance;
+    }
+}
+
+static void cube4(const uint8_t* cube, uint32_t dim, const float dir[3], float rgba[4])
+{
+    or_cube_linear(cube, dim, dir, rgba, 4);
+}
+
+static void light_pixel(const or_pass_constants* cb, const float* g0, const float* g1, const float* g2,
+                        const uint16_t* ambient, const uint32_t* const shadow[4], uint32_t shadowDim,
+                        const uint8_t* cube, uint32_t cubeDim, uint32_t W, uint32_t H, size_t idx,
+                        int numDirLights, float pcfRadius, float lit[4])
+{
+    /* DeferredShading.hlsl:25-30: the anisotropic-wrap fetch at exact texel centres is the texel itself. */
+    const float* G0 = g0 + idx * 4; const float* G1 = g1 + idx * 4; const float* G2 = g2 + idx * 4;
+    float posW[3] = { G0[0], G0[1], G0[2] };          /* GBuffer.hlsl:37 */
+    float metalness = G0[3];                          /* :38 (quirk Q5: always 0.5 in the reference scene) */
+    float albedo[3] = { G1[0], G1[1], G1[2] };        /* :39 */
+    float roughness = G1[3];                          /* :40 */
+    float nraw[3] = { G2[0], G2[1], G2[2] }, normalW[3];
+    or_normalize3(nraw, normalW);                     /* :41; G3 and G2.w ignored (Q13) */
+
+    float toEye[3] = { cb->EyePosW[0] - posW[0], cb->EyePosW[1] - posW[1], cb->EyePosW[2] - posW[2] };
+    float view[3];
+    or_normalize3(toEye, view);                       /* DeferredShading.hlsl:32 */
+    float fresnelR0[3];
+    for (int c = 0; c < 3; ++c) fresnelR0[c] = or_lerp(0.04f, albedo[c], metalness); /* :35 */
+
+    float pos4[4] = { posW[0], posW[1], posW[2], 1.0f };
+    float ambientAccess = 1.0f;
+    if (ambient) {
+        float sp[4];
+        or_mul_v4_m(pos4, cb->ViewProjTex, sp);       /* :40 */
+        ambientAccess = or_ambient_linear_clamp(ambient, W / 2, H / 2, sp[0] / sp[3], sp[1] / sp[3]); /* :41-42 */
+    }
+    float amb[4];
+    for (int c = 0; c < 3; ++c) amb[c] = ambientAccess * cb->AmbientLight[c] * albedo[c]; /* :44 */
+    amb[3] = ambientAccess * cb->AmbientLight[3] * 1.0f;
+
+    float shadowFactors[OR_MAX_LIGHTS];
+    for (int i = 0; i < OR_MAX_LIGHTS; ++i) shadowFactors[i] = 1.0f;  /* :46-51 */
+
+    static const float radius[4] = { 30.0f, 50.0f, 80.0f, 100.0f };  /* :53 */
+    float distance = sqrtf(or_dot3(toEye, toEye));                    /* :57 length(gEyePosW - posW) */
+    for (int j = 0; j < 4; ++j) {
+        /* :60 `abs(distance - radius[j] < 5.0f)` is abs() of a bool (quirk Q1): it is 1 whenever
+         * distance < radius[j], so the blend branch is taken for every j < 3. */
+        int blendTerm = (distance - radius[j] < 5.0f) ? 1 : 0;
+        if (j < 3 && distance < radius[j] && blendTerm != 0) {
+            float sp0[4], sp1[4];
+            or_mul_v4_m(pos4, cb->ShadowTransforms[j], sp0);          /* :62 */
+            or_mul_v4_m(pos4, cb->ShadowTransforms[j + 1], sp1);      /* :63 */
+            float a = pcf_poisson(shadow[j], shadowDim, sp0, pcfRadius);
+            float b = pcf_poisson(shadow[j + 1], shadowDim, sp1, pcfRadius);
+            shadowFactors[0] = 0.5f * (a + b);                         /* :66 */
+            break;
+        } else if (distance < radius[j]) {
+            float sp0[4];
+            or_mul_v4_m(pos4, cb->ShadowTransforms[j], sp0);          /* :71 */
+            shadowFactors[0] = pcf_poisson(shadow[j], shadowDim, sp0, pcfRadius); /* :72-73 */
+            break;
+        }
+    }
+
+    const float shininess = (1.0f - roughness) * 1.0f;                /* :84, normalW.a = 1 */
+
+    float direct[3] = { 0.0f, 0.0f, 0.0f };
+    for (int i = 0; i < numDirLights; ++i)                            /* PBR.hlsl:99-106; NUM_DIR_LIGHTS (Q6) */
+        pbr_dir_light(&cb->Lights[i], albedo, roughness, metalness, normalW, view, shadowFactors[i], direct);
+    for (int c = 0; c < 3; ++c) {
+        float d = direct[c] / (direct[c] + 1.0f);                     /* :89 */
+        d = or_det_powf_(d, 1.0f / 2.2f);                             /* :90 */
+        lit[c] = d + amb[c];                                          /* :92 */
+    }
+    /* w: directLight.w = 0 -> 0/(0+1) = 0 -> pow(0, 1/2.2) = 0 -> + ambient.a; then :99 overwrites with 1 */
+
+    float negv[3] = { -view[0], -view[1], -view[2] }, r[3];
+    or_reflect3(negv, normalW, r);                                    /* :94 */
+    float refl[4];
+    cube4(cube, cubeDim, r, refl);                                    /* :95 */
+    float cosI = or_saturate(or_dot3(normalW, r));                    /* LightingUtil.hlsl:54 */
+    float f0 = 1.0f - cosI;
+    float f5 = f0 * f0 * f0 * f0 * f0;                                /* :57 */
+    for (int c = 0; c < 3; ++c) {
+        float fresnel = fresnelR0[c] + (1.0f - fresnelR0[c]) * f5;
+        lit[c] += shininess * fresnel * refl[c];                      /* DeferredShading.hlsl:97 */
+    }
+    lit[3] = 1.0f;                                                    /* :99 */
+}
+
+/* Shaders/sky.hlsl:21-47: cubemap lookup along the view ray of the pixel (the sky sphere is centred on
+ * the eye, so the interpolated PosL is parallel to the ray).  Ray = near-plane point of the pixel in view
+ * space rotated by InvView. */
+static void sky_pixel(const or_pass_constants* cb, const uint8_t* cube, uint32_t cubeDim, uint32_t W, uint32_t H,
+                      uint32_t x, uint32_t y, float out[4])
+{
+    float u = ((float)x + 0.5f) / (float)W, v = ((float)y + 0.5f) / (float)H;
+    float posh[4] = { 2.0f * u - 1.0f, 1.0f - 2.0f * v, 0.0f, 1.0f }, ph[4];
+    or_mul_v4_m(posh, cb->InvProj, ph);
+    float pv[4] = { ph[0] / ph[3], ph[1] / ph[3], ph[2] / ph[3], 0.0f }, dw[4];
+    or_mul_v4_m(pv, cb->InvView, dw);
+    cube4(cube, cubeDim, dw, out);
+}
+
+void or_deferred_light(const or_pass_constants* cb, const float* g0, const float* g1, const float* g2,
+                       const uint32_t* depth, const uint16_t* ambient, const uint32_t* const shadow[4],
+                       uint32_t shadowDim, const uint8_t* cube, uint32_t cubeDim, uint8_t* out_rgba8,
+                       float* radiance_out, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows,
+                       int numDirLights, float pcfSearchRadius, int sky)
+{
+    uint32_t row1 = row0 + rows; if (row1 > H) row1 = H;
+    /* Colors::LightSteelBlue (CRYCHIC.cpp:247) */
+    static const float clearColor[4] = { 0.690196097f, 0.768627524f, 0.870588303f, 1.0f };
+#pragma omp parallel for schedule(dynamic, 4)
+    for (int y = (int)row0; y < (int)row1; ++y) {
+        for (uint32_t x = 0; x < W; ++x) {
+            size_t idx = (size_t)y * W + x;
+            float lit[4];
+            /* Coverage: the deferred draw re-rasterises the opaque geometry against a depth buffer cleared
+             * to 1.0 with LESS (CRYCHIC.cpp:248,273), i.e. exactly the pixels whose normal/depth pass depth
+             * is below the clear value. */
+            if ((depth[idx] & 0x00FFFFFFu) < 0x00FFFFFFu)
+                light_pixel(cb, g0, g1, g2, ambient, shadow, shadowDim, cube, cubeDim, W, H, idx, numDirLights,
+                            pcfSearchRadius, lit);
+            else if (sky)
+                sky_pixel(cb, cube, cubeDim, W, H, x, (uint32_t)y, lit);
+            else
+                for (int c = 0; c < 4; ++c) lit[c] = clearColor[c];
+            if (radiance_out) for (int c = 0; c < 4; ++c) radiance_out[idx * 4 + c] = lit[c];
+            for (int c = 0; c < 4; ++c) out_rgba8[idx * 4 + c] = or_to_unorm8(lit[c]);
+        }
+    }
+}
+
+void or_sample_cube(const uint8_t* cube, uint32_t dim, const float dir[3], float rgb[3]) { or_cube_linear(cube, dim, dir, rgb, 3); }
+float or_sample_ambient_linear_clamp(const uint16_t* ambient, uint32_t w2, uint32_t h2, float u, float v)
+{
+    return or_ambient_linear_clamp(ambient, w2, h2, u, v);
+}
+float or_det_sinf(float x) { return or_det_sinf_(x); }
+float or_det_cosf(float x) { return or_det_cosf_(x); }
+float or_det_log2f(float x) { return or_det_log2f_(x); }
+float or_det_exp2f(float x) { return or_det_exp2f_(x); }
+float or_det_powf(float x, float y) { return or_det_powf_(x, y); }

@@ -1,0 +1,149 @@
+/*
+ * or_samplers.h -- D3D fixed-function sampler emulation for the oracle (TEST INFRASTRUCTURE).
+ *
+ * Rules: texel i has its centre at (i + 0.5) / dim; bilinear at uv uses
+ * t = uv*dim - 0.5, i0 = floor(t), f = t - i0, texels i0 and i0+1 with weights (1-f) and f, evaluated
+ * as lerp(a, b, f) = a + f*(b - a), x first then y; the address mode is applied per texel.
+ * Non-finite or far-out-of-range coordinates are DEFINED to address only out-of-range texels.
+ */
+#ifndef OR_SAMPLERS_H
+#define OR_SAMPLERS_H
+
+#include "or_math.h"
+
+/* D24_UNORM -> float: u24 / (2^24 - 1)  (ShadowMap.cpp:94 R24_UNORM_X8 view, Common/d3dApp.cpp depth SRV). */
+static inline float or_d24(uint32_t v) { return (float)(v & 0x00FFFFFFu) / 16777215.0f; }
+static inline float or_unorm16(uint16_t v) { return (float)v / 65535.0f; }
+static inline float or_unorm8(uint8_t v) { return (float)v / 255.0f; }
+/* UNORM write: floor(saturate(x) * (2^n - 1) + 0.5) */
+static inline uint16_t or_to_unorm16(float x) { return (uint16_t)(or_saturate(x) * 65535.0f + 0.5f); }
+static inline uint8_t or_to_unorm8(float x) { return (uint8_t)(or_saturate(x) * 255.0f + 0.5f); }
+
+typedef struct or_bilin {
+    int i0, j0;   /* top-left texel (may be out of range) */
+    float fx, fy; /* weights of the +1 texels */
+} or_bilin;
+
+/* Clamp the (already floored) coordinate into [-2, dim+1] so the int conversion is defined; anything
+ * non-finite maps to -2 (fully out of range). */
+static inline int or_texel_index(float fl, uint32_t dim)
+{
+    if (!(fl >= -2.0f)) return -2;
+    if (fl > (float)dim + 1.0f) return (int)dim + 1;
+    return (int)fl;
+}
+
+static inline or_bilin or_bilinear_setup(float u, float v, uint32_t w, uint32_t h)
+{
+    or_bilin b;
+    float tx = u * (float)w - 0.5f;
+    float ty = v * (float)h - 0.5f;
+    float flx = floorf(tx), fly = floorf(ty);
+    b.fx = tx - flx;
+    b.fy = ty - fly;
+    b.i0 = or_texel_index(flx, w);
+    b.j0 = or_texel_index(fly, h);
+    if (!(b.fx == b.fx) || !(b.fy == b.fy) || fabsf(tx) == INFINITY || fabsf(ty) == INFINITY) {
+        b.i0 = -2; b.j0 = -2; b.fx = 0.0f; b.fy = 0.0f;
+    }
+    return b;
+}
+
+static inline float or_bilerp(float a, float b, float c, float d, float fx, float fy)
+{
+    float top = or_lerp(a, b, fx);
+    float bot = or_lerp(c, d, fx);
+    return or_lerp(top, bot, fy);
+}
+
+/* gsamDepthMap: linear, border = opaque white (CRYCHIC.cpp:1057-1066). */
+static inline float or_depth_texel_border1(const uint32_t* d, uint32_t W, uint32_t H, int x, int y)
+{
+    if (x < 0 || y < 0 || x >= (int)W || y >= (int)H) return 1.0f;
+    return or_d24(d[(size_t)y * W + (size_t)x]);
+}
+static inline float or_depth_linear_border(const uint32_t* d, uint32_t W, uint32_t H, float u, float v)
+{
+    or_bilin b = or_bilinear_setup(u, v, W, H);
+    float t00 = or_depth_texel_border1(d, W, H, b.i0, b.j0);
+    float t10 = or_depth_texel_border1(d, W, H, b.i0 + 1, b.j0);
+    float t01 = or_depth_texel_border1(d, W, H, b.i0, b.j0 + 1);
+    float t11 = or_depth_texel_border1(d, W, H, b.i0 + 1, b.j0 + 1);
+    return or_bilerp(t00, t10, t01, t11, b.fx, b.fy);
+}
+
+/* gsamShadow: comparison LESS_EQUAL (ref <= texel), min-mag linear, border opaque black = 0
+ * (CRYCHIC.cpp:2649-2658).  Compare each texel first, then filter. */
+static inline float or_shadow_texel_cmp(const uint32_t* s, uint32_t dim, int x, int y, float ref)
+{
+    float t = (x < 0 || y < 0 || x >= (int)dim || y >= (int)dim) ? 0.0f : or_d24(s[(size_t)y * dim + (size_t)x]);
+    return (ref <= t) ? 1.0f : 0.0f;
+}
+static inline float or_shadow_cmp_linear(const uint32_t* s, uint32_t dim, float u, float v, float ref)
+{
+    or_bilin b = or_bilinear_setup(u, v, dim, dim);
+    float c00 = or_shadow_texel_cmp(s, dim, b.i0, b.j0, ref);
+    float c10 = or_shadow_texel_cmp(s, dim, b.i0 + 1, b.j0, ref);
+    float c01 = or_shadow_texel_cmp(s, dim, b.i0, b.j0 + 1, ref);
+    float c11 = or_shadow_texel_cmp(s, dim, b.i0 + 1, b.j0 + 1, ref);
+    return or_bilerp(c00, c10, c01, c11, b.fx, b.fy);
+}
+
+/* gsamLinearWrap on the 256x256 RGBA8 random-vector map (CRYCHIC.cpp:1068-1073). */
+static inline int or_wrap(int i, int dim) { int m = i % dim; return m < 0 ? m + dim : m; }
+static inline void or_randvec_linear_wrap(const uint8_t* rv, float u, float v, float rgb[3])
+{
+    /* wrap the coordinate first so the int conversion stays in range */
+    float uw = u - floorf(u), vw = v - floorf(v);
+    or_bilin b = or_bilinear_setup(uw, vw, 256, 256);
+    int x0 = or_wrap(b.i0, 256), x1 = or_wrap(b.i0 + 1, 256);
+    int y0 = or_wrap(b.j0, 256), y1 = or_wrap(b.j0 + 1, 256);
+    for (int c = 0; c < 3; ++c) {
+        float t00 = or_unorm8(rv[((size_t)y0 * 256 + x0) * 4 + c]);
+        float t10 = or_unorm8(rv[((size_t)y0 * 256 + x1) * 4 + c]);
+        float t01 = or_unorm8(rv[((size_t)y1 * 256 + x0) * 4 + c]);
+        float t11 = or_unorm8(rv[((size_t)y1 * 256 + x1) * 4 + c]);
+        rgb[c] = or_bilerp(t00, t10, t01, t11, b.fx, b.fy);
+    }
+}
+
+/* gsamLinearClamp on the half-res R16_UNORM ambient map (CRYCHIC.cpp:2624-2629). */
+static inline int or_clampi(int i, int lo, int hi) { return i < lo ? lo : (i > hi ? hi : i); }
+static inline float or_ambient_linear_clamp(const uint16_t* a, uint32_t w2, uint32_t h2, float u, float v)
+{
+    or_bilin b = or_bilinear_setup(u, v, w2, h2);
+    int x0 = or_clampi(b.i0, 0, (int)w2 - 1), x1 = or_clampi(b.i0 + 1, 0, (int)w2 - 1);
+    int y0 = or_clampi(b.j0, 0, (int)h2 - 1), y1 = or_clampi(b.j0 + 1, 0, (int)h2 - 1);
+    float t00 = or_unorm16(a[(size_t)y0 * w2 + x0]);
+    float t10 = or_unorm16(a[(size_t)y0 * w2 + x1]);
+    float t01 = or_unorm16(a[(size_t)y1 * w2 + x0]);
+    float t11 = or_unorm16(a[(size_t)y1 * w2 + x1]);
+    return or_bilerp(t00, t10, t01, t11, b.fx, b.fy);
+}
+
+/* TextureCube.Sample with gsamLinearWrap (DeferredShading.hlsl:95, sky.hlsl:46): D3D face selection
+ * (major axis, ties x >= y >= z), then bilinear inside the face with clamp-to-edge (seams are not
+ * filtered across faces -- oracle definition). Faces: +X,-X,+Y,-Y,+Z,-Z. */
+static inline void or_cube_linear(const uint8_t* cube, uint32_t dim, const float r[3], float* out, int nch)
+{
+    float ax = fabsf(r[0]), ay = fabsf(r[1]), az = fabsf(r[2]);
+    int face; float sc, tc, ma;
+    if (ax >= ay && ax >= az) { ma = ax; if (r[0] >= 0.0f) { face = 0; sc = -r[2]; tc = -r[1]; } else { face = 1; sc = r[2]; tc = -r[1]; } }
+    else if (ay >= az)        { ma = ay; if (r[1] >= 0.0f) { face = 2; sc = r[0]; tc = r[2]; } else { face = 3; sc = r[0]; tc = -r[2]; } }
+    else                      { ma = az; if (r[2] >= 0.0f) { face = 4; sc = r[0]; tc = -r[1]; } else { face = 5; sc = -r[0]; tc = -r[1]; } }
+    float u = 0.5f * (sc / ma + 1.0f);
+    float v = 0.5f * (tc / ma + 1.0f);
+    or_bilin b = or_bilinear_setup(u, v, dim, dim);
+    int x0 = or_clampi(b.i0, 0, (int)dim - 1), x1 = or_clampi(b.i0 + 1, 0, (int)dim - 1);
+    int y0 = or_clampi(b.j0, 0, (int)dim - 1), y1 = or_clampi(b.j0 + 1, 0, (int)dim - 1);
+    const uint8_t* f = cube + (size_t)face * dim * dim * 4;
+    for (int c = 0; c < nch; ++c) {
+        float t00 = or_unorm8(f[((size_t)y0 * dim + x0) * 4 + c]);
+        float t10 = or_unorm8(f[((size_t)y0 * dim + x1) * 4 + c]);
+        float t01 = or_unorm8(f[((size_t)y1 * dim + x0) * 4 + c]);
+        float t11 = or_unorm8(f[((size_t)y1 * dim + x1) * 4 + c]);
+        out[c] = or_bilerp(t00, t10, t01, t11, b.fx, b.fy);
+    }
+}
+
+#endif

@@ -1,0 +1,87 @@
+// hostsim.cpp -- TEST HARNESS ONLY.  Compiles the product's per-pixel kernel bodies (csrc/*_core.hpp, the very
+// text the gfx950 kernels inline) for the host CPU so that the CPU-only test tier can compare them bit for bit
+// with the oracle before any GPU time is spent.  Nothing in the product loads this library.
+#include <cstring>
+#include "ssao_core.hpp"
+#include "light_core.hpp"
+
+using namespace cry;
+
+extern "C" {
+
+float hs_d24_to_float(uint32_t v) { return d24_to_float(v); }
+float hs_unorm16_to_float(uint32_t v) { return unorm16_to_float(v); }
+float hs_unorm8_to_float(uint32_t v) { return unorm8_to_float(v); }
+float hs_half_to_float(uint16_t v) { return half_to_float(v); }
+float hs_det_sin(float x) { return det_sin(x); }
+float hs_det_cos(float x) { return det_cos(x); }
+float hs_det_log2(float x) { return det_log2(x); }
+float hs_det_exp2(float x) { return det_exp2(x); }
+float hs_det_pow(float x, float y) { return det_pow(x, y); }
+float hs_nrand(float u, float v) { return nrand(u, v); }
+
+void hs_ssao(const crychic_ssao_constants* cb, const void* normal, const uint32_t* depth, const uint8_t* randvec,
+             uint16_t* ambient, void* edge_base, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows)
+{
+    const uint32_t w2 = W / 2;
+    EdgePlane e{ nullptr, nullptr, nullptr, nullptr };
+    if (edge_base) e = edge_plane_carve(edge_base, W, H);
+    const u2* nrm = (const u2*)normal;
+    for (uint32_t y = row0; y < row0 + rows; ++y)
+        for (uint32_t x = 0; x < w2; ++x) {
+            const SsaoCentre c = ssao_centre(*cb, nrm, depth, W, H, (int)x, (int)y);
+            if (e.nrm) {
+                e.nrm[y * w2 + x] = c.nrm_bits;
+                e.vz[y * w2 + x] = c.vz;
+                if (x == 0) e.gcol[y] = nrm[(2u * y + 1u) * W];
+                if (y == row0) e.grow[x] = nrm[2u * x + 1u];
+            }
+            if (ambient) ambient[y * w2 + x] = (uint16_t)ssao_pixel(*cb, c, depth, (const uint32_t*)randvec, W, H, x, y);
+        }
+}
+
+void hs_blur(const crychic_ssao_constants* cb, void* edge_base, const uint16_t* in, uint16_t* out, uint32_t W,
+             uint32_t H, int horizontal, uint32_t row0, uint32_t rows)
+{
+    const int w2 = (int)(W / 2), h2 = (int)(H / 2);
+    const EdgePlane e = edge_plane_carve(edge_base, W, H);
+    const float borderZ = ndc_to_view(*cb, 1.0f);
+    for (int y = (int)row0; y < (int)(row0 + rows); ++y)
+        for (int x = 0; x < w2; ++x) {
+            BlurTap taps[11];
+            for (int i = 0; i < 11; ++i)
+                taps[i] = blur_fetch(e, in, borderZ, w2, h2, horizontal ? x + i - 5 : x, horizontal ? y : y + i - 5);
+            out[y * w2 + x] = (uint16_t)blur_resolve(&cb->BlurWeights[0][0], taps);
+        }
+}
+
+void hs_light(const crychic_pass_constants* cb, const float* g0, const float* g1, const float* g2,
+              const uint32_t* depth, const uint16_t* ambient, const uint32_t* const shadow[4], uint32_t shadowDim,
+              const uint8_t* cube, uint32_t cubeDim, uint8_t* out, float* radiance, uint32_t W, uint32_t H,
+              uint32_t row0, uint32_t rows, int numDirLights, float pcfSearchRadius, uint32_t flags)
+{
+    LightParams P;
+    std::memcpy(P.ViewProjTex, cb->ViewProjTex, sizeof P.ViewProjTex);
+    std::memcpy(P.ShadowTransforms, cb->ShadowTransforms, sizeof P.ShadowTransforms);
+    std::memcpy(P.InvProj, cb->InvProj, sizeof P.InvProj);
+    std::memcpy(P.InvView, cb->InvView, sizeof P.InvView);
+    std::memcpy(P.EyePosW, cb->EyePosW, sizeof P.EyePosW);
+    P.pcfSearchRadius = pcfSearchRadius;
+    std::memcpy(P.AmbientLight, cb->AmbientLight, sizeof P.AmbientLight);
+    std::memcpy(P.Lights, cb->Lights, sizeof P.Lights);
+    for (int i = 0; i < 4; ++i) P.shadow[i] = shadow[i];
+    P.shadowDim = shadowDim; P.cubeDim = cubeDim; P.W = W; P.H = H; P.numDirLights = numDirLights; P.flags = flags;
+    const f4a* G0 = (const f4a*)g0; const f4a* G1 = (const f4a*)g1; const f4a* G2 = (const f4a*)g2;
+    for (uint32_t y = row0; y < row0 + rows; ++y)
+        for (uint32_t x = 0; x < W; ++x) {
+            const uint32_t idx = y * W + x;
+            f4 lit;
+            if ((depth[idx] & 0x00FFFFFFu) < 0x00FFFFFFu) lit = light_pixel(P, G0[idx], G1[idx], G2[idx], ambient, (const uint32_t*)cube);
+            else if (flags & CRYCHIC_LIGHT_SKY) lit = sky_pixel(P, (const uint32_t*)cube, x, y);
+            else lit = f4{ 0.690196097f, 0.768627524f, 0.870588303f, 1.0f };
+            if (radiance) { radiance[4 * idx] = lit.x; radiance[4 * idx + 1] = lit.y; radiance[4 * idx + 2] = lit.z; radiance[4 * idx + 3] = lit.w; }
+            ((uint32_t*)out)[idx] = pack_rgba8(lit);
+        }
+}
+
+}  // extern "C"

@@ -1,0 +1,79 @@
+"""Builds and loads tests/hostsim/libhostsim.so: the product's per-pixel kernel bodies compiled for the host
+(TEST HARNESS ONLY -- lets the CPU-only tier compare the kernel text with the oracle bit for bit)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SRC = os.path.join(ROOT, "tests", "hostsim", "hostsim.cpp")
+LIB = os.path.join(ROOT, "tests", "hostsim", "libhostsim.so")
+CSRC = os.path.join(ROOT, "crychic_renderer_amd", "csrc")
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+def build():
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("devmath.hpp", "ssao_core.hpp", "light_core.hpp")]
+    if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
+        subprocess.run([CLANG, "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
+                        "-I", os.path.join(ROOT, "include"), "-I", CSRC, SRC, "-o", LIB], check=True)
+    return LIB
+
+
+class HostSim:
+    def __init__(self):
+        self.lib = L = C.CDLL(build())
+        f, u32, i, vp = C.c_float, C.c_uint32, C.c_int, C.c_void_p
+        for n in ("hs_d24_to_float", "hs_unorm16_to_float", "hs_unorm8_to_float"):
+            getattr(L, n).restype = f; getattr(L, n).argtypes = [u32]
+        L.hs_half_to_float.restype = f; L.hs_half_to_float.argtypes = [C.c_uint16]
+        for n in ("hs_det_sin", "hs_det_cos", "hs_det_log2", "hs_det_exp2"):
+            getattr(L, n).restype = f; getattr(L, n).argtypes = [f]
+        L.hs_det_pow.restype = f; L.hs_det_pow.argtypes = [f, f]
+        L.hs_nrand.restype = f; L.hs_nrand.argtypes = [f, f]
+        L.hs_ssao.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, u32, u32]
+        L.hs_blur.argtypes = [vp, vp, vp, vp, u32, u32, i, u32, u32]
+        L.hs_light.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp, u32, vp, vp, u32, u32, u32, u32, i, f, u32]
+
+    def ssao(self, cb, normal_f16, depth_u32, randvec_u8, edge_bytes, row0=0, rows=None, emit=True):
+        H, W = depth_u32.shape
+        rows = H // 2 - row0 if rows is None else rows
+        out = np.zeros((H // 2, W // 2), dtype=np.uint16)
+        edge = np.zeros((edge_bytes,), dtype=np.uint8)
+        n = np.ascontiguousarray(normal_f16.view(np.uint16)); d = np.ascontiguousarray(depth_u32); r = np.ascontiguousarray(randvec_u8)
+        self.lib.hs_ssao(C.addressof(cb), n.ctypes.data, d.ctypes.data, r.ctypes.data, out.ctypes.data if emit else None,
+                         edge.ctypes.data, W, H, row0, rows)
+        return out, edge
+
+    def blur(self, cb, edge, ambient_in, W, H, horizontal, row0=0, rows=None):
+        rows = H // 2 - row0 if rows is None else rows
+        out = np.zeros((H // 2, W // 2), dtype=np.uint16)
+        a = np.ascontiguousarray(ambient_in)
+        self.lib.hs_blur(C.addressof(cb), edge.ctypes.data, a.ctypes.data, out.ctypes.data, W, H, 1 if horizontal else 0, row0, rows)
+        return out
+
+    def light(self, cb, g0, g1, g2, depth_u32, ambient, shadow_u32, cube_u8, num_dir_lights, pcf_radius, flags=0,
+              want_radiance=False):
+        H, W = depth_u32.shape
+        out = np.zeros((H, W, 4), dtype=np.uint8)
+        rad = np.zeros((H, W, 4), dtype=np.float32) if want_radiance else None
+        g0, g1, g2 = (np.ascontiguousarray(g) for g in (g0, g1, g2))
+        d = np.ascontiguousarray(depth_u32); s = np.ascontiguousarray(shadow_u32); c = np.ascontiguousarray(cube_u8)
+        a = np.ascontiguousarray(ambient) if ambient is not None else None
+        sh = (C.c_void_p * 4)(*[s[k].ctypes.data for k in range(4)])
+        self.lib.hs_light(C.addressof(cb), g0.ctypes.data, g1.ctypes.data, g2.ctypes.data, d.ctypes.data,
+                          a.ctypes.data if a is not None else None, sh, s.shape[1], c.ctypes.data, c.shape[1],
+                          out.ctypes.data, rad.ctypes.data if rad is not None else None, W, H, 0, H, num_dir_lights,
+                          pcf_radius, flags)
+        return (out, rad) if want_radiance else out
+
+
+_HS = None
+
+
+def load():
+    global _HS
+    if _HS is None:
+        _HS = HostSim()
+    return _HS

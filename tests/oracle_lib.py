@@ -1,0 +1,145 @@
+"""ctypes wrapper of the CPU oracle (oracle/liboracle.so).  TEST INFRASTRUCTURE: only tests/, smoke() and the
+cpu_baseline leg of bench.py may import this module."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+LIB = os.path.join(ORACLE_DIR, "liboracle.so")
+
+
+class OrLight(C.Structure):
+    _fields_ = [("Strength", C.c_float * 3), ("FalloffStart", C.c_float), ("Direction", C.c_float * 3),
+                ("FalloffEnd", C.c_float), ("Position", C.c_float * 3), ("SpotPower", C.c_float)]
+
+
+class OrPassConstants(C.Structure):
+    _fields_ = [("View", C.c_float * 16), ("InvView", C.c_float * 16), ("Proj", C.c_float * 16),
+                ("InvProj", C.c_float * 16), ("ViewProj", C.c_float * 16), ("InvViewProj", C.c_float * 16),
+                ("ViewProjTex", C.c_float * 16), ("ShadowTransforms", (C.c_float * 16) * 12),
+                ("EyePosW", C.c_float * 3), ("cbPerObjectPad1", C.c_float), ("RenderTargetSize", C.c_float * 2),
+                ("InvRenderTargetSize", C.c_float * 2), ("NearZ", C.c_float), ("FarZ", C.c_float),
+                ("TotalTime", C.c_float), ("DeltaTime", C.c_float), ("AmbientLight", C.c_float * 4),
+                ("Lights", OrLight * 16)]
+
+
+class OrSsaoConstants(C.Structure):
+    _fields_ = [("Proj", C.c_float * 16), ("InvProj", C.c_float * 16), ("ProjTex", C.c_float * 16),
+                ("OffsetVectors", (C.c_float * 4) * 14), ("BlurWeights", (C.c_float * 4) * 3),
+                ("RenderTargetSize", C.c_float * 2), ("InvRenderTargetSize", C.c_float * 2),
+                ("OcclusionRadius", C.c_float), ("OcclusionFadeStart", C.c_float), ("OcclusionFadeEnd", C.c_float),
+                ("SurfaceEpsilon", C.c_float)]
+
+
+class OrCamera(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("look", C.c_float * 3), ("up", C.c_float * 3), ("fovY", C.c_float),
+                ("aspect", C.c_float), ("nearZ", C.c_float), ("farZ", C.c_float)]
+
+
+def build(force=False):
+    srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h")) or f == "Makefile"]
+    if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
+        subprocess.run(["make", "-C", ORACLE_DIR, "-B", "liboracle.so"], check=True, stdout=subprocess.DEVNULL)
+    return LIB
+
+
+def _np(a, dtype):
+    a = np.ascontiguousarray(a)
+    assert a.dtype == dtype, (a.dtype, dtype)
+    return a
+
+
+class Oracle:
+    def __init__(self):
+        self.lib = C.CDLL(build())
+        L = self.lib
+        f, u32, i, vp = C.c_float, C.c_uint32, C.c_int, C.c_void_p
+        for name in ("or_det_sinf", "or_det_cosf", "or_det_log2f", "or_det_exp2f"):
+            getattr(L, name).restype = f
+            getattr(L, name).argtypes = [f]
+        L.or_det_powf.restype = f; L.or_det_powf.argtypes = [f, f]
+        L.or_half_to_float.restype = f; L.or_half_to_float.argtypes = [C.c_uint16]
+        L.or_d24_to_float.restype = f; L.or_d24_to_float.argtypes = [u32]
+        L.or_nrand.restype = f; L.or_nrand.argtypes = [f, f]
+        L.or_randf.restype = f
+        L.or_pcf_search_radius.restype = f; L.or_pcf_search_radius.argtypes = [u32, i]
+        L.or_ndc_depth_to_view_depth.restype = f; L.or_ndc_depth_to_view_depth.argtypes = [vp, f]
+        L.or_sample_depth_linear_border.restype = f
+        L.or_sample_depth_linear_border.argtypes = [vp, u32, u32, f, f]
+        L.or_sample_shadow_cmp.restype = f; L.or_sample_shadow_cmp.argtypes = [vp, u32, f, f, f]
+        L.or_pcf_poisson.restype = f; L.or_pcf_poisson.argtypes = [vp, u32, vp, f]
+        L.or_sample_ambient_linear_clamp.restype = f
+        L.or_sample_ambient_linear_clamp.argtypes = [vp, u32, u32, f, f]
+        L.or_calc_gauss_weights.argtypes = [f, vp, i]
+        L.or_cascade_shadow_transforms.argtypes = [vp, vp, u32, vp, vp, vp]
+        L.or_build_pass_constants.argtypes = [vp, u32, u32, vp, vp, vp]
+        L.or_build_ssao_constants.argtypes = [vp, u32, u32, vp, vp]
+        L.or_ssao.argtypes = [vp, vp, vp, vp, u32, u32, vp, u32, u32]
+        L.or_ssao_blur.argtypes = [vp, vp, vp, vp, vp, u32, u32, i, u32, u32]
+        L.or_compute_ssao.argtypes = [vp, vp, vp, vp, u32, u32, vp, vp, i]
+        L.or_deferred_light.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp, u32, vp, vp, u32, u32, u32, u32, i, f, i]
+        L.or_mat_perspective_fov_lh.argtypes = [f, f, f, f, vp]
+        L.or_num_threads.restype = i
+
+    # ---- passes on numpy arrays (inputs are converted to the plane layouts of crychic_oracle.h) ----
+    def ssao(self, cb, normal_f16, depth_u32, randvec_u8, row0=0, rows=None):
+        H, W = depth_u32.shape
+        rows = H // 2 - row0 if rows is None else rows
+        out = np.zeros((H // 2, W // 2), dtype=np.uint16)
+        n = _np(normal_f16.view(np.uint16), np.uint16); d = _np(depth_u32, np.uint32); r = _np(randvec_u8, np.uint8)
+        self.lib.or_ssao(C.addressof(cb), n.ctypes.data, d.ctypes.data, r.ctypes.data, W, H, out.ctypes.data, row0, rows)
+        return out
+
+    def blur(self, cb, normal_f16, depth_u32, ambient_in, horizontal, row0=0, rows=None):
+        H, W = depth_u32.shape
+        rows = H // 2 - row0 if rows is None else rows
+        out = np.zeros((H // 2, W // 2), dtype=np.uint16)
+        n = _np(normal_f16.view(np.uint16), np.uint16); d = _np(depth_u32, np.uint32); a = _np(ambient_in, np.uint16)
+        self.lib.or_ssao_blur(C.addressof(cb), n.ctypes.data, d.ctypes.data, a.ctypes.data, out.ctypes.data, W, H,
+                              1 if horizontal else 0, row0, rows)
+        return out
+
+    def compute_ssao(self, cb, normal_f16, depth_u32, randvec_u8, blur_count):
+        H, W = depth_u32.shape
+        a0 = np.zeros((H // 2, W // 2), dtype=np.uint16); a1 = np.zeros_like(a0)
+        n = _np(normal_f16.view(np.uint16), np.uint16); d = _np(depth_u32, np.uint32); r = _np(randvec_u8, np.uint8)
+        self.lib.or_compute_ssao(C.addressof(cb), n.ctypes.data, d.ctypes.data, r.ctypes.data, W, H, a0.ctypes.data,
+                                 a1.ctypes.data, blur_count)
+        return a0
+
+    def deferred_light(self, cb, g0, g1, g2, depth_u32, ambient, shadow_u32, cube_u8, num_dir_lights, pcf_radius,
+                       sky=False, want_radiance=False, row0=0, rows=None):
+        H, W = depth_u32.shape
+        rows = H - row0 if rows is None else rows
+        out = np.zeros((H, W, 4), dtype=np.uint8)
+        rad = np.zeros((H, W, 4), dtype=np.float32) if want_radiance else None
+        g0, g1, g2 = (_np(g, np.float32) for g in (g0, g1, g2))
+        d = _np(depth_u32, np.uint32); s = _np(shadow_u32, np.uint32); c = _np(cube_u8, np.uint8)
+        a = _np(ambient, np.uint16) if ambient is not None else None
+        sh = (C.c_void_p * 4)(*[s[k].ctypes.data for k in range(4)])
+        self.lib.or_deferred_light(C.addressof(cb), g0.ctypes.data, g1.ctypes.data, g2.ctypes.data, d.ctypes.data,
+                                   a.ctypes.data if a is not None else None, sh, s.shape[1], c.ctypes.data, c.shape[1],
+                                   out.ctypes.data, rad.ctypes.data if rad is not None else None, W, H, row0, rows,
+                                   num_dir_lights, pcf_radius, 1 if sky else 0)
+        return (out, rad) if want_radiance else out
+
+
+_ORACLE = None
+
+
+def load():
+    global _ORACLE
+    if _ORACLE is None:
+        _ORACLE = Oracle()
+    return _ORACLE
+
+
+def as_oracle_cb(product_cb, cls):
+    """Reinterpret a product constant struct (same byte layout) as the oracle's struct."""
+    o = cls()
+    assert C.sizeof(o) == C.sizeof(product_cb)
+    C.memmove(C.addressof(o), C.addressof(product_cb), C.sizeof(o))
+    return o
