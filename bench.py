@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- Mpixels/s of the CRYCHIC hot path (SSAO + 2*blurCount bilateral sweeps + deferred PBR lighting)
+on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one frame: every input plane (G-buffer, view normals, depth, 4 shadow cascades, cubemap, noise) is
+already resident in HBM; the step runs crychic_draw_hot_path for this rank's row strip and, for N > 1, the RCCL
+all-gather of the composed RGBA8 strips (strong scaling of ONE frame, the only collective).
+Workload = BASELINE.json configs[2]: 3840x2160, 3 directional lights, blurCount 4, cascade PCF.
+The PCF radius follows the reference shader as written (Common.hlsl:305 unsigned division => 16 coincident taps);
+--pcf intended benches the 2.5-texel variant instead.
+
+Rank 0 prints ONE JSON line: metric/value/... plus "roofline" (dominant kernel = deferred lighting, measured with
+HIP events on the launch stream) and "cpu_baseline" (the CPU oracle timed on a bounded band of the same frame).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--blur-count", type=int, default=4)
+    ap.add_argument("--lights", type=int, default=3)
+    ap.add_argument("--shadow-dim", type=int, default=4096)
+    ap.add_argument("--cube-dim", type=int, default=256)
+    ap.add_argument("--pcf", choices=["literal", "intended"], default="literal")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-band-rows", type=int, default=0, help="full-res rows of the CPU baseline band (0 = auto)")
+    return ap.parse_args()
+
+
+def cpu_baseline(planes, args, pcf_radius):
+    """The CPU oracle (oracle/, OpenMP over rows, all host cores) on a horizontal band through the middle of the
+    same frame; band size is calibrated so the leg takes roughly 10-30 s.  kind = "port": the reference has no CPU
+    implementation (D3D12 + HLSL only), the oracle is this repo's literal restatement."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import numpy as np
+    import oracle_lib
+    import scene_util
+    orc = oracle_lib.load()
+    p = scene_util.np_planes(planes)
+    consts = planes["consts"]
+    scb = oracle_lib.as_oracle_cb(consts.ssao_cb, oracle_lib.OrSsaoConstants)
+    pcb = oracle_lib.as_oracle_cb(consts.pass_cb, oracle_lib.OrPassConstants)
+    W, H = args.width, args.height
+    bc = args.blur_count
+
+    def run_band(rows_full):
+        rows_full = max(2, min(H, rows_full) & ~1)
+        r0 = ((H - rows_full) // 2) & ~1
+        h0, hn = r0 // 2, rows_full // 2
+        t0 = time.perf_counter()
+        a0 = orc.ssao(scb, p["normal"], p["depth"], p["randvec"], h0, hn)
+        cur = a0
+        for _ in range(bc):
+            cur = orc.blur(scb, p["normal"], p["depth"], cur, True, h0, hn)
+            cur = orc.blur(scb, p["normal"], p["depth"], cur, False, h0, hn)
+        orc.deferred_light(pcb, p["g0"], p["g1"], p["g2"], p["depth"], cur, p["shadow"], p["cube"], args.lights, pcf_radius,
+                           row0=r0, rows=rows_full)
+        return rows_full, time.perf_counter() - t0
+
+    rows, dt = run_band(args.cpu_band_rows or 64)
+    if not args.cpu_band_rows:
+        target = 15.0
+        want = int(rows * target / max(dt, 1e-3))
+        if want > rows * 2:
+            rows, dt = run_band(min(H, want))
+    return {"value": round(rows * W / dt / 1e6, 3), "unit": "Mpixels/s", "cores": int(orc.lib.or_num_threads()), "kind": "port",
+            "sample": "oracle (C, OpenMP) SSAO + %d blur sweeps + lighting on a %d-row band (%d x %d px) of the same "
+                      "frame, %.1f s" % (2 * bc, rows, W, rows, dt)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from crychic_renderer_amd import build
+    if rank == 0:
+        build.build(verbose=False)
+    if world > 1:
+        dist.barrier()
+    from crychic_renderer_amd import Context, Crychic, scene
+    from crychic_renderer_amd._lib import lib, check
+    from crychic_renderer_amd import sharding
+
+    W, H = args.width, args.height
+    ctx = Context(local_rank)
+    dev = ctx.device
+    planes = scene.make_scene(W, H, shadow_dim=args.shadow_dim, cube_dim=args.cube_dim, device=str(dev))
+    app = Crychic(ctx, W, H, planes["randvec"], planes["cube"], shadow_dim=args.shadow_dim)
+    app.load_scene(planes)
+    app.blurCount, app.numDirLights = args.blur_count, args.lights
+    app.pcfSearchRadius = lib.crychic_pcf_search_radius(args.shadow_dim, 1 if args.pcf == "literal" else 0)
+    row0, rows = sharding.strip_rows(H, world, rank)
+    gather = sharding.FrameGather(W, H, world, rank, dev) if world > 1 else None
+
+    def step(i):
+        if gather is None:
+            app.Draw(row0, rows)
+        else:
+            app.mBackBuffer = gather.strip_buffer(i)   # double-buffered so gather(i) overlaps Draw(i+1)
+            app.Draw(row0, rows)
+            gather.launch(i)
+
+    def fence():
+        if gather is not None:
+            gather.wait_all()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # ---- per-pass timing of the same workload (HIP events recorded by the library on the launch stream) ----
+    app.set_profiling(True)
+    app.mBackBuffer = planes["out"]
+    acc = {"ssao_ms": 0.0, "blur_ms": 0.0, "light_ms": 0.0, "total_ms": 0.0}
+    nprof = max(5, min(50, args.steps))
+    for _ in range(nprof):
+        app.Draw(row0, rows)
+        t = app.last_pass_times()
+        for k in acc:
+            acc[k] += t[k] / nprof
+    app.set_profiling(False)
+
+    if rank == 0:
+        npx = W * H
+        strip_px = W * rows
+        # algorithmic bytes of the lighting pass: 48 B G0..G2 + 2 B/4 px ambient + 4 B RGBA8 out = 52.5 B per pixel
+        # (depth mask, shadow cascades and cubemap are not counted)
+        light_bytes = 52.5 * strip_px
+        achieved = light_bytes / (acc["light_ms"] * 1e-3) / 1e9
+        frame_bytes = (59 + 14 * args.blur_count) * npx
+        out = {
+            "metric": "Mpixels/s for G-buffer->SSAO+blur->deferred PBR lighting at 4K",
+            "value": round(npx * args.steps / dt / 1e6, 2),
+            "unit": "Mpixels/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: %dx%d, box+grid scene, %d dir lights, 14-tap SSAO + %d-pass bilateral "
+                                   "blur + cascade PCF (%s radius), 4x%d^2 D24 shadow maps" % (W, H, args.lights, args.blur_count,
+                                                                                             args.pcf, args.shadow_dim),
+                       "sharding": "row strips x%d + RCCL all-gather of RGBA8 strips" % world if world > 1 else "single GPU",
+                       "frame_algorithmic_MB": round(frame_bytes / 1e6, 1),
+                       "frame_hbm_roofline_frac": round(frame_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS * world, 4)
+                       if world == 1 else None,
+                       "pass_ms": {k: round(v, 4) for k, v in acc.items()}},
+            "roofline": {"kernel": "light_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(planes, args, app.pcfSearchRadius)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -98,7 +98,22 @@ class CrychicError(RuntimeError):
         self.status = status
 
 
+def _preload_hip_runtime():
+    """PyTorch wheels bundle their own libamdhip64.so (same soname as /opt/rocm's).  Device pointers handed to the C
+    ABI come from torch's allocator, so both must live in ONE HIP runtime: load torch's copy first, then the
+    dynamic linker resolves libcrychic_hip.so's NEEDED libamdhip64.so.7 to it by soname.  Without torch (pure C++
+    callers) the library simply binds to /opt/rocm's runtime."""
+    try:
+        import torch  # noqa: F401  (imports its bundled runtime)
+    except ImportError:
+        return
+    cand = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load():
+    _preload_hip_runtime()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "libcrychic_hip.so is not built (%s). Run `python -m crychic_renderer_amd.build`; "

@@ -1,0 +1,281 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on the same seeded
+inputs.  Bar: BIT-EXACT on every plane (R16 ambient, RGBA8 colour, and the fp32 radiance bits) -- the kernels use
+the oracle's IEEE-754 evaluation order (DESIGN.md "Numerical contract"), so no tolerance is needed; where a
+tolerance would apply (radiance) it is stated as 0 ulp.  Oracle = oracle/ (parity unpinned, see its header)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib
+import scene_util
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(built_lib):
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests selected but no HIP device is visible")
+    from crychic_renderer_amd import Context
+    c = Context(0)
+    assert "gfx950" in c.device_name, c.device_name
+    yield c
+    c.close()
+
+
+def to_dev(p, ctx):
+    return {k: torch.from_numpy(np.ascontiguousarray(v).view(np.int32) if v.dtype == np.uint32 else np.ascontiguousarray(v)).to(ctx.device)
+            for k, v in p.items()}
+
+
+def dev_u16(t):
+    return t.cpu().numpy().view(np.uint16)
+
+
+def ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def stream(ctx):
+    return C.c_void_p(torch.cuda.current_stream(ctx.device).cuda_stream)
+
+
+class Case:
+    """One seeded scene: numpy planes for the oracle + device copies for the HIP path."""
+
+    def __init__(self, ctx, built_lib, W, H, shadow_dim=512, cube_dim=64, device="cpu"):
+        from crychic_renderer_amd import scene
+        self.W, self.H = W, H
+        if device == "cpu":
+            self.planes = scene_util.cpu_scene(W, H, shadow_dim, cube_dim)
+        else:
+            self.planes = scene.make_scene(W, H, shadow_dim=shadow_dim, cube_dim=cube_dim, device=device)
+        self.np = scene_util.np_planes(self.planes)
+        self.dev = to_dev(self.np, ctx)
+        self.consts = self.planes["consts"]
+        self.scb = oracle_lib.as_oracle_cb(self.consts.ssao_cb, oracle_lib.OrSsaoConstants)
+        self.pcb = oracle_lib.as_oracle_cb(self.consts.pass_cb, oracle_lib.OrPassConstants)
+        w2, h2 = W // 2, H // 2
+        self.a0 = torch.zeros((h2, w2), dtype=torch.int16, device=ctx.device)
+        self.a1 = torch.zeros((h2, w2), dtype=torch.int16, device=ctx.device)
+        self.edge = torch.zeros((int(built_lib.lib.crychic_edge_plane_bytes(W, H)),), dtype=torch.uint8, device=ctx.device)
+        self.out = torch.zeros((H, W, 4), dtype=torch.uint8, device=ctx.device)
+        self.rad = torch.zeros((H, W, 4), dtype=torch.float32, device=ctx.device)
+        self.shadow_ptrs = (C.c_void_p * 4)(*[self.dev["shadow"][k].data_ptr() for k in range(4)])
+
+
+_cases = {}
+
+
+def get_case(ctx, built_lib, W, H, **kw):
+    key = (W, H, tuple(sorted(kw.items())))
+    if key not in _cases:
+        _cases[key] = Case(ctx, built_lib, W, H, **kw)
+    return _cases[key]
+
+
+SIZES = [(64, 64), (256, 256), (322, 190), (130, 34)]
+
+
+@pytest.mark.parametrize("W,H", SIZES)
+def test_ssao_bit_exact(ctx, built_lib, oracle, W, H):
+    c = get_case(ctx, built_lib, W, H)
+    lib, check = built_lib.lib, built_lib.check
+    check(lib.crychic_ssao(ctx.handle, C.byref(c.consts.ssao_cb), ptr(c.dev["normal"]), ptr(c.dev["depth"]),
+                           ptr(c.dev["randvec"]), ptr(c.a0), ptr(c.edge), W, H, 0, H // 2, stream(ctx)))
+    torch.cuda.synchronize()
+    ref = oracle.ssao(c.scb, c.np["normal"], c.np["depth"], c.np["randvec"])
+    got = dev_u16(c.a0)
+    assert np.array_equal(got, ref), "ambient differs in %d of %d pixels" % ((got != ref).sum(), ref.size)
+    assert ref.min() < 65535  # the scene really occludes something
+
+
+@pytest.mark.parametrize("W,H", SIZES)
+def test_blur_sweeps_bit_exact(ctx, built_lib, oracle, W, H):
+    c = get_case(ctx, built_lib, W, H)
+    lib, check = built_lib.lib, built_lib.check
+    rng = np.random.default_rng(1234 + W)
+    amb = rng.integers(0, 65536, size=(H // 2, W // 2), dtype=np.uint16)  # noise: exercises every accept/reject mix
+    check(lib.crychic_ssao_edges(ctx.handle, C.byref(c.consts.ssao_cb), ptr(c.dev["normal"]), ptr(c.dev["depth"]),
+                                 ptr(c.edge), W, H, 0, H // 2, stream(ctx)))
+    cur = amb
+    for horz in (1, 0, 1, 0):
+        c.a0.copy_(torch.from_numpy(cur.view(np.int16)))
+        check(lib.crychic_ssao_blur(ctx.handle, C.byref(c.consts.ssao_cb), ptr(c.edge), ptr(c.a0), ptr(c.a1), W, H, horz,
+                                    0, H // 2, stream(ctx)))
+        torch.cuda.synchronize()
+        ref = oracle.blur(c.scb, c.np["normal"], c.np["depth"], cur, bool(horz))
+        got = dev_u16(c.a1)
+        assert np.array_equal(got, ref), "sweep horz=%d differs in %d pixels" % (horz, (got != ref).sum())
+        cur = ref
+
+
+@pytest.mark.parametrize("blur_count", [0, 1, 3, 4])
+def test_compute_ssao_bit_exact(ctx, built_lib, oracle, blur_count):
+    W, H = 256, 256
+    c = get_case(ctx, built_lib, W, H)
+    lib, check = built_lib.lib, built_lib.check
+    check(lib.crychic_ssao_compute(ctx.handle, C.byref(c.consts.ssao_cb), ptr(c.dev["normal"]), ptr(c.dev["depth"]),
+                                   ptr(c.dev["randvec"]), ptr(c.a0), ptr(c.a1), ptr(c.edge), W, H, blur_count, 0, H // 2,
+                                   stream(ctx)))
+    torch.cuda.synchronize()
+    ref = oracle.compute_ssao(c.scb, c.np["normal"], c.np["depth"], c.np["randvec"], blur_count)
+    assert np.array_equal(dev_u16(c.a0), ref)
+
+
+@pytest.mark.parametrize("W,H", [(64, 64), (256, 256), (322, 190)])
+@pytest.mark.parametrize("num_dir_lights,literal,sky,ssao_on", [(1, 1, 0, 1), (3, 1, 1, 1), (3, 0, 0, 1), (1, 0, 1, 0)])
+def test_deferred_light_bit_exact(ctx, built_lib, oracle, W, H, num_dir_lights, literal, sky, ssao_on):
+    c = get_case(ctx, built_lib, W, H)
+    lib, check = built_lib.lib, built_lib.check
+    amb = oracle.compute_ssao(c.scb, c.np["normal"], c.np["depth"], c.np["randvec"], 1) if ssao_on else None
+    if ssao_on:
+        c.a0.copy_(torch.from_numpy(amb.view(np.int16)))
+    radius = lib.crychic_pcf_search_radius(c.np["shadow"].shape[1], literal)
+    assert (radius == 0.0) == bool(literal)
+    check(lib.crychic_deferred_light(ctx.handle, C.byref(c.consts.pass_cb), ptr(c.dev["g0"]), ptr(c.dev["g1"]),
+                                     ptr(c.dev["g2"]), ptr(c.dev["depth"]), ptr(c.a0) if ssao_on else None,
+                                     c.shadow_ptrs, c.np["shadow"].shape[1], ptr(c.dev["cube"]), c.np["cube"].shape[1],
+                                     ptr(c.out), ptr(c.rad), W, H, 0, H, num_dir_lights, radius, sky, stream(ctx)))
+    torch.cuda.synchronize()
+    ref, ref_rad = oracle.deferred_light(c.pcb, c.np["g0"], c.np["g1"], c.np["g2"], c.np["depth"], amb, c.np["shadow"],
+                                         c.np["cube"], num_dir_lights, radius, sky=bool(sky), want_radiance=True)
+    got, got_rad = c.out.cpu().numpy(), c.rad.cpu().numpy()
+    assert np.array_equal(got, ref), "RGBA8 differs in %d of %d channels" % ((got != ref).sum(), ref.size)
+    # radiance: tolerance 0 ulp (bit pattern equality, NaN-safe)
+    assert np.array_equal(got_rad.view(np.uint32), ref_rad.view(np.uint32))
+
+
+def test_draw_hot_path_matches_oracle_and_strips(ctx, built_lib, oracle):
+    """crychic_draw_hot_path == oracle ComputeSsao + lighting; rendering the frame as 1, 2, 3 and 8 row strips
+    (the multi-GPU decomposition, each strip recomputing its own SSAO/blur halo) gives the same bytes."""
+    from crychic_renderer_amd import Crychic
+    W, H = 256, 256
+    c = get_case(ctx, built_lib, W, H)
+    app = Crychic(ctx, W, H, c.dev["randvec"], c.dev["cube"], shadow_dim=c.np["shadow"].shape[1])
+    app.load_scene({**c.dev, "consts": c.consts})
+    app.blurCount, app.numDirLights = 3, 3
+    app.pcfSearchRadius = built_lib.lib.crychic_pcf_search_radius(c.np["shadow"].shape[1], 0)
+    app.Draw()
+    torch.cuda.synchronize()
+    full = app.mBackBuffer.cpu().numpy().copy()
+    amb = oracle.compute_ssao(c.scb, c.np["normal"], c.np["depth"], c.np["randvec"], 3)
+    ref = oracle.deferred_light(c.pcb, c.np["g0"], c.np["g1"], c.np["g2"], c.np["depth"], amb, c.np["shadow"], c.np["cube"],
+                                3, app.pcfSearchRadius)
+    assert np.array_equal(full, ref)
+    for nranks in (2, 3, 8):
+        app.mBackBuffer.zero_()
+        for rank in range(nranks):
+            r0, rn = C.c_uint32(), C.c_uint32()
+            built_lib.check(built_lib.lib.crychic_strip_rows(H, nranks, rank, C.byref(r0), C.byref(rn)))
+            # poison the AO planes so a strip cannot lean on rows another strip computed
+            app.mSsao.mAmbientMap0.fill_(0x5A5A)
+            app.mSsao.mAmbientMap1.fill_(0x2525)
+            app.Draw(r0.value, rn.value)
+        torch.cuda.synchronize()
+        assert np.array_equal(app.mBackBuffer.cpu().numpy(), full), "strip decomposition nranks=%d differs" % nranks
+
+
+def test_c2_1080p_parity(ctx, built_lib, oracle):
+    """BASELINE config 2: 1920x1080, 3 lights, 14-sample SSAO + 1 blur pass, vs the oracle."""
+    from crychic_renderer_amd import Crychic
+    W, H = 1920, 1080
+    c = get_case(ctx, built_lib, W, H, shadow_dim=1024, cube_dim=128, device=str(ctx.device))
+    app = Crychic(ctx, W, H, c.dev["randvec"], c.dev["cube"], shadow_dim=1024)
+    app.load_scene({**c.dev, "consts": c.consts})
+    app.blurCount, app.numDirLights = 1, 3
+    app.Draw()
+    torch.cuda.synchronize()
+    amb = oracle.compute_ssao(c.scb, c.np["normal"], c.np["depth"], c.np["randvec"], 1)
+    assert np.array_equal(dev_u16(app.mSsao.mAmbientMap0), amb)
+    ref = oracle.deferred_light(c.pcb, c.np["g0"], c.np["g1"], c.np["g2"], c.np["depth"], amb, c.np["shadow"], c.np["cube"],
+                                3, app.pcfSearchRadius)
+    assert np.array_equal(app.mBackBuffer.cpu().numpy(), ref)
+
+
+def test_c3_4k_properties(ctx, built_lib, oracle):
+    """BASELINE config 3 size (3840x2160, blurCount 4): size-independent properties + oracle spot rows."""
+    from crychic_renderer_amd import Crychic
+    W, H = 3840, 2160
+    c = get_case(ctx, built_lib, W, H, shadow_dim=2048, cube_dim=256, device=str(ctx.device))
+    lib, check = built_lib.lib, built_lib.check
+    app = Crychic(ctx, W, H, c.dev["randvec"], c.dev["cube"], shadow_dim=2048)
+    app.load_scene({**c.dev, "consts": c.consts})
+    app.blurCount, app.numDirLights = 4, 3
+    app.Draw()
+    torch.cuda.synchronize()
+    full = app.mBackBuffer.cpu().numpy().copy()
+    ao = dev_u16(app.mSsao.mAmbientMap0).copy()
+    # (1) idempotence / determinism: a second draw gives the same bytes
+    app.Draw()
+    torch.cuda.synchronize()
+    assert np.array_equal(app.mBackBuffer.cpu().numpy(), full)
+    # (2) strip decomposition (8 ranks) == whole frame
+    app.mBackBuffer.zero_()
+    for rank in range(8):
+        r0, rn = C.c_uint32(), C.c_uint32()
+        check(lib.crychic_strip_rows(H, 8, rank, C.byref(r0), C.byref(rn)))
+        app.mSsao.mAmbientMap0.fill_(0x5A5A)
+        app.Draw(r0.value, rn.value)
+    torch.cuda.synchronize()
+    assert np.array_equal(app.mBackBuffer.cpu().numpy(), full)
+    # (3) blur of a constant map is the identity
+    check(lib.crychic_ssao_edges(ctx.handle, C.byref(c.consts.ssao_cb), ptr(c.dev["normal"]), ptr(c.dev["depth"]),
+                                 ptr(c.edge), W, H, 0, H // 2, stream(ctx)))
+    c.a0.fill_(12345)
+    for horz in (1, 0):
+        check(lib.crychic_ssao_blur(ctx.handle, C.byref(c.consts.ssao_cb), ptr(c.edge), ptr(c.a0), ptr(c.a1), W, H, horz, 0,
+                                    H // 2, stream(ctx)))
+        torch.cuda.synchronize()
+        assert int((c.a1 != 12345).sum()) == 0
+    # (4) uncovered pixels carry the clear colour, covered ones alpha 255
+    cov = c.np["depth"] < 0xFFFFFF
+    assert (full[~cov] == np.array([176, 196, 222, 255], dtype=np.uint8)).all()
+    assert (full[cov][:, 3] == 255).all()
+    # (5) oracle on a band of rows in the middle of the frame (SSAO rows via the oracle's row range)
+    band0, band1 = H // 2 - 24, H // 2 + 24
+    ref_ssao = oracle.ssao(c.scb, c.np["normal"], c.np["depth"], c.np["randvec"], band0 // 2, (band1 - band0) // 2)
+    check(lib.crychic_ssao(ctx.handle, C.byref(c.consts.ssao_cb), ptr(c.dev["normal"]), ptr(c.dev["depth"]),
+                           ptr(c.dev["randvec"]), ptr(c.a0), None, W, H, 0, H // 2, stream(ctx)))
+    torch.cuda.synchronize()
+    assert np.array_equal(dev_u16(c.a0)[band0 // 2:band1 // 2], ref_ssao[band0 // 2:band1 // 2])
+    ref_band = oracle.deferred_light(c.pcb, c.np["g0"], c.np["g1"], c.np["g2"], c.np["depth"], ao, c.np["shadow"], c.np["cube"],
+                                     3, app.pcfSearchRadius, row0=band0, rows=band1 - band0)
+    assert np.array_equal(full[band0:band1], ref_band[band0:band1])
+
+
+def test_flat_wall_ssao_is_unoccluded(ctx, built_lib):
+    """a flat plane facing the camera has distZ = 0 <= eps for every tap => access = 1."""
+    W, H = 128, 128
+    c = get_case(ctx, built_lib, 64, 64)
+    consts = scene_util.cpu_scene(W, H, 512, 64)["consts"]
+    depth = torch.full((H, W), int(round(0.5 * 16777215)), dtype=torch.int32, device=ctx.device)
+    normal = torch.zeros((H, W, 4), dtype=torch.float16, device=ctx.device)
+    normal[..., 2] = -1.0
+    a = torch.zeros((H // 2, W // 2), dtype=torch.int16, device=ctx.device)
+    built_lib.check(built_lib.lib.crychic_ssao(ctx.handle, C.byref(consts.ssao_cb), ptr(normal), ptr(depth), ptr(c.dev["randvec"]),
+                                               ptr(a), None, W, H, 0, H // 2, stream(ctx)))
+    torch.cuda.synchronize()
+    inner = dev_u16(a)[8:-8, 8:-8]  # away from the border (taps that leave the map see depth 1.0)
+    assert (inner == 65535).all()
+
+
+def test_error_behaviour(ctx, built_lib):
+    """Argument errors come back as negative status + message (the reference throws DxException)."""
+    lib = built_lib.lib
+    c = get_case(ctx, built_lib, 64, 64)
+    rc = lib.crychic_ssao(ctx.handle, C.byref(c.consts.ssao_cb), ptr(c.dev["normal"]), ptr(c.dev["depth"]), ptr(c.dev["randvec"]),
+                          ptr(c.a0), None, 63, 64, 0, 32, stream(ctx))
+    assert rc == -1 and b"even" in lib.crychic_last_error()
+    rc = lib.crychic_ssao(ctx.handle, C.byref(c.consts.ssao_cb), None, ptr(c.dev["depth"]), ptr(c.dev["randvec"]), ptr(c.a0), None,
+                          64, 64, 0, 32, stream(ctx))
+    assert rc == -1
+    rc = lib.crychic_ssao_blur(ctx.handle, C.byref(c.consts.ssao_cb), ptr(c.edge), ptr(c.a0), ptr(c.a0), 64, 64, 1, 0, 32, stream(ctx))
+    assert rc == -1 and b"in place" in lib.crychic_last_error()
+    rc = lib.crychic_ssao(ctx.handle, C.byref(c.consts.ssao_cb), ptr(c.dev["normal"]), ptr(c.dev["depth"]), ptr(c.dev["randvec"]),
+                          ptr(c.a0), None, 64, 64, 30, 8, stream(ctx))
+    assert rc == -1
+    with pytest.raises(built_lib.CrychicError):
+        built_lib.check(rc)
