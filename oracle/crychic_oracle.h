@@ -170,6 +170,7 @@ void or_deferred_light(const or_pass_constants* cb, const float* g0, const float
                        int numDirLights, float pcfSearchRadius, int sky);
 
 /* Exposed pieces (unit-tested individually). */
+void  or_eval_array(int kind, size_t n, const float* in, const float* in2, float* out);
 float or_det_sinf(float x);
 float or_det_cosf(float x);
 float or_det_log2f(float x);

@@ -252,3 +252,26 @@ float or_det_cosf(float x) { return or_det_cosf_(x); }
 float or_det_log2f(float x) { return or_det_log2f_(x); }
 float or_det_exp2f(float x) { return or_det_exp2f_(x); }
 float or_det_powf(float x, float y) { return or_det_powf_(x, y); }
+
+/* Batch evaluation of the scalar definitions (unit tests compare them with the product's device math compiled
+ * for the host).  kind: 0 sin, 1 cos, 2 log2, 3 exp2, 4 pow(in, in2), 5 nrand(in, in2), 6 d24 decode (in = bits),
+ * 7 unorm16 decode, 8 unorm8 decode, 9 half decode. */
+void or_eval_array(int kind, size_t n, const float* in, const float* in2, float* out)
+{
+    const uint32_t* bits = (const uint32_t*)in;
+    for (size_t i = 0; i < n; ++i) {
+        switch (kind) {
+        case 0: out[i] = or_det_sinf_(in[i]); break;
+        case 1: out[i] = or_det_cosf_(in[i]); break;
+        case 2: out[i] = or_det_log2f_(in[i]); break;
+        case 3: out[i] = or_det_exp2f_(in[i]); break;
+        case 4: out[i] = or_det_powf_(in[i], in2[i]); break;
+        case 5: out[i] = nrand(in[i], in2[i]); break;
+        case 6: out[i] = or_d24(bits[i]); break;
+        case 7: out[i] = or_unorm16((uint16_t)bits[i]); break;
+        case 8: out[i] = or_unorm8((uint8_t)bits[i]); break;
+        case 9: out[i] = or_half_bits_to_float((uint16_t)bits[i]); break;
+        default: out[i] = 0.0f;
+        }
+    }
+}

@@ -20,6 +20,27 @@ float hs_det_exp2(float x) { return det_exp2(x); }
 float hs_det_pow(float x, float y) { return det_pow(x, y); }
 float hs_nrand(float u, float v) { return nrand(u, v); }
 
+// kind: 0 sin, 1 cos, 2 log2, 3 exp2, 4 pow, 5 nrand, 6 d24, 7 unorm16, 8 unorm8, 9 half (same numbering as or_eval_array)
+void hs_eval_array(int kind, size_t n, const float* in, const float* in2, float* out)
+{
+    const uint32_t* bits = (const uint32_t*)in;
+    for (size_t i = 0; i < n; ++i) {
+        switch (kind) {
+        case 0: out[i] = det_sin(in[i]); break;
+        case 1: out[i] = det_cos(in[i]); break;
+        case 2: out[i] = det_log2(in[i]); break;
+        case 3: out[i] = det_exp2(in[i]); break;
+        case 4: out[i] = det_pow(in[i], in2[i]); break;
+        case 5: out[i] = nrand(in[i], in2[i]); break;
+        case 6: out[i] = d24_to_float(bits[i]); break;
+        case 7: out[i] = unorm16_to_float(bits[i]); break;
+        case 8: out[i] = unorm8_to_float(bits[i]); break;
+        case 9: out[i] = half_to_float((uint16_t)bits[i]); break;
+        default: out[i] = 0.0f;
+        }
+    }
+}
+
 void hs_ssao(const crychic_ssao_constants* cb, const void* normal, const uint32_t* depth, const uint8_t* randvec,
              uint16_t* ambient, void* edge_base, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows)
 {

@@ -32,9 +32,16 @@ class HostSim:
             getattr(L, n).restype = f; getattr(L, n).argtypes = [f]
         L.hs_det_pow.restype = f; L.hs_det_pow.argtypes = [f, f]
         L.hs_nrand.restype = f; L.hs_nrand.argtypes = [f, f]
+        L.hs_eval_array.argtypes = [i, C.c_size_t, vp, vp, vp]
         L.hs_ssao.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, u32, u32]
         L.hs_blur.argtypes = [vp, vp, vp, vp, u32, u32, i, u32, u32]
         L.hs_light.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp, u32, vp, vp, u32, u32, u32, u32, i, f, u32]
+
+    def eval_array(self, kind, a, b=None):
+        a = np.ascontiguousarray(a); out = np.zeros(a.shape, dtype=np.float32)
+        b = np.ascontiguousarray(b) if b is not None else a
+        self.lib.hs_eval_array(kind, a.size, a.ctypes.data, b.ctypes.data, out.ctypes.data)
+        return out
 
     def ssao(self, cb, normal_f16, depth_u32, randvec_u8, edge_bytes, row0=0, rows=None, emit=True):
         H, W = depth_u32.shape

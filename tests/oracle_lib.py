@@ -83,6 +83,22 @@ class Oracle:
         L.or_deferred_light.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp, u32, vp, vp, u32, u32, u32, u32, i, f, i]
         L.or_mat_perspective_fov_lh.argtypes = [f, f, f, f, vp]
         L.or_num_threads.restype = i
+        L.or_set_num_threads.argtypes = [i]
+        L.or_msvc_rand.restype = i; L.or_msvc_rand.argtypes = [vp]
+        L.or_randf.argtypes = [vp]
+        L.or_build_offset_vectors.argtypes = [vp, vp]
+        L.or_build_random_vector_texture.argtypes = [vp, i, vp]
+        L.or_mat_inverse.argtypes = [vp, vp]
+        L.or_mat_mul.argtypes = [vp, vp, vp]
+        L.or_sample_cube.argtypes = [vp, u32, vp, vp]
+        L.or_sample_randvec.argtypes = [vp, f, f, vp]
+        L.or_eval_array.argtypes = [i, C.c_size_t, vp, vp, vp]
+
+    def eval_array(self, kind, a, b=None):
+        a = np.ascontiguousarray(a); out = np.zeros(a.shape, dtype=np.float32)
+        b = np.ascontiguousarray(b) if b is not None else a
+        self.lib.or_eval_array(kind, a.size, a.ctypes.data, b.ctypes.data, out.ctypes.data)
+        return out
 
     # ---- passes on numpy arrays (inputs are converted to the plane layouts of crychic_oracle.h) ----
     def ssao(self, cb, normal_f16, depth_u32, randvec_u8, row0=0, rows=None):

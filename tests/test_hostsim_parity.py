@@ -1,0 +1,89 @@
+"""CPU tier of the parity ladder: the per-pixel kernel bodies the gfx950 kernels inline (csrc/*_core.hpp), compiled
+for the host, must reproduce the oracle bit for bit on seeded scenes -- ragged sizes included.  (The GPU tier,
+tests/test_gpu_parity.py, repeats this through the C ABI on the real kernels.)"""
+import numpy as np
+import pytest
+
+import oracle_lib
+import scene_util
+
+SIZES = [(64, 64), (130, 34), (256, 256)]
+
+
+def setup(W, H, built_lib):
+    pl = scene_util.cpu_scene(W, H, 512, 64)
+    p = scene_util.np_planes(pl)
+    c = pl["consts"]
+    scb = oracle_lib.as_oracle_cb(c.ssao_cb, oracle_lib.OrSsaoConstants)
+    pcb = oracle_lib.as_oracle_cb(c.pass_cb, oracle_lib.OrPassConstants)
+    eb = int(built_lib.lib.crychic_edge_plane_bytes(W, H))
+    return p, c, scb, pcb, eb
+
+
+@pytest.mark.parametrize("W,H", SIZES)
+def test_ssao_and_blur_chain(built_lib, oracle, hostsim, W, H):
+    p, c, scb, pcb, eb = setup(W, H, built_lib)
+    ref = oracle.ssao(scb, p["normal"], p["depth"], p["randvec"])
+    got, edge = hostsim.ssao(c.ssao_cb, p["normal"], p["depth"], p["randvec"], eb)
+    assert np.array_equal(got, ref)
+    assert ref.min() < 65535
+    # blur on the SSAO output and on noise (noise exercises every accept/reject combination)
+    rng = np.random.default_rng(W * 7 + H)
+    for start in (ref, rng.integers(0, 65536, size=ref.shape, dtype=np.uint16)):
+        cur = start
+        for horz in (True, False, True, False):
+            r = oracle.blur(scb, p["normal"], p["depth"], cur, horz)
+            g = hostsim.blur(c.ssao_cb, edge, cur, W, H, horz)
+            assert np.array_equal(g, r), (horz, int((g != r).sum()))
+            cur = r
+
+
+def test_row_ranges_match_full(built_lib, oracle, hostsim):
+    W, H = 130, 34
+    p, c, scb, pcb, eb = setup(W, H, built_lib)
+    full = oracle.ssao(scb, p["normal"], p["depth"], p["randvec"])
+    part = oracle.ssao(scb, p["normal"], p["depth"], p["randvec"], 5, 7)
+    assert np.array_equal(part[5:12], full[5:12]) and (part[:5] == 0).all() and (part[12:] == 0).all()
+    got, _ = hostsim.ssao(c.ssao_cb, p["normal"], p["depth"], p["randvec"], eb, 5, 7)
+    assert np.array_equal(got[5:12], full[5:12])
+
+
+@pytest.mark.parametrize("W,H", SIZES)
+@pytest.mark.parametrize("ndl,literal,sky,ssao_on", [(1, 1, 0, 1), (3, 0, 1, 1), (3, 1, 0, 0), (2, 0, 0, 1)])
+def test_deferred_light(built_lib, oracle, hostsim, W, H, ndl, literal, sky, ssao_on):
+    p, c, scb, pcb, eb = setup(W, H, built_lib)
+    amb = oracle.compute_ssao(scb, p["normal"], p["depth"], p["randvec"], 1) if ssao_on else None
+    radius = built_lib.lib.crychic_pcf_search_radius(p["shadow"].shape[1], literal)
+    ref, rref = oracle.deferred_light(pcb, p["g0"], p["g1"], p["g2"], p["depth"], amb, p["shadow"], p["cube"], ndl, radius,
+                                      sky=bool(sky), want_radiance=True)
+    got, rgot = hostsim.light(c.pass_cb, p["g0"], p["g1"], p["g2"], p["depth"], amb, p["shadow"], p["cube"], ndl, radius,
+                              flags=sky, want_radiance=True)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(rgot.view(np.uint32), rref.view(np.uint32))
+    assert len(np.unique(ref.reshape(-1, 4), axis=0)) > 50   # a real image, not a constant
+
+
+def test_degenerate_inputs_agree(built_lib, oracle, hostsim):
+    """NaN / inf / zero-length inputs must take the same path on both sides (sampler and detmath special cases)."""
+    W, H = 64, 64
+    p, c, scb, pcb, eb = setup(W, H, built_lib)
+    g0, g1, g2 = p["g0"].copy(), p["g1"].copy(), p["g2"].copy()
+    depth = p["depth"].copy(); depth[:] = 1000
+    g2[0:8] = 0.0                      # zero normal -> normalize gives NaN
+    g0[8:16, :, :3] = 1e30             # far away -> huge shadow coordinates
+    g0[16:24, :, 0] = np.inf
+    g1[24:32, :, 3] = 0.0              # roughness 0 -> D = 0 * inf
+    g0[32:40, :, :3] = np.array(list(c.cam.pos), dtype=np.float32)  # at the eye: view = 0/0
+    g1[40:48, :, :3] = -1.0            # negative albedo
+    radius = built_lib.lib.crychic_pcf_search_radius(p["shadow"].shape[1], 0)
+    amb = np.full((H // 2, W // 2), 40000, dtype=np.uint16)
+    ref, rref = oracle.deferred_light(pcb, g0, g1, g2, depth, amb, p["shadow"], p["cube"], 3, radius, want_radiance=True)
+    got, rgot = hostsim.light(c.pass_cb, g0, g1, g2, depth, amb, p["shadow"], p["cube"], 3, radius, want_radiance=True)
+    assert np.array_equal(got, ref)
+    assert np.array_equal(rgot.view(np.uint32), rref.view(np.uint32))
+    # SSAO with a degenerate normal map (zero / NaN normals) and depth 0 (viewZ = near)
+    normal = p["normal"].copy(); normal[0:16] = 0; normal[16:20, :, 0] = np.nan
+    d2 = p["depth"].copy(); d2[20:30] = 0
+    r = oracle.ssao(scb, normal, d2, p["randvec"])
+    g, _ = hostsim.ssao(c.ssao_cb, normal, d2, p["randvec"], eb)
+    assert np.array_equal(g, r)
