@@ -162,21 +162,22 @@ struct Bilin { int i0, j0; float fx, fy; };
 
 CRY_HD int texel_index(float fl, uint32_t dim)
 {
-    if (!(fl >= -2.0f)) return -2;
-    if (fl > (float)dim + 1.0f) return (int)dim + 1;
-    return (int)fl;
+    // clamp(fl, -2, dim + 1) with NaN -> -2 (fmax returns the non-NaN operand); fl is already integral
+    const float c = __builtin_fminf(__builtin_fmaxf(fl, -2.0f), (float)dim + 1.0f);
+    return (int)c;
 }
 CRY_HD Bilin bilinear_setup(float u, float v, uint32_t w, uint32_t h)
 {
     Bilin b;
-    float tx = u * (float)w - 0.5f;
-    float ty = v * (float)h - 0.5f;
-    float flx = __builtin_floorf(tx), fly = __builtin_floorf(ty);
-    b.fx = tx - flx;
-    b.fy = ty - fly;
-    b.i0 = texel_index(flx, w);
-    b.j0 = texel_index(fly, h);
-    if (!(b.fx == b.fx) || !(b.fy == b.fy)) { b.i0 = -2; b.j0 = -2; b.fx = 0.0f; b.fy = 0.0f; }
+    const float tx = u * (float)w - 0.5f;
+    const float ty = v * (float)h - 0.5f;
+    const float flx = __builtin_floorf(tx), fly = __builtin_floorf(ty);
+    const float fx = tx - flx, fy = ty - fly;
+    const bool bad = !(fx == fx) | !(fy == fy);   // non-finite coordinates address only out-of-range texels
+    b.fx = bad ? 0.0f : fx;
+    b.fy = bad ? 0.0f : fy;
+    b.i0 = bad ? -2 : texel_index(flx, w);
+    b.j0 = bad ? -2 : texel_index(fly, h);
     return b;
 }
 CRY_HD float bilerp(float t00, float t10, float t01, float t11, float fx, float fy)
@@ -186,5 +187,37 @@ CRY_HD float bilerp(float t00, float t10, float t01, float t11, float fx, float 
     return lerpf(top, bot, fy);
 }
 CRY_HD int clampi(int i, int lo, int hi) { return i < lo ? lo : (i > hi ? hi : i); }
+
+// Two horizontally adjacent texels of a row-major 32-bit plane with one 8-byte load (the address is only 4-byte
+// aligned: gfx950 global loads allow that).  `row` points at texel 0 of an in-range row, width >= 2.
+struct TexelPair { uint32_t a, b; };
+struct RawPair { uint32_t lo, hi; };
+CRY_HD RawPair load_pair(const uint32_t* __restrict__ p)
+{
+    RawPair v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+// BORDER / range-checked variant: returns texels i0 and i0+1 where they exist (the caller replaces out-of-range
+// ones by the border value; what is returned for them is unspecified but always read from valid memory).
+CRY_HD TexelPair pair_at(const uint32_t* __restrict__ row, uint32_t width, int i0)
+{
+    const int cx = clampi(i0, 0, (int)width - 2);
+    const RawPair v = load_pair(row + cx);
+    TexelPair t;
+    t.a = (i0 == cx) ? v.lo : v.hi;      // i0 == width-1 -> hi
+    t.b = (i0 + 1 == cx) ? v.lo : v.hi;  // i0 == -1      -> lo
+    return t;
+}
+// CLAMP variant: texels clamp(i0) and clamp(i0+1).
+CRY_HD TexelPair pair_at_clamped(const uint32_t* __restrict__ row, uint32_t width, int i0)
+{
+    const int cx = clampi(i0, 0, (int)width - 2);
+    const RawPair v = load_pair(row + cx);
+    TexelPair t;
+    t.a = (i0 > (int)width - 2) ? v.hi : v.lo;
+    t.b = (i0 < 0) ? v.lo : v.hi;
+    return t;
+}
 
 }  // namespace cry

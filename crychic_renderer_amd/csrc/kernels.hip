@@ -36,27 +36,55 @@ __global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, co
 }
 
 // ---- bilateral blur ------------------------------------------------------------------------------------------
-// Shaders/SsaoBlur.hlsl:85-146, one sweep.  Straight per-pixel form: every tap is re-read through L1/L2 from the
-// half-res edge workspace (12 B/pixel) and the ambient plane (2 B/pixel).
+// Shaders/SsaoBlur.hlsl:85-146, one sweep.  A 64 x 16 output tile plus its 5-pixel apron along the sweep axis is
+// staged once in LDS as pre-decoded floats (normal.xyz + linear depth as one 16-byte entry, ambient as one dword), so
+// the 11-tap window of every pixel is served by one ds_read_b128 + one ds_read_b32 per tap instead of 3 global
+// fetches + 4 format conversions.  Consecutive lanes read consecutive 16-byte entries (conflict-free for both
+// directions: the horizontal window slides along a staged row, the vertical one hops whole rows).
 template <bool HORZ>
 __global__ __launch_bounds__(256) void blur_kernel(crychic_ssao_constants cb, EdgePlane edge,
                                                    const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
                                                    uint32_t W, uint32_t H, uint32_t row0, uint32_t row1)
 {
+    constexpr int BW = 64, BH = 16, R = 5;
+    constexpr int SW = HORZ ? BW + 2 * R : BW;
+    constexpr int SH = HORZ ? BH : BH + 2 * R;
+    __shared__ f4a s_nz[SW * SH];
+    __shared__ float s_a[SW * SH];
+
     const int w2 = (int)(W / 2), h2 = (int)(H / 2);
-    const int x = (int)(blockIdx.x * 64u + (threadIdx.x & 63u));
-    const int y = (int)(row0 + blockIdx.y * 4u + (threadIdx.x >> 6));
-    if (x >= w2 || y >= (int)row1) return;
+    const int x0 = (int)blockIdx.x * BW, y0 = (int)row0 + (int)blockIdx.y * BH;
+    const int sx0 = HORZ ? x0 - R : x0, sy0 = HORZ ? y0 : y0 - R;
     const float borderZ = ndc_to_view(cb, 1.0f);
-    BlurTap taps[11];
+
+    for (int k = (int)threadIdx.x; k < SW * SH; k += 256) {
+        const int ly = k / SW, lx = k - ly * SW;
+        const BlurTap t = blur_fetch(edge, in, borderZ, w2, h2, sx0 + lx, sy0 + ly);
+        s_nz[k] = f4a{ t.n.x, t.n.y, t.n.z, t.z };
+        s_a[k] = t.a;
+    }
+    __syncthreads();
+
+    const int tx = (int)(threadIdx.x & 63u), tyb = (int)(threadIdx.x >> 6);
+    const int x = x0 + tx;
 #pragma unroll
-    for (int i = 0; i < 11; ++i)
-        taps[i] = blur_fetch(edge, in, borderZ, w2, h2, HORZ ? x + i - 5 : x, HORZ ? y : y + i - 5);
-    out[(uint32_t)y * (uint32_t)w2 + (uint32_t)x] = (uint16_t)blur_resolve(&cb.BlurWeights[0][0], taps);
+    for (int j = 0; j < BH / 4; ++j) {
+        const int ty = tyb + 4 * j;
+        const int y = y0 + ty;
+        if (x < w2 && y < (int)row1) {
+            const uint32_t v = blur_pixel(&cb.BlurWeights[0][0], [&](int i) {
+                const int idx = HORZ ? ty * SW + tx + i : (ty + i) * SW + tx;
+                const f4a q = s_nz[idx];
+                return BlurTap{ f3{ q.x, q.y, q.z }, q.w, s_a[idx] };
+            });
+            out[(uint32_t)y * (uint32_t)w2 + (uint32_t)x] = (uint16_t)v;
+        }
+    }
 }
 
 // ---- deferred lighting -----------------------------------------------------------------------------------------
 // Shaders/DeferredShading.hlsl:23-101 as a full-screen pass over rows [row0, row1), masked by depth < 1.
+template <bool ZERO_RADIUS>
 __global__ __launch_bounds__(256) void light_kernel(LightParams P, const f4a* __restrict__ g0,
                                                     const f4a* __restrict__ g1, const f4a* __restrict__ g2,
                                                     const uint32_t* __restrict__ depth,
@@ -72,7 +100,7 @@ __global__ __launch_bounds__(256) void light_kernel(LightParams P, const f4a* __
     // coverage: the reference re-rasterises the opaque items with LESS against depth cleared to 1.0
     // (CRYCHIC.cpp:248,273) -- exactly the pixels whose normal/depth pass depth is below the clear value.
     if ((depth[idx] & 0x00FFFFFFu) < 0x00FFFFFFu) {
-        lit = light_pixel(P, g0[idx], g1[idx], g2[idx], ambient, cube);
+        lit = light_pixel<ZERO_RADIUS>(P, g0[idx], g1[idx], g2[idx], ambient, cube);
     } else if (P.flags & CRYCHIC_LIGHT_SKY) {
         lit = sky_pixel(P, cube, x, y);
     } else {
@@ -83,7 +111,10 @@ __global__ __launch_bounds__(256) void light_kernel(LightParams P, const f4a* __
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------
-static inline dim3 grid_for(uint32_t width, uint32_t rows) { return dim3((width + 63u) / 64u, (rows + 3u) / 4u, 1); }
+static inline dim3 grid_for(uint32_t width, uint32_t rows, uint32_t rows_per_block = 4u)
+{
+    return dim3((width + 63u) / 64u, (rows + rows_per_block - 1u) / rows_per_block, 1);
+}
 
 hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, const uint32_t* depth,
                        const uint8_t* randvec, uint16_t* ambient, void* edge_base, uint32_t W, uint32_t H,
@@ -107,7 +138,7 @@ hipError_t launch_blur(const crychic_ssao_constants& cb, const void* edge_base, 
 {
     if (rows == 0) return hipSuccess;
     const EdgePlane e = edge_plane_carve(const_cast<void*>(edge_base), W, H);
-    const dim3 grid = grid_for(W / 2, rows);
+    const dim3 grid = grid_for(W / 2, rows, 16u);
     if (horizontal)
         hipLaunchKernelGGL(blur_kernel<true>, grid, dim3(256), 0, stream, cb, e, in, out, W, H, row0, row0 + rows);
     else
@@ -121,8 +152,14 @@ hipError_t launch_light(const LightParams& P, const float* g0, const float* g1, 
 {
     if (rows == 0) return hipSuccess;
     const dim3 grid = grid_for(P.W, rows);
-    hipLaunchKernelGGL(light_kernel, grid, dim3(256), 0, stream, P, (const f4a*)g0, (const f4a*)g1, (const f4a*)g2,
-                       depth, ambient, (const uint32_t*)cube, (uint32_t*)out, (f4a*)radiance, row0, row0 + rows);
+    if (P.pcfSearchRadius == 0.0f)
+        hipLaunchKernelGGL(light_kernel<true>, grid, dim3(256), 0, stream, P, (const f4a*)g0, (const f4a*)g1,
+                           (const f4a*)g2, depth, ambient, (const uint32_t*)cube, (uint32_t*)out, (f4a*)radiance, row0,
+                           row0 + rows);
+    else
+        hipLaunchKernelGGL(light_kernel<false>, grid, dim3(256), 0, stream, P, (const f4a*)g0, (const f4a*)g1,
+                           (const f4a*)g2, depth, ambient, (const uint32_t*)cube, (uint32_t*)out, (f4a*)radiance, row0,
+                           row0 + rows);
     return hipGetLastError();
 }
 

@@ -35,19 +35,20 @@ CRY_HD float nrand(float u, float v)
 }
 
 // gsamShadow: LESS_EQUAL comparison on each texel, then bilinear; BORDER colour 0  (CRYCHIC.cpp:2649-2658)
-CRY_HD float shadow_texel_cmp(const uint32_t* __restrict__ s, uint32_t dim, int x, int y, float ref)
-{
-    bool in = ((uint32_t)x < dim) & ((uint32_t)y < dim);
-    float t = in ? d24_to_float(s[(uint32_t)y * dim + (uint32_t)x]) : 0.0f;
-    return (ref <= t) ? 1.0f : 0.0f;
-}
 CRY_HD float shadow_cmp_linear(const uint32_t* __restrict__ s, uint32_t dim, float u, float v, float ref)
 {
-    Bilin b = bilinear_setup(u, v, dim, dim);
-    float c00 = shadow_texel_cmp(s, dim, b.i0, b.j0, ref);
-    float c10 = shadow_texel_cmp(s, dim, b.i0 + 1, b.j0, ref);
-    float c01 = shadow_texel_cmp(s, dim, b.i0, b.j0 + 1, ref);
-    float c11 = shadow_texel_cmp(s, dim, b.i0 + 1, b.j0 + 1, ref);
+    const Bilin b = bilinear_setup(u, v, dim, dim);
+    const uint32_t r0 = (uint32_t)clampi(b.j0, 0, (int)dim - 1), r1 = (uint32_t)clampi(b.j0 + 1, 0, (int)dim - 1);
+    const TexelPair p0 = pair_at(s + r0 * dim, dim, b.i0);   // one 8-byte load per footprint row
+    const TexelPair p1 = pair_at(s + r1 * dim, dim, b.i0);
+    const bool xa = (uint32_t)b.i0 < dim, xb = (uint32_t)(b.i0 + 1) < dim;
+    const bool y0 = (uint32_t)b.j0 < dim, y1 = (uint32_t)(b.j0 + 1) < dim;
+    const float t00 = (xa & y0) ? d24_to_float(p0.a) : 0.0f;
+    const float t10 = (xb & y0) ? d24_to_float(p0.b) : 0.0f;
+    const float t01 = (xa & y1) ? d24_to_float(p1.a) : 0.0f;
+    const float t11 = (xb & y1) ? d24_to_float(p1.b) : 0.0f;
+    const float c00 = (ref <= t00) ? 1.0f : 0.0f, c10 = (ref <= t10) ? 1.0f : 0.0f;
+    const float c01 = (ref <= t01) ? 1.0f : 0.0f, c11 = (ref <= t11) ? 1.0f : 0.0f;
     return bilerp(c00, c10, c01, c11, b.fx, b.fy);
 }
 
@@ -59,12 +60,15 @@ CRY_HD float shadow_cmp_linear(const uint32_t* __restrict__ s, uint32_t dim, flo
       -0.24188840f, 0.99706507f, -0.81409955f, 0.91437590f, 0.19984126f, 0.78641367f, 0.14383161f, -0.14100790f }
 
 // CalcCascadeShadowFactorWithPoisson  Common.hlsl:263-317
+// ZERO_RADIUS is a compile-time promise that radius == 0 (the reference's own value): it removes the general tap loop
+// from the instantiation the reference-literal configuration runs.
+template <bool ZERO_RADIUS>
 CRY_HD float pcf_poisson(const uint32_t* __restrict__ s, uint32_t dim, float spx, float spy, float spz, float spw,
                          float radius)
 {
     const float x = spx / spw, y = spy / spw, depth = spz / spw;  // :266-269
     float percentLit = 0.0f;
-    if (radius == 0.0f) {
+    if (ZERO_RADIUS || radius == 0.0f) {
         // Common.hlsl:305 as written (uint division) gives radius 0: every one of the 16 taps is
         // uv + (+-0) == uv, so one filtered fetch is accumulated 16 times -- bit-identical to the loop.
         const float tap = shadow_cmp_linear(s, dim, x, y, depth);
@@ -143,10 +147,11 @@ CRY_HD f4 cube_linear(const uint32_t* __restrict__ cube, uint32_t dim, f3 r)
     const float u = 0.5f * (sc / ma + 1.0f);
     const float v = 0.5f * (tc / ma + 1.0f);
     const Bilin b = bilinear_setup(u, v, dim, dim);
-    const uint32_t x0 = (uint32_t)clampi(b.i0, 0, (int)dim - 1), x1 = (uint32_t)clampi(b.i0 + 1, 0, (int)dim - 1);
     const uint32_t y0 = (uint32_t)clampi(b.j0, 0, (int)dim - 1), y1 = (uint32_t)clampi(b.j0 + 1, 0, (int)dim - 1);
     const uint32_t* f = cube + face * dim * dim;
-    const uint32_t t00 = f[y0 * dim + x0], t10 = f[y0 * dim + x1], t01 = f[y1 * dim + x0], t11 = f[y1 * dim + x1];
+    const TexelPair p0 = pair_at_clamped(f + y0 * dim, dim, b.i0);
+    const TexelPair p1 = pair_at_clamped(f + y1 * dim, dim, b.i0);
+    const uint32_t t00 = p0.a, t10 = p0.b, t01 = p1.a, t11 = p1.b;
     f4 o;
     o.x = bilerp(unorm8_to_float(t00 & 255u), unorm8_to_float(t10 & 255u), unorm8_to_float(t01 & 255u),
                  unorm8_to_float(t11 & 255u), b.fx, b.fy);
@@ -170,6 +175,7 @@ CRY_HD float ambient_linear_clamp(const uint16_t* __restrict__ a, uint32_t w2, u
 }
 
 // DeferredShading.hlsl:23-101 for one covered pixel.
+template <bool ZERO_RADIUS>
 CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16_t* __restrict__ ambient,
                       const uint32_t* __restrict__ cube)
 {
@@ -206,14 +212,14 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
     if (j < 4) {
         const float* T0 = P.ShadowTransforms[j];
         const uint32_t* s0 = P.shadow[j];
-        const float a = pcf_poisson(s0, P.shadowDim, mulcol(posW.x, posW.y, posW.z, 1.0f, T0 + 0),
+        const float a = pcf_poisson<ZERO_RADIUS>(s0, P.shadowDim, mulcol(posW.x, posW.y, posW.z, 1.0f, T0 + 0),
                                     mulcol(posW.x, posW.y, posW.z, 1.0f, T0 + 4),
                                     mulcol(posW.x, posW.y, posW.z, 1.0f, T0 + 8),
                                     mulcol(posW.x, posW.y, posW.z, 1.0f, T0 + 12), P.pcfSearchRadius);
         if (j < 3) {
             const float* T1 = P.ShadowTransforms[j + 1];
             const uint32_t* s1 = P.shadow[j + 1];
-            const float b = pcf_poisson(s1, P.shadowDim, mulcol(posW.x, posW.y, posW.z, 1.0f, T1 + 0),
+            const float b = pcf_poisson<ZERO_RADIUS>(s1, P.shadowDim, mulcol(posW.x, posW.y, posW.z, 1.0f, T1 + 0),
                                         mulcol(posW.x, posW.y, posW.z, 1.0f, T1 + 4),
                                         mulcol(posW.x, posW.y, posW.z, 1.0f, T1 + 8),
                                         mulcol(posW.x, posW.y, posW.z, 1.0f, T1 + 12), P.pcfSearchRadius);

@@ -52,26 +52,38 @@ CRY_HD float ndc_to_view(const crychic_ssao_constants& cb, float z_ndc)
 // gsamDepthMap: linear filter, BORDER (1.0) addressing  (CRYCHIC.cpp:1057-1066)
 CRY_HD float depth_texel(const uint32_t* __restrict__ depth, uint32_t W, uint32_t H, int x, int y)
 {
-    bool in = ((uint32_t)x < W) & ((uint32_t)y < H);
-    return in ? d24_to_float(depth[(uint32_t)y * W + (uint32_t)x]) : 1.0f;
+    // Always fetch (from the clamped address) and select afterwards: the four texel loads of a bilinear footprint
+    // issue back to back instead of sitting in four dependent exec-masked branches.
+    const bool in = ((uint32_t)x < W) & ((uint32_t)y < H);
+    const uint32_t cx = (uint32_t)clampi(x, 0, (int)W - 1), cy = (uint32_t)clampi(y, 0, (int)H - 1);
+    const float t = d24_to_float(depth[cy * W + cx]);
+    return in ? t : 1.0f;
 }
 CRY_HD float depth_linear_border(const uint32_t* __restrict__ depth, uint32_t W, uint32_t H, float u, float v)
 {
-    Bilin b = bilinear_setup(u, v, W, H);
-    float t00 = depth_texel(depth, W, H, b.i0, b.j0);
-    float t10 = depth_texel(depth, W, H, b.i0 + 1, b.j0);
-    float t01 = depth_texel(depth, W, H, b.i0, b.j0 + 1);
-    float t11 = depth_texel(depth, W, H, b.i0 + 1, b.j0 + 1);
+    const Bilin b = bilinear_setup(u, v, W, H);
+    // rows j0, j0+1: one 8-byte load each (texels i0, i0+1), fetched from clamped addresses, border selected after
+    const uint32_t r0 = (uint32_t)clampi(b.j0, 0, (int)H - 1), r1 = (uint32_t)clampi(b.j0 + 1, 0, (int)H - 1);
+    const TexelPair p0 = pair_at(depth + r0 * W, W, b.i0);
+    const TexelPair p1 = pair_at(depth + r1 * W, W, b.i0);
+    const bool xa = (uint32_t)b.i0 < W, xb = (uint32_t)(b.i0 + 1) < W;
+    const bool y0 = (uint32_t)b.j0 < H, y1 = (uint32_t)(b.j0 + 1) < H;
+    const float t00 = (xa & y0) ? d24_to_float(p0.a) : 1.0f;
+    const float t10 = (xb & y0) ? d24_to_float(p0.b) : 1.0f;
+    const float t01 = (xa & y1) ? d24_to_float(p1.a) : 1.0f;
+    const float t11 = (xb & y1) ? d24_to_float(p1.b) : 1.0f;
     return bilerp(t00, t10, t01, t11, b.fx, b.fy);
 }
 // The same sampler at the centre of half-res pixel (xi, yi) (even W, H): texels 2xi..2xi+1 x 2yi..2yi+1 with
 // weights 1/2; a pixel outside the half-res map only ever addresses border texels.
 CRY_HD float depth_at_half_pixel(const uint32_t* __restrict__ depth, uint32_t W, uint32_t H, int xi, int yi)
 {
-    float t00 = depth_texel(depth, W, H, 2 * xi, 2 * yi);
-    float t10 = depth_texel(depth, W, H, 2 * xi + 1, 2 * yi);
-    float t01 = depth_texel(depth, W, H, 2 * xi, 2 * yi + 1);
-    float t11 = depth_texel(depth, W, H, 2 * xi + 1, 2 * yi + 1);
+    const bool in = ((uint32_t)(2 * xi) < W) & ((uint32_t)(2 * yi) < H);   // even sizes: all four in or all four out
+    const uint32_t cx = (uint32_t)clampi(2 * xi, 0, (int)W - 2), cy = (uint32_t)clampi(2 * yi, 0, (int)H - 2);
+    const RawPair p0 = load_pair(depth + cy * W + cx);
+    const RawPair p1 = load_pair(depth + (cy + 1) * W + cx);
+    const float t00 = in ? d24_to_float(p0.lo) : 1.0f, t10 = in ? d24_to_float(p0.hi) : 1.0f;
+    const float t01 = in ? d24_to_float(p1.lo) : 1.0f, t11 = in ? d24_to_float(p1.hi) : 1.0f;
     return bilerp(t00, t10, t01, t11, 0.5f, 0.5f);
 }
 
@@ -160,8 +172,8 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
         const float distZ = p.z - r.z;                                           // :185
         const f3 dn = normalize3(f3{ r.x - p.x, r.y - p.y, r.z - p.z });
         const float dp = maxnn(dot3(n, dn), 0.0f);                               // :186
-        float occ = 0.0f;                                                        // :76-108
-        if (distZ > eps) occ = saturate((fadeEnd - distZ) / fadeLength);
+        const float fade = saturate((fadeEnd - distZ) / fadeLength);             // :76-108
+        const float occ = (distZ > eps) ? fade : 0.0f;
         occlusionSum += dp * occ;                                                // :188-190
     }
     occlusionSum = occlusionSum / 14.0f;                                         // :193
@@ -184,29 +196,35 @@ CRY_HD BlurTap blur_fetch(const EdgePlane& e, const uint16_t* __restrict__ amb, 
 {
     BlurTap t;
     const int cx = clampi(xi, 0, w2 - 1), cy = clampi(yi, 0, h2 - 1);
-    u2 nb;
-    if (xi < 0) nb = e.gcol[cy];
-    else if (yi < 0) nb = e.grow[cx];
-    else nb = e.nrm[(uint32_t)cy * (uint32_t)w2 + (uint32_t)cx];
+    const uint32_t idx = (uint32_t)cy * (uint32_t)w2 + (uint32_t)cx;
+    const u2* src = e.nrm + idx;                       // one load through a selected address (no divergent branches)
+    src = (yi < 0) ? e.grow + cx : src;
+    src = (xi < 0) ? e.gcol + cy : src;
+    const u2 nb = *src;
     t.n = unpack_normal(nb);
     const bool inside = ((uint32_t)xi < (uint32_t)w2) & ((uint32_t)yi < (uint32_t)h2);
-    t.z = inside ? e.vz[(uint32_t)cy * (uint32_t)w2 + (uint32_t)cx] : borderZ;
-    t.a = unorm16_to_float(amb[(uint32_t)cy * (uint32_t)w2 + (uint32_t)cx]);
+    const float vz = e.vz[idx];
+    t.z = inside ? vz : borderZ;
+    t.a = unorm16_to_float(amb[idx]);
     return t;
 }
 
-// One output pixel from its 11 taps, taps[5] being the centre.
-CRY_HD uint32_t blur_resolve(const float* __restrict__ w, const BlurTap* taps)
+// One output pixel from its 11 taps; fetch(i) returns tap i (i = 5 is the centre).  Accumulation order is the
+// shader's loop order (SsaoBlur.hlsl:113).
+template <class Fetch>
+CRY_HD uint32_t blur_pixel(const float* __restrict__ w, Fetch fetch)
 {
-    float color = w[5] * taps[5].a;     // :106
+    const BlurTap c = fetch(5);
+    float color = w[5] * c.a;           // :106
     float total = w[5];                 // :107
-    const f3 cn = taps[5].n;
-    const float cz = taps[5].z;
 #pragma unroll
     for (int i = 0; i < 11; ++i) {      // :113
         if (i == 5) continue;
-        const bool ok = (dot3(taps[i].n, cn) >= 0.8f) & (__builtin_fabsf(taps[i].z - cz) <= 0.2f);  // :131-132
-        if (ok) { color += w[i] * taps[i].a; total += w[i]; }
+        const BlurTap t = fetch(i);
+        const bool ok = (dot3(t.n, c.n) >= 0.8f) & (__builtin_fabsf(t.z - c.z) <= 0.2f);  // :131-132
+        const float c2 = color + w[i] * t.a, t2 = total + w[i];   // select, not branch: the wave never diverges here
+        color = ok ? c2 : color;
+        total = ok ? t2 : total;
     }
     return float_to_unorm16(color / total);  // :145
 }

@@ -69,10 +69,9 @@ void hs_blur(const crychic_ssao_constants* cb, void* edge_base, const uint16_t* 
     const float borderZ = ndc_to_view(*cb, 1.0f);
     for (int y = (int)row0; y < (int)(row0 + rows); ++y)
         for (int x = 0; x < w2; ++x) {
-            BlurTap taps[11];
-            for (int i = 0; i < 11; ++i)
-                taps[i] = blur_fetch(e, in, borderZ, w2, h2, horizontal ? x + i - 5 : x, horizontal ? y : y + i - 5);
-            out[y * w2 + x] = (uint16_t)blur_resolve(&cb->BlurWeights[0][0], taps);
+            out[y * w2 + x] = (uint16_t)blur_pixel(&cb->BlurWeights[0][0], [&](int i) {
+                return blur_fetch(e, in, borderZ, w2, h2, horizontal ? x + i - 5 : x, horizontal ? y : y + i - 5);
+            });
         }
 }
 
@@ -97,7 +96,8 @@ void hs_light(const crychic_pass_constants* cb, const float* g0, const float* g1
         for (uint32_t x = 0; x < W; ++x) {
             const uint32_t idx = y * W + x;
             f4 lit;
-            if ((depth[idx] & 0x00FFFFFFu) < 0x00FFFFFFu) lit = light_pixel(P, G0[idx], G1[idx], G2[idx], ambient, (const uint32_t*)cube);
+            if ((depth[idx] & 0x00FFFFFFu) < 0x00FFFFFFu) lit = (pcfSearchRadius == 0.0f) ? light_pixel<true>(P, G0[idx], G1[idx], G2[idx], ambient, (const uint32_t*)cube)
+                                                                                        : light_pixel<false>(P, G0[idx], G1[idx], G2[idx], ambient, (const uint32_t*)cube);
             else if (flags & CRYCHIC_LIGHT_SKY) lit = sky_pixel(P, (const uint32_t*)cube, x, y);
             else lit = f4{ 0.690196097f, 0.768627524f, 0.870588303f, 1.0f };
             if (radiance) { radiance[4 * idx] = lit.x; radiance[4 * idx + 1] = lit.y; radiance[4 * idx + 2] = lit.z; radiance[4 * idx + 3] = lit.w; }
