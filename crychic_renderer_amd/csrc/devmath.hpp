@@ -56,7 +56,7 @@ CRY_HD float d24_to_float(uint32_t texel)
 {
     uint32_t u = texel & 0x00FFFFFFu;
     float q = (float)u * 5.9604644775390625e-8f;
-    return u ? u2f(f2u(q) + 1u) : 0.0f;
+    return u2f(f2u(q) + (u != 0u ? 1u : 0u));   // u == 0: q is +0.0 and stays +0.0
 }
 // u / 65535.0f and u / 255.0f, correctly rounded, via one reciprocal multiply and one residual correction.
 CRY_HD float unorm16_to_float(uint32_t u)

@@ -43,10 +43,11 @@ CRY_HD float shadow_cmp_linear(const uint32_t* __restrict__ s, uint32_t dim, flo
     const TexelPair p1 = pair_at(s + r1 * dim, dim, b.i0);
     const bool xa = (uint32_t)b.i0 < dim, xb = (uint32_t)(b.i0 + 1) < dim;
     const bool y0 = (uint32_t)b.j0 < dim, y1 = (uint32_t)(b.j0 + 1) < dim;
-    const float t00 = (xa & y0) ? d24_to_float(p0.a) : 0.0f;
-    const float t10 = (xb & y0) ? d24_to_float(p0.b) : 0.0f;
-    const float t01 = (xa & y1) ? d24_to_float(p1.a) : 0.0f;
-    const float t11 = (xb & y1) ? d24_to_float(p1.b) : 0.0f;
+    // the BORDER colour 0 is D24 0: select on the integer texel, then decode unconditionally
+    const float t00 = d24_to_float((xa && y0) ? p0.a : 0u);
+    const float t10 = d24_to_float((xb && y0) ? p0.b : 0u);
+    const float t01 = d24_to_float((xa && y1) ? p1.a : 0u);
+    const float t11 = d24_to_float((xb && y1) ? p1.b : 0u);
     const float c00 = (ref <= t00) ? 1.0f : 0.0f, c10 = (ref <= t10) ? 1.0f : 0.0f;
     const float c01 = (ref <= t01) ? 1.0f : 0.0f, c11 = (ref <= t11) ? 1.0f : 0.0f;
     return bilerp(c00, c10, c01, c11, b.fx, b.fy);

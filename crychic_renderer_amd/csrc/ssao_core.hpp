@@ -54,10 +54,10 @@ CRY_HD float depth_texel(const uint32_t* __restrict__ depth, uint32_t W, uint32_
 {
     // Always fetch (from the clamped address) and select afterwards: the four texel loads of a bilinear footprint
     // issue back to back instead of sitting in four dependent exec-masked branches.
-    const bool in = ((uint32_t)x < W) & ((uint32_t)y < H);
+    const bool in = ((uint32_t)x < W) && ((uint32_t)y < H);
     const uint32_t cx = (uint32_t)clampi(x, 0, (int)W - 1), cy = (uint32_t)clampi(y, 0, (int)H - 1);
-    const float t = d24_to_float(depth[cy * W + cx]);
-    return in ? t : 1.0f;
+    const uint32_t t = depth[cy * W + cx];
+    return d24_to_float(in ? t : 0x00FFFFFFu);
 }
 CRY_HD float depth_linear_border(const uint32_t* __restrict__ depth, uint32_t W, uint32_t H, float u, float v)
 {
@@ -68,10 +68,11 @@ CRY_HD float depth_linear_border(const uint32_t* __restrict__ depth, uint32_t W,
     const TexelPair p1 = pair_at(depth + r1 * W, W, b.i0);
     const bool xa = (uint32_t)b.i0 < W, xb = (uint32_t)(b.i0 + 1) < W;
     const bool y0 = (uint32_t)b.j0 < H, y1 = (uint32_t)(b.j0 + 1) < H;
-    const float t00 = (xa & y0) ? d24_to_float(p0.a) : 1.0f;
-    const float t10 = (xb & y0) ? d24_to_float(p0.b) : 1.0f;
-    const float t01 = (xa & y1) ? d24_to_float(p1.a) : 1.0f;
-    const float t11 = (xb & y1) ? d24_to_float(p1.b) : 1.0f;
+    // the BORDER colour 1.0 is exactly D24 0xFFFFFF: select on the integer texel, then decode unconditionally
+    const float t00 = d24_to_float((xa && y0) ? p0.a : 0x00FFFFFFu);
+    const float t10 = d24_to_float((xb && y0) ? p0.b : 0x00FFFFFFu);
+    const float t01 = d24_to_float((xa && y1) ? p1.a : 0x00FFFFFFu);
+    const float t11 = d24_to_float((xb && y1) ? p1.b : 0x00FFFFFFu);
     return bilerp(t00, t10, t01, t11, b.fx, b.fy);
 }
 // The same sampler at the centre of half-res pixel (xi, yi) (even W, H): texels 2xi..2xi+1 x 2yi..2yi+1 with
@@ -82,8 +83,8 @@ CRY_HD float depth_at_half_pixel(const uint32_t* __restrict__ depth, uint32_t W,
     const uint32_t cx = (uint32_t)clampi(2 * xi, 0, (int)W - 2), cy = (uint32_t)clampi(2 * yi, 0, (int)H - 2);
     const RawPair p0 = load_pair(depth + cy * W + cx);
     const RawPair p1 = load_pair(depth + (cy + 1) * W + cx);
-    const float t00 = in ? d24_to_float(p0.lo) : 1.0f, t10 = in ? d24_to_float(p0.hi) : 1.0f;
-    const float t01 = in ? d24_to_float(p1.lo) : 1.0f, t11 = in ? d24_to_float(p1.hi) : 1.0f;
+    const float t00 = d24_to_float(in ? p0.lo : 0x00FFFFFFu), t10 = d24_to_float(in ? p0.hi : 0x00FFFFFFu);
+    const float t01 = d24_to_float(in ? p1.lo : 0x00FFFFFFu), t11 = d24_to_float(in ? p1.hi : 0x00FFFFFFu);
     return bilerp(t00, t10, t01, t11, 0.5f, 0.5f);
 }
 
