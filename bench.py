@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--cube-dim", type=int, default=256)
     ap.add_argument("--pcf", choices=["literal", "intended"], default="literal")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dump-scene", default="", help="write the input planes + constants for tools/prof_driver and exit")
     ap.add_argument("--cpu-band-rows", type=int, default=0, help="full-res rows of the CPU baseline band (0 = auto)")
     return ap.parse_args()
 
@@ -87,6 +88,22 @@ def cpu_baseline(planes, args, pcf_radius):
                       "frame, %.1f s" % (2 * bc, rows, W, rows, dt)}
 
 
+def dump_scene(d, planes, args, pcf_radius):
+    """Raw planes + constant buffers for the torch-free profiling driver (tools/prof_driver.cpp)."""
+    os.makedirs(d, exist_ok=True)
+    for k in ("depth", "normal", "g0", "g1", "g2", "cube", "randvec"):
+        planes[k].cpu().numpy().tofile(os.path.join(d, k + ".bin"))
+    for i in range(4):
+        planes["shadow"][i].cpu().numpy().tofile(os.path.join(d, "shadow%d.bin" % i))
+    c = planes["consts"]
+    open(os.path.join(d, "ssao_cb.bin"), "wb").write(bytes(c.ssao_cb))
+    open(os.path.join(d, "pass_cb.bin"), "wb").write(bytes(c.pass_cb))
+    with open(os.path.join(d, "meta.txt"), "w") as f:
+        f.write("%d %d %d %d %d %d %r 0\n" % (args.width, args.height, args.shadow_dim, args.cube_dim, args.blur_count, args.lights,
+                                             float(pcf_radius)))
+    print("scene dumped to", d)
+
+
 def main():
     args = parse()
     import torch
@@ -123,6 +140,9 @@ def main():
     app.load_scene(planes)
     app.blurCount, app.numDirLights = args.blur_count, args.lights
     app.pcfSearchRadius = lib.crychic_pcf_search_radius(args.shadow_dim, 1 if args.pcf == "literal" else 0)
+    if args.dump_scene:
+        dump_scene(args.dump_scene, planes, args, app.pcfSearchRadius)
+        return
     row0, rows = sharding.strip_rows(H, world, rank)
     gather = sharding.FrameGather(W, H, world, rank, dev) if world > 1 else None
 
