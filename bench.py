@@ -88,6 +88,19 @@ def cpu_baseline(planes, args, pcf_radius):
                       "frame, %.1f s" % (2 * bc, rows, W, rows, dt)}
 
 
+def pmc_traffic(args, world):
+    """HBM bytes per light_kernel launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
+    (2*FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950 correction of MI355X_MICROARCH.md).  PMC collection cannot run
+    inside this process, so the figure applies only to the exact workload it was measured on; otherwise null."""
+    if world != 1 or (args.width, args.height, args.blur_count, args.lights, args.pcf, args.shadow_dim) != (3840, 2160, 4, 3, "literal", 4096):
+        return None
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            return int(json.load(f)["kernels"]["cry::light_kernel<true>"]["hbm_bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def dump_scene(d, planes, args, pcf_radius):
     """Raw planes + constant buffers for the torch-free profiling driver (tools/prof_driver.cpp)."""
     os.makedirs(d, exist_ok=True)
@@ -215,7 +228,7 @@ def main():
                        if world == 1 else None,
                        "pass_ms": {k: round(v, 4) for k, v in acc.items()}},
             "roofline": {"kernel": "light_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None},
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args, world)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(planes, args, app.pcfSearchRadius)

@@ -82,9 +82,11 @@ int ssao_compute_impl(crychic_ctx* ctx, const crychic_ssao_constants* cb, const 
     if (afterSsao) CRY_HIP(hipEventRecord(afterSsao, stream));
     for (int i = 0; i < blurCount; ++i) {
         clamp_rows(h2, (int64_t)row0 - 5 * (blurCount - i), (int64_t)row0 + rows + 5 * (blurCount - i), &r0, &rn);
-        CRY_HIP(cry::launch_blur(*cb, edge, ambient0, ambient1, W, H, true, r0, rn, stream));   // Ssao.cpp:240
+        // iteration 0 records each direction's tap decisions; iterations 1.. replay them (same geometry, same rows or fewer)
+        const cry::BlurMode mode = blurCount == 1 ? cry::BlurMode::Plain : (i == 0 ? cry::BlurMode::Record : cry::BlurMode::Replay);
+        CRY_HIP(cry::launch_blur(*cb, edge, ambient0, ambient1, W, H, true, mode, r0, rn, stream));   // Ssao.cpp:240
         clamp_rows(h2, (int64_t)row0 - 5 * (blurCount - 1 - i), (int64_t)row0 + rows + 5 * (blurCount - 1 - i), &r0, &rn);
-        CRY_HIP(cry::launch_blur(*cb, edge, ambient1, ambient0, W, H, false, r0, rn, stream));  // Ssao.cpp:241
+        CRY_HIP(cry::launch_blur(*cb, edge, ambient1, ambient0, W, H, false, mode, r0, rn, stream));  // Ssao.cpp:241
     }
     return 0;
 }
@@ -199,7 +201,8 @@ int crychic_ssao_blur(crychic_ctx* ctx, const crychic_ssao_constants* cb, const 
     if (!cb || !edge_dev || !ambient_in_dev || !ambient_out_dev) return fail(CRYCHIC_E_INVALID_ARG, "null argument");
     if (ambient_in_dev == ambient_out_dev) return fail(CRYCHIC_E_INVALID_ARG, "blur cannot run in place (the reference ping-pongs, Ssao.cpp:253-266)");
     if (row0 > H / 2 || rows > H / 2 - row0) return fail(CRYCHIC_E_INVALID_ARG, "rows [%u,+%u) outside the %u-row ambient map", row0, rows, H / 2);
-    CRY_HIP(cry::launch_blur(*cb, edge_dev, ambient_in_dev, ambient_out_dev, W, H, horizontal != 0, row0, rows, (hipStream_t)stream));
+    CRY_HIP(cry::launch_blur(*cb, edge_dev, ambient_in_dev, ambient_out_dev, W, H, horizontal != 0, cry::BlurMode::Plain, row0, rows,
+                             (hipStream_t)stream));
     return 0;
 }
 

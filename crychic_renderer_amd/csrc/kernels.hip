@@ -10,6 +10,31 @@
 
 namespace cry {
 
+// XCD-aware tile order.  Workgroups are dealt round-robin over the 8 XCDs (each with a private 4 MiB L2), so with
+// the natural order every XCD touches the whole frame: the SSAO depth taps then miss L2 eight times over
+// (measured: 362 MB fetched per 4K launch against 50 MB of planes).  The remap hands each XCD stripes of STRIPE
+// consecutive tile rows, interleaved over the frame with period 8*STRIPE: neighbouring tiles -- which share tap
+// footprints and blur aprons -- share an L2, while cheap (sky) and expensive (near geometry) regions still spread
+// over all XCDs (one contiguous band per XCD measured 1.8x SLOWER on the lighting pass: load imbalance).
+// Placement is a performance hint only: any dispatch order produces the same pixels.
+template <uint32_t STRIPE>
+__device__ __forceinline__ void tile_origin(uint32_t& bx, uint32_t& by)
+{
+    const uint32_t nbx = gridDim.x, n = nbx * gridDim.y;
+    uint32_t b = blockIdx.y * nbx + blockIdx.x;
+    if (STRIPE > 0) {
+        const uint32_t chunk = nbx * STRIPE;              // tiles per stripe
+        const uint32_t full = (n / (chunk * 8u)) * (chunk * 8u);   // tiles covered by whole 8-stripe groups
+        if (b < full) {
+            const uint32_t xcd = b & 7u, k = b >> 3;      // k-th tile this XCD receives
+            const uint32_t j = k / chunk, o = k - j * chunk;
+            b = (j * 8u + xcd) * chunk + o;
+        }                                                 // the tail keeps its ids (bijective)
+    }
+    by = b / nbx;
+    bx = b - by * nbx;
+}
+
 // ---- SSAO ------------------------------------------------------------------------------------------------
 // Shaders/Ssao.hlsl:117-199 over half-res rows [row0, row1).  EMIT_AO = false builds only the edge workspace.
 template <bool EMIT_AO>
@@ -20,8 +45,10 @@ __global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, co
                                                    uint32_t H, uint32_t row0, uint32_t row1)
 {
     const uint32_t w2 = W / 2;
-    const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u);
-    const uint32_t y = row0 + blockIdx.y * 4u + (threadIdx.x >> 6);
+    uint32_t bx, by;
+    tile_origin<16>(bx, by);
+    const uint32_t x = bx * 64u + (threadIdx.x & 63u);
+    const uint32_t y = row0 + by * 4u + (threadIdx.x >> 6);
     if (x >= w2 || y >= row1) return;
 
     const SsaoCentre c = ssao_centre(cb, normal, depth, W, H, (int)x, (int)y);
@@ -41,7 +68,7 @@ __global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, co
 // the 11-tap window of every pixel is served by one ds_read_b128 + one ds_read_b32 per tap instead of 3 global
 // fetches + 4 format conversions.  Consecutive lanes read consecutive 16-byte entries (conflict-free for both
 // directions: the horizontal window slides along a staged row, the vertical one hops whole rows).
-template <bool HORZ>
+template <bool HORZ, bool RECORD>
 __global__ __launch_bounds__(256) void blur_kernel(crychic_ssao_constants cb, EdgePlane edge,
                                                    const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
                                                    uint32_t W, uint32_t H, uint32_t row0, uint32_t row1)
@@ -53,7 +80,9 @@ __global__ __launch_bounds__(256) void blur_kernel(crychic_ssao_constants cb, Ed
     __shared__ float s_a[SW * SH];
 
     const int w2 = (int)(W / 2), h2 = (int)(H / 2);
-    const int x0 = (int)blockIdx.x * BW, y0 = (int)row0 + (int)blockIdx.y * BH;
+    uint32_t bx, by;
+    tile_origin<4>(bx, by);
+    const int x0 = (int)bx * BW, y0 = (int)row0 + (int)by * BH;
     const int sx0 = HORZ ? x0 - R : x0, sy0 = HORZ ? y0 : y0 - R;
     const float borderZ = ndc_to_view(cb, 1.0f);
 
@@ -67,15 +96,72 @@ __global__ __launch_bounds__(256) void blur_kernel(crychic_ssao_constants cb, Ed
 
     const int tx = (int)(threadIdx.x & 63u), tyb = (int)(threadIdx.x >> 6);
     const int x = x0 + tx;
+    uint16_t* __restrict__ mask_out = HORZ ? edge.mask_h : edge.mask_v;
+    float* __restrict__ total_out = HORZ ? edge.total_h : edge.total_v;
 #pragma unroll
     for (int j = 0; j < BH / 4; ++j) {
         const int ty = tyb + 4 * j;
         const int y = y0 + ty;
         if (x < w2 && y < (int)row1) {
-            const uint32_t v = blur_pixel(&cb.BlurWeights[0][0], [&](int i) {
+            const BlurOut o = blur_pixel_full(&cb.BlurWeights[0][0], [&](int i) {
                 const int idx = HORZ ? ty * SW + tx + i : (ty + i) * SW + tx;
                 const f4a q = s_nz[idx];
                 return BlurTap{ f3{ q.x, q.y, q.z }, q.w, s_a[idx] };
+            });
+            const uint32_t p = (uint32_t)y * (uint32_t)w2 + (uint32_t)x;
+            out[p] = (uint16_t)o.value;
+            if (RECORD) { mask_out[p] = (uint16_t)o.mask; total_out[p] = o.total; }
+        }
+    }
+}
+
+// A later sweep of the same direction: the per-tap decisions and totalWeight recorded by the RECORD sweep are
+// replayed, so only the ambient tile (+ apron) is staged and each tap costs one LDS read, one multiply-add and a
+// select.  Bit-identical to blur_kernel (same float operations in the same order).
+template <bool HORZ>
+__global__ __launch_bounds__(256) void blur_replay_kernel(crychic_ssao_constants cb, EdgePlane edge,
+                                                          const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
+                                                          uint32_t W, uint32_t H, uint32_t row0, uint32_t row1)
+{
+    constexpr int BW = 64, BH = 16, R = 5;
+    constexpr int SW = HORZ ? BW + 2 * R : BW;
+    constexpr int SH = HORZ ? BH : BH + 2 * R;
+    __shared__ float s_a[SW * SH];
+
+    const int w2 = (int)(W / 2), h2 = (int)(H / 2);
+    uint32_t bx, by;
+    tile_origin<4>(bx, by);
+    const int x0 = (int)bx * BW, y0 = (int)row0 + (int)by * BH;
+    const int sx0 = HORZ ? x0 - R : x0, sy0 = HORZ ? y0 : y0 - R;
+    // this thread's four outputs: fetch their recorded decisions first so the loads fly during the staging
+    const int tx = (int)(threadIdx.x & 63u), tyb = (int)(threadIdx.x >> 6);
+    const int x = x0 + tx;
+    const uint16_t* __restrict__ mask_in = HORZ ? edge.mask_h : edge.mask_v;
+    const float* __restrict__ total_in = HORZ ? edge.total_h : edge.total_v;
+    uint32_t m[BH / 4];
+    float tot[BH / 4];
+#pragma unroll
+    for (int j = 0; j < BH / 4; ++j) {
+        const int y = y0 + tyb + 4 * j;
+        const bool live = (x < w2) && (y < (int)row1);
+        const uint32_t p = live ? (uint32_t)y * (uint32_t)w2 + (uint32_t)x : 0u;
+        m[j] = mask_in[p];
+        tot[j] = total_in[p];
+    }
+    for (int k = (int)threadIdx.x; k < SW * SH; k += 256) {
+        const int ly = k / SW, lx = k - ly * SW;
+        const int cx = clampi(sx0 + lx, 0, w2 - 1), cy = clampi(sy0 + ly, 0, h2 - 1);   // ambient: point / CLAMP
+        s_a[k] = unorm16_to_float(in[(uint32_t)cy * (uint32_t)w2 + (uint32_t)cx]);
+    }
+    __syncthreads();
+
+#pragma unroll
+    for (int j = 0; j < BH / 4; ++j) {
+        const int ty = tyb + 4 * j;
+        const int y = y0 + ty;
+        if (x < w2 && y < (int)row1) {
+            const uint32_t v = blur_pixel_replay(&cb.BlurWeights[0][0], m[j], tot[j], [&](int i) {
+                return s_a[HORZ ? ty * SW + tx + i : (ty + i) * SW + tx];
             });
             out[(uint32_t)y * (uint32_t)w2 + (uint32_t)x] = (uint16_t)v;
         }
@@ -92,8 +178,10 @@ __global__ __launch_bounds__(256) void light_kernel(LightParams P, const f4a* __
                                                     const uint32_t* __restrict__ cube, uint32_t* __restrict__ out,
                                                     f4a* __restrict__ radiance, uint32_t row0, uint32_t row1)
 {
-    const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u);
-    const uint32_t y = row0 + blockIdx.y * 4u + (threadIdx.x >> 6);
+    uint32_t bx, by;
+    tile_origin<0>(bx, by);
+    const uint32_t x = bx * 64u + (threadIdx.x & 63u);
+    const uint32_t y = row0 + by * 4u + (threadIdx.x >> 6);
     if (x >= P.W || y >= row1) return;
     const uint32_t idx = y * P.W + x;
     f4 lit;
@@ -121,7 +209,7 @@ hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, con
                        uint32_t row0, uint32_t rows, bool emit_ao, hipStream_t stream)
 {
     if (rows == 0) return hipSuccess;
-    EdgePlane e{ nullptr, nullptr, nullptr, nullptr };
+    EdgePlane e{};
     if (edge_base) e = edge_plane_carve(edge_base, W, H);
     const dim3 grid = grid_for(W / 2, rows);
     if (emit_ao)
@@ -134,15 +222,21 @@ hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, con
 }
 
 hipError_t launch_blur(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out,
-                       uint32_t W, uint32_t H, bool horizontal, uint32_t row0, uint32_t rows, hipStream_t stream)
+                       uint32_t W, uint32_t H, bool horizontal, BlurMode mode, uint32_t row0, uint32_t rows,
+                       hipStream_t stream)
 {
     if (rows == 0) return hipSuccess;
     const EdgePlane e = edge_plane_carve(const_cast<void*>(edge_base), W, H);
     const dim3 grid = grid_for(W / 2, rows, 16u);
-    if (horizontal)
-        hipLaunchKernelGGL(blur_kernel<true>, grid, dim3(256), 0, stream, cb, e, in, out, W, H, row0, row0 + rows);
-    else
-        hipLaunchKernelGGL(blur_kernel<false>, grid, dim3(256), 0, stream, cb, e, in, out, W, H, row0, row0 + rows);
+#define CRY_LAUNCH_BLUR(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, cb, e, in, out, W, H, row0, row0 + rows)
+    if (mode == BlurMode::Replay) {
+        if (horizontal) CRY_LAUNCH_BLUR(blur_replay_kernel<true>); else CRY_LAUNCH_BLUR(blur_replay_kernel<false>);
+    } else if (mode == BlurMode::Record) {
+        if (horizontal) CRY_LAUNCH_BLUR((blur_kernel<true, true>)); else CRY_LAUNCH_BLUR((blur_kernel<false, true>));
+    } else {
+        if (horizontal) CRY_LAUNCH_BLUR((blur_kernel<true, false>)); else CRY_LAUNCH_BLUR((blur_kernel<false, false>));
+    }
+#undef CRY_LAUNCH_BLUR
     return hipGetLastError();
 }
 

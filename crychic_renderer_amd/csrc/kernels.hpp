@@ -12,8 +12,12 @@ hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, con
                        const uint8_t* randvec, uint16_t* ambient, void* edge_base, uint32_t W, uint32_t H,
                        uint32_t row0, uint32_t rows, bool emit_ao, hipStream_t stream);
 
+// Plain: a self-contained sweep.  Record: same, and stores the per-pixel tap decisions + totalWeight of this
+// direction in the edge workspace.  Replay: uses what a Record sweep of the same direction stored (same geometry).
+enum class BlurMode { Plain, Record, Replay };
 hipError_t launch_blur(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out,
-                       uint32_t W, uint32_t H, bool horizontal, uint32_t row0, uint32_t rows, hipStream_t stream);
+                       uint32_t W, uint32_t H, bool horizontal, BlurMode mode, uint32_t row0, uint32_t rows,
+                       hipStream_t stream);
 
 hipError_t launch_light(const LightParams& P, const float* g0, const float* g1, const float* g2,
                         const uint32_t* depth, const uint16_t* ambient, const uint8_t* cube, uint8_t* out,

@@ -11,7 +11,7 @@ namespace cry {
 // Everything a blur tap needs besides the ambient value is a function of the half-res pixel only
 // (SsaoBlur.hlsl:109-111,121-123): the point-sampled normal and the linearised bilinear depth.  The SSAO
 // kernel already computes both for its own pixel, so it stores them once per frame:
-//   nrm  [h2][w2]  8 B  (the fp16 texel (2x+1, 2y+1) verbatim)
+//   nrm  [h2][w2]  8 B  (the fp16 texel (2x+1, 2y+1) verbatim)   -- plus per-direction tap masks / totals, below
 //   vz   [h2][w2]  4 B  (view-space depth, fp32)
 //   gcol [h2]      8 B  normal texel (0, 2y+1): CLAMP target of every horizontal tap with x + i < 0
 //   grow [w2]      8 B  normal texel (2x+1, 0): CLAMP target of every vertical tap with y + i < 0
@@ -20,20 +20,32 @@ struct EdgePlane {
     float* vz;
     u2* gcol;
     u2* grow;
+    // The accept/reject decision of every blur tap (SsaoBlur.hlsl:131-132) depends on geometry only, so it is the
+    // same in all blurCount iterations.  The first sweep of each direction records the 11 decisions of a pixel as a
+    // bit mask and the resulting totalWeight; later sweeps of that direction replay them (blur_pixel_replay).
+    uint16_t* mask_h;
+    uint16_t* mask_v;
+    float* total_h;
+    float* total_v;
 };
 CRY_HD size_t edge_plane_bytes(uint32_t W, uint32_t H)
 {
     size_t w2 = W / 2, h2 = H / 2;
-    return w2 * h2 * 12 + (w2 + h2) * 8;
+    return w2 * h2 * 24 + (w2 + h2) * 8;
 }
 CRY_HD EdgePlane edge_plane_carve(void* base, uint32_t W, uint32_t H)
 {
     size_t w2 = W / 2, h2 = H / 2, n = w2 * h2;
+    char* b = (char*)base;
     EdgePlane e;
-    e.nrm = (u2*)base;
-    e.vz = (float*)((char*)base + n * 8);
-    e.gcol = (u2*)((char*)base + n * 12);
-    e.grow = e.gcol + h2;
+    e.nrm = (u2*)b;                       // n * 8
+    e.vz = (float*)(b + n * 8);           // n * 4
+    e.total_h = (float*)(b + n * 12);     // n * 4
+    e.total_v = (float*)(b + n * 16);     // n * 4
+    e.mask_h = (uint16_t*)(b + n * 20);   // n * 2
+    e.mask_v = (uint16_t*)(b + n * 22);   // n * 2
+    e.gcol = (u2*)(b + n * 24);           // h2 * 8
+    e.grow = e.gcol + h2;                 // w2 * 8
     return e;
 }
 
@@ -211,13 +223,19 @@ CRY_HD BlurTap blur_fetch(const EdgePlane& e, const uint16_t* __restrict__ amb, 
 }
 
 // One output pixel from its 11 taps; fetch(i) returns tap i (i = 5 is the centre).  Accumulation order is the
-// shader's loop order (SsaoBlur.hlsl:113).
+// shader's loop order (SsaoBlur.hlsl:113).  Also reports which taps passed the edge test and the final totalWeight.
+struct BlurOut {
+    uint32_t value;  // R16_UNORM
+    uint32_t mask;   // bit i set <=> tap i accepted (bit 5, the centre, always set)
+    float total;
+};
 template <class Fetch>
-CRY_HD uint32_t blur_pixel(const float* __restrict__ w, Fetch fetch)
+CRY_HD BlurOut blur_pixel_full(const float* __restrict__ w, Fetch fetch)
 {
     const BlurTap c = fetch(5);
     float color = w[5] * c.a;           // :106
     float total = w[5];                 // :107
+    uint32_t mask = 1u << 5;
 #pragma unroll
     for (int i = 0; i < 11; ++i) {      // :113
         if (i == 5) continue;
@@ -226,8 +244,26 @@ CRY_HD uint32_t blur_pixel(const float* __restrict__ w, Fetch fetch)
         const float c2 = color + w[i] * t.a, t2 = total + w[i];   // select, not branch: the wave never diverges here
         color = ok ? c2 : color;
         total = ok ? t2 : total;
+        mask |= ok ? (1u << i) : 0u;
     }
-    return float_to_unorm16(color / total);  // :145
+    return BlurOut{ float_to_unorm16(color / total), mask, total };  // :145
+}
+template <class Fetch>
+CRY_HD uint32_t blur_pixel(const float* __restrict__ w, Fetch fetch) { return blur_pixel_full(w, fetch).value; }
+
+// The same pixel with the decisions replayed from a previous sweep of the same direction: identical float
+// operations in identical order, minus the normal / depth tests.  amb(i) returns the ambient value of tap i.
+template <class Amb>
+CRY_HD uint32_t blur_pixel_replay(const float* __restrict__ w, uint32_t mask, float total, Amb amb)
+{
+    float color = w[5] * amb(5);
+#pragma unroll
+    for (int i = 0; i < 11; ++i) {
+        if (i == 5) continue;
+        const float c2 = color + w[i] * amb(i);
+        color = (mask & (1u << i)) ? c2 : color;
+    }
+    return float_to_unorm16(color / total);
 }
 
 }  // namespace cry

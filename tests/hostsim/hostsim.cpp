@@ -45,7 +45,7 @@ void hs_ssao(const crychic_ssao_constants* cb, const void* normal, const uint32_
              uint16_t* ambient, void* edge_base, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows)
 {
     const uint32_t w2 = W / 2;
-    EdgePlane e{ nullptr, nullptr, nullptr, nullptr };
+    EdgePlane e{};
     if (edge_base) e = edge_plane_carve(edge_base, W, H);
     const u2* nrm = (const u2*)normal;
     for (uint32_t y = row0; y < row0 + rows; ++y)
@@ -72,6 +72,32 @@ void hs_blur(const crychic_ssao_constants* cb, void* edge_base, const uint16_t* 
             out[y * w2 + x] = (uint16_t)blur_pixel(&cb->BlurWeights[0][0], [&](int i) {
                 return blur_fetch(e, in, borderZ, w2, h2, horizontal ? x + i - 5 : x, horizontal ? y : y + i - 5);
             });
+        }
+}
+
+// record = 1: full sweep that also stores masks/totals; record = 2: replay sweep using them
+void hs_blur_mode(const crychic_ssao_constants* cb, void* edge_base, const uint16_t* in, uint16_t* out, uint32_t W,
+                  uint32_t H, int horizontal, int mode, uint32_t row0, uint32_t rows)
+{
+    const int w2 = (int)(W / 2), h2 = (int)(H / 2);
+    const EdgePlane e = edge_plane_carve(edge_base, W, H);
+    const float borderZ = ndc_to_view(*cb, 1.0f);
+    uint16_t* mask = horizontal ? e.mask_h : e.mask_v;
+    float* total = horizontal ? e.total_h : e.total_v;
+    for (int y = (int)row0; y < (int)(row0 + rows); ++y)
+        for (int x = 0; x < w2; ++x) {
+            const uint32_t p = (uint32_t)y * w2 + x;
+            if (mode == 2) {
+                out[p] = (uint16_t)blur_pixel_replay(&cb->BlurWeights[0][0], mask[p], total[p], [&](int i) {
+                    const int xi = clampi(horizontal ? x + i - 5 : x, 0, w2 - 1), yi = clampi(horizontal ? y : y + i - 5, 0, h2 - 1);
+                    return unorm16_to_float(in[(uint32_t)yi * w2 + xi]);
+                });
+            } else {
+                const BlurOut o = blur_pixel_full(&cb->BlurWeights[0][0], [&](int i) {
+                    return blur_fetch(e, in, borderZ, w2, h2, horizontal ? x + i - 5 : x, horizontal ? y : y + i - 5);
+                });
+                out[p] = (uint16_t)o.value; mask[p] = (uint16_t)o.mask; total[p] = o.total;
+            }
         }
 }
 

@@ -35,6 +35,7 @@ class HostSim:
         L.hs_eval_array.argtypes = [i, C.c_size_t, vp, vp, vp]
         L.hs_ssao.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, u32, u32]
         L.hs_blur.argtypes = [vp, vp, vp, vp, u32, u32, i, u32, u32]
+        L.hs_blur_mode.argtypes = [vp, vp, vp, vp, u32, u32, i, i, u32, u32]
         L.hs_light.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp, u32, vp, vp, u32, u32, u32, u32, i, f, u32]
 
     def eval_array(self, kind, a, b=None):
@@ -58,6 +59,12 @@ class HostSim:
         out = np.zeros((H // 2, W // 2), dtype=np.uint16)
         a = np.ascontiguousarray(ambient_in)
         self.lib.hs_blur(C.addressof(cb), edge.ctypes.data, a.ctypes.data, out.ctypes.data, W, H, 1 if horizontal else 0, row0, rows)
+        return out
+
+    def blur_mode(self, cb, edge, ambient_in, W, H, horizontal, mode):
+        out = np.zeros((H // 2, W // 2), dtype=np.uint16)
+        a = np.ascontiguousarray(ambient_in)
+        self.lib.hs_blur_mode(C.addressof(cb), edge.ctypes.data, a.ctypes.data, out.ctypes.data, W, H, 1 if horizontal else 0, mode, 0, H // 2)
         return out
 
     def light(self, cb, g0, g1, g2, depth_u32, ambient, shadow_u32, cube_u8, num_dir_lights, pcf_radius, flags=0,

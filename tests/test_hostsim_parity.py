@@ -38,6 +38,19 @@ def test_ssao_and_blur_chain(built_lib, oracle, hostsim, W, H):
             cur = r
 
 
+@pytest.mark.parametrize("W,H", [(64, 64), (130, 34)])
+def test_blur_record_replay_matches_oracle(built_lib, oracle, hostsim, W, H):
+    """Iterations 2.. of the blur replay the tap decisions recorded by iteration 1 (same geometry): same bits."""
+    p, c, scb, pcb, eb = setup(W, H, built_lib)
+    ref, edge = hostsim.ssao(c.ssao_cb, p["normal"], p["depth"], p["randvec"], eb)
+    cur_ref = cur = ref
+    for it in range(4):
+        for horz in (True, False):
+            cur_ref = oracle.blur(scb, p["normal"], p["depth"], cur_ref, horz)
+            cur = hostsim.blur_mode(c.ssao_cb, edge, cur, W, H, horz, 1 if it == 0 else 2)
+            assert np.array_equal(cur, cur_ref), (it, horz, int((cur != cur_ref).sum()))
+
+
 def test_row_ranges_match_full(built_lib, oracle, hostsim):
     W, H = 130, 34
     p, c, scb, pcb, eb = setup(W, H, built_lib)
