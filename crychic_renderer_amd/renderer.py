@@ -200,7 +200,17 @@ class Crychic:
         return f
 
     def Draw(self, row0=0, rows=None):  # CRYCHIC.cpp:172-306 (hot part)
-        f = self.frame_desc(row0, rows)
+        # The descriptor only changes when a plane is re-allocated or a knob is turned: keep it across frames so the
+        # per-frame host cost is one FFI call (matters once a strip takes tens of microseconds on 8 GPUs).
+        key = (row0, rows, self.mBackBuffer.data_ptr(), self.mSsao.mAmbientMap0.data_ptr(), self.mDepthStencilBuffer.data_ptr(),
+               self.mDeferred.mGBuffer[0].data_ptr(), self.blurCount, self.numDirLights, self.pcfSearchRadius, self.flags)
+        if self._desc is None:
+            self._desc = {}
+        f = self._desc.get(key)
+        if f is None:
+            if len(self._desc) > 16:
+                self._desc.clear()
+            f = self._desc[key] = self.frame_desc(row0, rows)
         check(lib.crychic_draw_hot_path(self.ctx.handle, C.byref(self.mSsaoCB), C.byref(self.mMainPassCB), C.byref(f),
                                         _stream(self.ctx.device)))
 
