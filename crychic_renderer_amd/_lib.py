@@ -51,6 +51,16 @@ class FrameDesc(C.Structure):
                 ("edge_dev", C.c_void_p), ("out_rgba8_dev", C.c_void_p)]
 
 
+class DrawItem(C.Structure):
+    _fields_ = [("vertices_dev", C.c_void_p), ("vertexCount", C.c_uint32), ("indices_dev", C.c_void_p), ("indexCount", C.c_uint32),
+                ("startIndexLocation", C.c_uint32), ("baseVertexLocation", C.c_int32), ("instances_dev", C.c_void_p),
+                ("instanceCount", C.c_uint32)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("rgba8_dev", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
 class PassTimes(C.Structure):
     _fields_ = [("ssao_ms", C.c_float), ("blur_ms", C.c_float), ("light_ms", C.c_float), ("total_ms", C.c_float)]
 
@@ -87,6 +97,14 @@ PROTOTYPES = {
     "crychic_ctx_set_profiling": (_i, [_vp, _i]),
     "crychic_ctx_last_pass_times": (_i, [_vp, _P(PassTimes)]),
     "crychic_strip_rows": (_i, [_u32, _i, _i, _P(_u32), _P(_u32)]),
+    "crychic_create_box": (_i, [_f, _f, _f, _u32, _vp, _u32, _vp, _u32, _P(_u32)]),
+    "crychic_create_grid": (_i, [_f, _f, _u32, _u32, _vp, _u32, _vp, _u32, _P(_u32)]),
+    "crychic_load_mesh_text": (_i, [C.c_char_p, _vp, _u32, _vp, _u32, _P(_u32), _P(_u32)]),
+    "crychic_raster_workspace_bytes": (_sz, [C.c_uint64, _u32, _u32]),
+    "crychic_draw_scene_to_shadow_map": (_i, [_vp, _P(PassConstants), _P(DrawItem), _u32, _vp, _u32, _i, _f, _vp, _sz, _vp]),
+    "crychic_draw_normals_and_depth": (_i, [_vp, _P(PassConstants), _P(DrawItem), _u32, _vp, _vp, _u32, _u32, _vp, _sz, _vp]),
+    "crychic_draw_gbuffer": (_i, [_vp, _P(PassConstants), _P(DrawItem), _u32, _vp, _u32, _P(Texture), _u32, _vp, _vp, _vp, _vp,
+                                  _u32, _u32, _vp, _sz, _vp]),
 }
 
 

@@ -11,6 +11,7 @@
 #include "kernels.hpp"
 #include "light_core.hpp"
 #include "ssao_core.hpp"
+#include "raster_core.hpp"
 
 namespace {
 
@@ -293,6 +294,65 @@ int crychic_ctx_last_pass_times(crychic_ctx* ctx, crychic_pass_times* out)
     CRY_HIP(hipEventElapsedTime(&out->light_ms, ctx->ev[2], ctx->ev[3]));
     CRY_HIP(hipEventElapsedTime(&out->total_ms, ctx->ev[0], ctx->ev[3]));
     return 0;
+}
+
+size_t crychic_raster_workspace_bytes(uint64_t triangles, uint32_t W, uint32_t H) { return cry::raster_workspace_bytes(triangles, W, H); }
+
+static int raster_common(crychic_ctx* ctx, cry::RasterPass& p, const crychic_pass_constants* passCB, const crychic_draw_item* items,
+                         uint32_t nItems, void* stream)
+{
+    if (int rc = bind(ctx)) return rc;
+    if (!passCB || (!items && nItems) || !p.depth || !p.workspace) return fail(CRYCHIC_E_INVALID_ARG, "null argument");
+    if (p.W == 0 || p.H == 0 || (uint64_t)p.W * p.H > 0x7FFFFFFFull) return fail(CRYCHIC_E_INVALID_ARG, "bad target size %ux%u", p.W, p.H);
+    for (uint32_t i = 0; i < nItems; ++i) {
+        const crychic_draw_item& d = items[i];
+        if (d.indexCount % 3u) return fail(CRYCHIC_E_INVALID_ARG, "item %u: indexCount %u is not a triangle list", i, d.indexCount);
+        if (d.indexCount && d.instanceCount && (!d.vertices_dev || !d.indices_dev || !d.instances_dev))
+            return fail(CRYCHIC_E_INVALID_ARG, "item %u: null buffer", i);
+    }
+    p.view = passCB->View;
+    p.viewProj = passCB->ViewProj;
+    p.items = items;
+    p.nItems = nItems;
+    hipError_t e = cry::launch_raster_pass(p, (hipStream_t)stream);
+    if (e == hipErrorInvalidValue) return fail(CRYCHIC_E_INVALID_ARG, "raster workspace too small (need crychic_raster_workspace_bytes) or too many textures");
+    if (e != hipSuccess) return fail(CRYCHIC_E_HIP, "raster pass failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int crychic_draw_scene_to_shadow_map(crychic_ctx* ctx, const crychic_pass_constants* passCB, const crychic_draw_item* items,
+                                     uint32_t nItems, uint32_t* shadow_dev, uint32_t shadowDim, int depthBias,
+                                     float slopeScaledDepthBias, void* workspace_dev, size_t workspaceBytes, void* stream)
+{
+    cry::RasterPass p = {};
+    p.mode = 0; p.W = shadowDim; p.H = shadowDim; p.depthBias = depthBias; p.slopeScaledDepthBias = slopeScaledDepthBias;
+    p.depth = shadow_dev; p.workspace = workspace_dev; p.workspaceBytes = workspaceBytes;
+    return raster_common(ctx, p, passCB, items, nItems, stream);
+}
+
+int crychic_draw_normals_and_depth(crychic_ctx* ctx, const crychic_pass_constants* passCB, const crychic_draw_item* items,
+                                   uint32_t nItems, void* normal_dev, uint32_t* depth_dev, uint32_t W, uint32_t H,
+                                   void* workspace_dev, size_t workspaceBytes, void* stream)
+{
+    if (!normal_dev) return fail(CRYCHIC_E_INVALID_ARG, "null normal target");
+    cry::RasterPass p = {};
+    p.mode = 1; p.W = W; p.H = H; p.depth = depth_dev; p.normal = normal_dev; p.workspace = workspace_dev; p.workspaceBytes = workspaceBytes;
+    return raster_common(ctx, p, passCB, items, nItems, stream);
+}
+
+int crychic_draw_gbuffer(crychic_ctx* ctx, const crychic_pass_constants* passCB, const crychic_draw_item* items, uint32_t nItems,
+                         const crychic_material_data* materials_dev, uint32_t nMaterials, const crychic_texture* textures,
+                         uint32_t nTextures, float* g0_dev, float* g1_dev, float* g2_dev, uint32_t* depth_dev, uint32_t W, uint32_t H,
+                         void* workspace_dev, size_t workspaceBytes, void* stream)
+{
+    if (!g0_dev || !g1_dev || !g2_dev) return fail(CRYCHIC_E_INVALID_ARG, "null G-buffer target");
+    if (nTextures && !textures) return fail(CRYCHIC_E_INVALID_ARG, "null texture table");
+    cry::RasterPass p = {};
+    p.mode = 2; p.W = W; p.H = H; p.depth = depth_dev; p.g0 = g0_dev; p.g1 = g1_dev; p.g2 = g2_dev;
+    p.materials = materials_dev; p.nMaterials = nMaterials;
+    p.textures = reinterpret_cast<const cry::Texture*>(textures); p.nTextures = nTextures;
+    p.workspace = workspace_dev; p.workspaceBytes = workspaceBytes;
+    return raster_common(ctx, p, passCB, items, nItems, stream);
 }
 
 int crychic_strip_rows(uint32_t H, int nranks, int rank, uint32_t* row0, uint32_t* rows)

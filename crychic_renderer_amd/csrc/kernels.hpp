@@ -23,4 +23,23 @@ hipError_t launch_light(const LightParams& P, const float* g0, const float* g1, 
                         const uint32_t* depth, const uint16_t* ambient, const uint8_t* cube, uint8_t* out,
                         float* radiance, uint32_t row0, uint32_t rows, hipStream_t stream);
 
+
+// ---- producer passes (raster.hip) ----
+struct crychic_pass_constants_viewproj { float m[16]; };   // one transposed 4x4 passed by value in the kernarg segment
+struct Texture;
+struct RasterPass {
+    int mode;                               // 0 shadow depth, 1 view normals + depth, 2 G-buffer + depth
+    const float* view;                      // PassConstants.View (transposed storage)
+    const float* viewProj;                  // PassConstants.ViewProj
+    const crychic_draw_item* items; uint32_t nItems;     // host array, device pointers inside
+    const crychic_material_data* materials; uint32_t nMaterials;   // device
+    const Texture* textures; uint32_t nTextures;         // host array of {device pointer, w, h}
+    uint32_t W, H;
+    int depthBias; float slopeScaledDepthBias;
+    uint32_t* depth; void* normal; float* g0; float* g1; float* g2;
+    void* workspace; size_t workspaceBytes;
+};
+size_t raster_workspace_bytes(uint64_t triangles, uint32_t W, uint32_t H);
+hipError_t launch_raster_pass(const RasterPass& p, hipStream_t stream);
+
 }  // namespace cry

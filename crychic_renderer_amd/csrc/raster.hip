@@ -1,0 +1,175 @@
+// raster.hip -- gfx950 kernels of the producer passes: a D3D-rules rasteriser that fills the shadow
+// cascades, the view-normal + depth target and the G-buffer from indexed, instanced triangle lists.
+//
+// Structure (all launches stream-ordered, no host synchronisation):
+//   clear_vis      visibility buffer := (depth 1.0, no primitive)
+//   setup_kernel   one lane per (instance, triangle): vertex shader x3, clip to 0 <= z <= w, viewport + 1/256 snap,
+//                  cull; up to 3 setup triangles land in slots fixed by draw order (slot = serial, so equal depths
+//                  resolve to the earlier primitive exactly like in-order LESS testing); live slots are appended to
+//                  a list with one atomic each
+//   raster_kernel  persistent workgroups walk the live list; a 64 x 4 lane footprint sweeps the triangle's pixel box
+//                  with 64-bit integer edge functions and atomicMin()s the 64-bit key (d24 << 32 | serial)
+//   resolve_kernel one lane per pixel: depth plane from the key, perspective-correct attributes of the winning
+//                  primitive, then the pass's pixel shader (DrawNormals.hlsl / GeometryPass.hlsl)
+#include <hip/hip_runtime.h>
+#include "kernels.hpp"
+#include "raster_core.hpp"
+
+namespace cry {
+
+struct RasterCounters { uint32_t nlive; uint32_t overflow; uint32_t pad[2]; };
+
+__global__ __launch_bounds__(256) void clear_vis_kernel(uint64_t* __restrict__ vis, uint32_t n, RasterCounters* c)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) vis[i] = kVisClear;
+    if (i == 0) { c->nlive = 0; c->overflow = 0; }
+}
+
+__global__ __launch_bounds__(128) void setup_kernel(crychic_draw_item item, const crychic_material_data* __restrict__ materials,
+                                                    uint32_t nMaterials, crychic_pass_constants_viewproj vp, uint32_t W, uint32_t H,
+                                                    SetupTri* __restrict__ tris, uint32_t slotBase, uint32_t* __restrict__ live,
+                                                    RasterCounters* __restrict__ counters)
+{
+    const uint32_t ntri = item.indexCount / 3u;
+    const uint64_t gid = (uint64_t)blockIdx.x * 128u + threadIdx.x;
+    if (gid >= (uint64_t)ntri * item.instanceCount) return;
+    const uint32_t inst = (uint32_t)(gid / ntri), tri = (uint32_t)(gid - (uint64_t)inst * ntri);
+    const crychic_instance_data I = item.instances_dev[inst];
+    const crychic_material_data* M = (materials && I.MaterialIndex < nMaterials) ? &materials[I.MaterialIndex] : nullptr;
+    const uint32_t slot0 = slotBase + (uint32_t)gid * 3u;
+    tris[slot0].A2 = 0; tris[slot0 + 1].A2 = 0; tris[slot0 + 2].A2 = 0;
+
+    VsOut v[3];
+    bool bad = false;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const int64_t vi = (int64_t)item.indices_dev[item.startIndexLocation + tri * 3u + c] + item.baseVertexLocation;
+        if (vi < 0 || vi >= (int64_t)item.vertexCount) { bad = true; break; }
+        v[c] = vertex_shader(item.vertices_dev[vi], I, M, vp.m);
+    }
+    if (bad) { atomicOr(&counters->overflow, 2u); return; }
+
+    bool overflow = false;
+    const bool inside = (v[0].posH[2] >= 0.0f) & (v[1].posH[2] >= 0.0f) & (v[2].posH[2] >= 0.0f) &
+                        (v[0].posH[3] - v[0].posH[2] >= 0.0f) & (v[1].posH[3] - v[1].posH[2] >= 0.0f) & (v[2].posH[3] - v[2].posH[2] >= 0.0f);
+    if (inside) {
+        SetupTri s;
+        if (setup_triangle(v[0], v[1], v[2], I.MaterialIndex, W, H, s, &overflow)) {
+            tris[slot0] = s;
+            live[atomicAdd(&counters->nlive, 1u)] = slot0;
+        }
+    } else {
+        VsOut poly[8], tmp[8];
+        poly[0] = v[0]; poly[1] = v[1]; poly[2] = v[2];
+        int n = clip_plane(poly, 3, 0, tmp);
+        n = clip_plane(tmp, n, 1, poly);
+        for (int c = 1; c + 1 < n; ++c) {
+            SetupTri s;
+            if (setup_triangle(poly[0], poly[c], poly[c + 1], I.MaterialIndex, W, H, s, &overflow)) {
+                tris[slot0 + (uint32_t)(c - 1)] = s;
+                live[atomicAdd(&counters->nlive, 1u)] = slot0 + (uint32_t)(c - 1);
+            }
+        }
+    }
+    if (overflow) atomicOr(&counters->overflow, 1u);
+}
+
+__global__ __launch_bounds__(256) void raster_kernel(const SetupTri* __restrict__ tris, const uint32_t* __restrict__ live,
+                                                     const RasterCounters* __restrict__ counters, unsigned long long* __restrict__ vis,
+                                                     uint32_t W, uint32_t H, int shadowMode, int depthBias, float slopeBias)
+{
+    const uint32_t nlive = counters->nlive;          // written by the setup kernels that precede this launch in the stream
+    const int lx = (int)(threadIdx.x & 63u), ly = (int)(threadIdx.x >> 6);
+    for (uint32_t k = blockIdx.x; k < nlive; k += gridDim.x) {    // every workgroup reaches the same exit condition
+        const uint32_t slot = live[k];
+        const SetupTri t = tris[slot];
+        const PixelBox b = triangle_box(t, W, H);
+        if (b.x0 > b.x1 || b.y0 > b.y1) continue;
+        const EdgeFlags e = triangle_edge_flags(t);
+        const double bias = shadowMode ? triangle_depth_bias(t, depthBias, slopeBias) : 0.0;
+        for (int y = b.y0 + ly; y <= b.y1; y += 4)
+            for (int x = b.x0 + lx; x <= b.x1; x += 64) {
+                const uint64_t key = fragment_key(t, e, bias, x, y, slot + 1u);
+                if (key != ~0ull) atomicMin(&vis[(uint32_t)y * W + (uint32_t)x], (unsigned long long)key);
+            }
+    }
+}
+
+__global__ __launch_bounds__(256) void resolve_kernel(int mode, const unsigned long long* __restrict__ vis, const SetupTri* __restrict__ tris,
+                                                      crychic_pass_constants_viewproj view, const crychic_material_data* __restrict__ materials,
+                                                      uint32_t nMaterials, const Texture* __restrict__ textures, uint32_t nTextures,
+                                                      uint32_t W, uint32_t H, uint32_t* __restrict__ depth, u2* __restrict__ normal,
+                                                      f4a* __restrict__ g0, f4a* __restrict__ g1, f4a* __restrict__ g2)
+{
+    const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (x >= W || y >= H) return;
+    const uint32_t idx = y * W + x;
+    const uint64_t key = vis[idx];
+    const uint32_t serial = (uint32_t)(key & 0xFFFFFFFFull);
+    depth[idx] = (uint32_t)(key >> 32);
+    if (mode == 0) return;
+    if (serial == 0) {                       // nothing drawn here: the pass's clear values
+        if (mode == 1) normal[idx] = u2{ 0u, 0x00003C00u };                      // (0, 0, 1, 0) in fp16, Ssao.cpp:317
+        else { g0[idx] = f4a{ 0, 0, 0, 0 }; g1[idx] = f4a{ 0, 0, 0, 0 }; g2[idx] = f4a{ 0, 0, 0, 0 }; }   // CRYCHIC.cpp:2554
+        return;
+    }
+    const ResolveOut r = resolve_pixel(mode, tris[serial - 1u], (int)x, (int)y, view.m, materials, nMaterials, textures, nTextures);
+    if (mode == 1) {
+        normal[idx] = u2{ (uint32_t)float_to_half(r.normalV.x) | ((uint32_t)float_to_half(r.normalV.y) << 16), (uint32_t)float_to_half(r.normalV.z) };
+    } else {
+        g0[idx] = f4a{ r.g0.x, r.g0.y, r.g0.z, r.g0.w };
+        g1[idx] = f4a{ r.g1.x, r.g1.y, r.g1.z, r.g1.w };
+        g2[idx] = f4a{ r.g2.x, r.g2.y, r.g2.z, r.g2.w };
+    }
+}
+
+size_t raster_workspace_bytes(uint64_t triangles, uint32_t W, uint32_t H)
+{
+    const uint64_t slots = triangles * 3u;
+    return (size_t)((uint64_t)W * H * 8u + slots * sizeof(SetupTri) + slots * 4u + 64u * sizeof(Texture) + sizeof(RasterCounters) + 1024u);
+}
+
+hipError_t launch_raster_pass(const RasterPass& p, hipStream_t stream)
+{
+    // carve the workspace: vis | tris | live | textures | counters (all 16-byte aligned)
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < p.nItems; ++i) total += (uint64_t)(p.items[i].indexCount / 3u) * p.items[i].instanceCount;
+    const uint64_t slots = total * 3u;
+    if (slots >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
+    if (raster_workspace_bytes(total, p.W, p.H) > p.workspaceBytes || p.nTextures > 64u) return hipErrorInvalidValue;
+    char* base = (char*)p.workspace;
+    unsigned long long* vis = (unsigned long long*)base;
+    size_t off = (size_t)p.W * p.H * 8u;
+    SetupTri* tris = (SetupTri*)(base + off); off += (size_t)slots * sizeof(SetupTri);
+    uint32_t* live = (uint32_t*)(base + off); off += ((size_t)slots * 4u + 15u) & ~(size_t)15u;
+    Texture* texDev = (Texture*)(base + off); off += 64u * sizeof(Texture);
+    RasterCounters* counters = (RasterCounters*)(base + off);
+
+    const uint32_t npx = p.W * p.H;
+    hipLaunchKernelGGL(clear_vis_kernel, dim3((npx + 255u) / 256u), dim3(256), 0, stream, (uint64_t*)vis, npx, counters);
+    if (p.nTextures) {
+        hipError_t e = hipMemcpyAsync(texDev, p.textures, p.nTextures * sizeof(Texture), hipMemcpyHostToDevice, stream);
+        if (e != hipSuccess) return e;
+    }
+    crychic_pass_constants_viewproj vp, view;
+    for (int i = 0; i < 16; ++i) { vp.m[i] = p.viewProj[i]; view.m[i] = p.view[i]; }
+    uint32_t slotBase = 0;
+    for (uint32_t i = 0; i < p.nItems; ++i) {
+        const uint64_t n = (uint64_t)(p.items[i].indexCount / 3u) * p.items[i].instanceCount;
+        if (n == 0) continue;
+        hipLaunchKernelGGL(setup_kernel, dim3((uint32_t)((n + 127u) / 128u)), dim3(128), 0, stream, p.items[i], p.materials, p.nMaterials,
+                           vp, p.W, p.H, tris, slotBase, live, counters);
+        slotBase += (uint32_t)(n * 3u);
+    }
+    if (slots) {
+        hipLaunchKernelGGL(raster_kernel, dim3(256u * 8u), dim3(256), 0, stream, tris, live, counters, vis, p.W, p.H,
+                           p.mode == 0 ? 1 : 0, p.depthBias, p.slopeScaledDepthBias);
+    }
+    hipLaunchKernelGGL(resolve_kernel, dim3((p.W + 63u) / 64u, (p.H + 3u) / 4u), dim3(256), 0, stream, p.mode, vis, tris, view,
+                       p.materials, p.nMaterials, p.nTextures ? texDev : nullptr, p.nTextures, p.W, p.H, p.depth, (u2*)p.normal,
+                       (f4a*)p.g0, (f4a*)p.g1, (f4a*)p.g2);
+    return hipGetLastError();
+}
+
+}  // namespace cry

@@ -1,0 +1,118 @@
+"""Meshes, instances and materials of the reference's live scene for the producer passes.
+
+Host-side data comes from the library's geometry functions (csrc/host_geometry.cpp); the layouts are the
+reference's structured-buffer ABI (FrameResource.h:7-27,69-75)."""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import check, lib
+
+VERTEX_DT = np.dtype([("Pos", "<f4", 3), ("Normal", "<f4", 3), ("TexC", "<f4", 2), ("TangentU", "<f4", 3)])
+INSTANCE_DT = np.dtype([("World", "<f4", 16), ("TexTransform", "<f4", 16), ("MaterialIndex", "<u4"), ("pad", "<u4", 3)])
+MATERIAL_DT = np.dtype([("DiffuseAlbedo", "<f4", 4), ("FresnelR0", "<f4", 3), ("Roughness", "<f4"), ("MatTransform", "<f4", 16),
+                        ("DiffuseMapIndex", "<u4"), ("NormalMapIndex", "<u4"), ("Metalness", "<f4"), ("pad", "<u4")])
+assert VERTEX_DT.itemsize == 44 and INSTANCE_DT.itemsize == 144 and MATERIAL_DT.itemsize == 112
+
+IDENTITY = np.eye(4, dtype=np.float32).reshape(-1)
+
+
+def _two_pass(fn, *args):
+    ni = C.c_uint32()
+    nv = check(fn(*args, None, 0, None, 0, C.byref(ni)))
+    v = np.zeros(nv, VERTEX_DT)
+    idx = np.zeros(ni.value, np.uint32)
+    check(fn(*args, v.ctypes.data, nv, idx.ctypes.data, ni.value, C.byref(ni)))
+    return v, idx
+
+
+def create_box(width, height, depth, num_subdivisions):
+    """GeometryGenerator::CreateBox (Common/GeometryGenerator.cpp:10-101)."""
+    return _two_pass(lib.crychic_create_box, float(width), float(height), float(depth), int(num_subdivisions))
+
+
+def create_grid(width, depth, m, n):
+    """GeometryGenerator::CreateGrid (Common/GeometryGenerator.cpp:551-614)."""
+    return _two_pass(lib.crychic_create_grid, float(width), float(depth), int(m), int(n))
+
+
+def load_mesh_text(path):
+    """Models/*.txt as CRYCHIC::BuildSkullGeometry reads them (CRYCHIC.cpp:1447-1557)."""
+    nv, ni = C.c_uint32(), C.c_uint32()
+    check(lib.crychic_load_mesh_text(path.encode(), None, 0, None, 0, C.byref(nv), C.byref(ni)))
+    v = np.zeros(nv.value, VERTEX_DT)
+    idx = np.zeros(ni.value, np.uint32)
+    check(lib.crychic_load_mesh_text(path.encode(), v.ctypes.data, nv.value, idx.ctypes.data, ni.value, C.byref(nv), C.byref(ni)))
+    return v, idx
+
+
+def world_matrix(scale=(1, 1, 1), translate=(0, 0, 0)):
+    """XMMatrixScaling(s) * XMMatrixTranslation(t), stored transposed like UpdateInstanceData does (CRYCHIC.cpp:546)."""
+    m = np.diag([scale[0], scale[1], scale[2], 1.0]).astype(np.float32)
+    m[3, :3] = translate
+    return m.T.reshape(-1).copy()
+
+
+def make_instances(worlds, material_indices):
+    inst = np.zeros(len(worlds), INSTANCE_DT)
+    for k, (w, mi) in enumerate(zip(worlds, material_indices)):
+        inst[k]["World"] = w
+        inst[k]["TexTransform"] = IDENTITY
+        inst[k]["MaterialIndex"] = mi
+    return inst
+
+
+def reference_materials():
+    """CRYCHIC::BuildMaterials (CRYCHIC.cpp:1768-1821); Metalness is never assigned, so the MaterialData default 0.5
+    reaches the GPU (FrameResource.h:25, CRYCHIC.cpp:578-586)."""
+    rows = [((1.0, 1.0, 1.0, 1.0), (0.1, 0.1, 0.1), 0.3, 0, 1),      # bricks0
+            ((0.9, 0.9, 0.9, 1.0), (0.2, 0.2, 0.2), 0.7, 2, 3),      # tile0
+            ((0.0, 0.0, 0.0, 1.0), (0.98, 0.97, 0.95), 0.1, 4, 5),   # mirror0
+            ((1.0, 1.0, 1.0, 1.0), (0.6, 0.6, 0.6), 0.8, 4, 5),      # skullMat
+            ((1.0, 1.0, 1.0, 1.0), (0.1, 0.1, 0.1), 1.0, 6, 7)]      # sky
+    m = np.zeros(len(rows), MATERIAL_DT)
+    for k, (alb, r0, rough, dmap, nmap) in enumerate(rows):
+        m[k]["DiffuseAlbedo"] = alb
+        m[k]["FresnelR0"] = r0
+        m[k]["Roughness"] = rough
+        m[k]["MatTransform"] = IDENTITY
+        m[k]["DiffuseMapIndex"] = dmap
+        m[k]["NormalMapIndex"] = nmap
+        m[k]["Metalness"] = 0.5
+    return m
+
+
+def cascade_scene_items(shadow_layer=False):
+    """The Opaque (or OpaqueShadow) render items of CRYCHIC::BuildCascadeShadowRenderItems[WithShadow]
+    (CRYCHIC.cpp:2322-2375, 2380-2435): 100 instanced boxes + the grid.  Returns [(vertices, indices, instances), ...]."""
+    box = create_box(1.0, 1.0, 1.0, 3)              # CRYCHIC.cpp:1253
+    grid = create_grid(20.0, 30.0, 60, 40)          # CRYCHIC.cpp:1254
+    worlds, mats = [], []
+    for i in range(10):
+        for j in range(10):
+            worlds.append(world_matrix((1.6, 1.6, 1.6), ((-5 + i) * 5.0, 0.8, (-5 + j) * 5.0)))
+            mats.append(i % 3 if shadow_layer else i % 2)
+    box_inst = make_instances(worlds, mats)
+    grid_inst = make_instances([world_matrix((3.0, 3.0, 3.0))], [1 if shadow_layer else 3])
+    return [(box[0], box[1], box_inst), (grid[0], grid[1], grid_inst)]
+
+
+def procedural_textures(size=64):
+    """Stand-ins for the DDS material textures (row f4 decodes the real ones): index 0/2/4/6 diffuse, 1/3/5/7 normal maps
+    (the heap order of CRYCHIC::LoadTextures, CRYCHIC.cpp:954-959)."""
+    y, x = np.mgrid[0:size, 0:size]
+    out = []
+    for k in range(8):
+        t = np.zeros((size, size, 4), np.uint8)
+        if k % 2 == 0:   # diffuse: brick / tile pattern
+            mortar = ((x % 16) < 1) | ((y % 8) < 1) if k == 0 else ((x % 32) < 2) | ((y % 32) < 2)
+            base = np.array([[200, 120, 90], [230, 230, 235], [255, 255, 255], [255, 255, 255]][k // 2], np.uint8)
+            t[..., :3] = base
+            t[mortar, :3] = (base * 0.6).astype(np.uint8)
+            t[..., 3] = 255
+        else:            # normal map: gentle bumps around (0.5, 0.5, 1)
+            nx = 128 + (20 * np.sin(2 * np.pi * x / 16.0)).astype(np.int32)
+            ny = 128 + (20 * np.cos(2 * np.pi * y / 8.0)).astype(np.int32)
+            t[..., 0] = nx; t[..., 1] = ny; t[..., 2] = 250; t[..., 3] = 255
+        out.append(t)
+    return out

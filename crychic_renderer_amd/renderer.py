@@ -10,7 +10,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import FrameDesc, PassConstants, PassTimes, SsaoConstants, check, lib
+from ._lib import DrawItem, FrameDesc, PassConstants, PassTimes, SsaoConstants, Texture, check, lib
 
 
 def _ptr(t):
@@ -221,3 +221,66 @@ class Crychic:
         t = PassTimes()
         check(lib.crychic_ctx_last_pass_times(self.ctx.handle, C.byref(t)))
         return {"ssao_ms": t.ssao_ms, "blur_ms": t.blur_ms, "light_ms": t.light_ms, "total_ms": t.total_ms}
+
+
+class SceneGeometry:
+    """Device-resident vertex / index / instance / material / texture buffers of a set of render items, i.e. what
+    CRYCHIC::BuildShapeGeometry + BuildMaterials + the per-frame InstanceBuffers hold (CRYCHIC.cpp:1250-1445, 515-592)."""
+
+    def __init__(self, ctx, items, materials=None, textures=None):
+        import numpy as np
+        dev = ctx.device
+        self.ctx = ctx
+        self._keep = []
+        self.items = (DrawItem * len(items))()
+        self.triangles = 0
+        for k, (v, idx, inst) in enumerate(items):
+            tv = torch.from_numpy(np.ascontiguousarray(v).view(np.uint8).copy()).to(dev)
+            ti = torch.from_numpy(np.ascontiguousarray(idx).view(np.int32).copy()).to(dev)
+            tn = torch.from_numpy(np.ascontiguousarray(inst).view(np.uint8).copy()).to(dev)
+            self._keep += [tv, ti, tn]
+            self.items[k] = DrawItem(tv.data_ptr(), len(v), ti.data_ptr(), len(idx), 0, 0, tn.data_ptr(), len(inst))
+            self.triangles += (len(idx) // 3) * len(inst)
+        self.materials = None
+        self.n_materials = 0
+        if materials is not None:
+            self.materials = torch.from_numpy(np.ascontiguousarray(materials).view(np.uint8).copy()).to(dev)
+            self.n_materials = len(materials)
+        self.textures = None
+        self.n_textures = 0
+        if textures:
+            self.textures = (Texture * len(textures))()
+            for k, t in enumerate(textures):
+                if t is None:
+                    continue
+                tt = torch.from_numpy(np.ascontiguousarray(t)).to(dev)
+                self._keep.append(tt)
+                self.textures[k] = Texture(tt.data_ptr(), t.shape[1], t.shape[0])
+            self.n_textures = len(textures)
+        self._ws = {}
+
+    def workspace(self, W, H):
+        key = (W, H)
+        if key not in self._ws:
+            n = int(lib.crychic_raster_workspace_bytes(self.triangles, W, H))
+            self._ws[key] = torch.zeros((n,), dtype=torch.uint8, device=self.ctx.device)
+        return self._ws[key]
+
+    def DrawSceneToShadowMap(self, pass_cb, shadow_plane, depth_bias=10000, slope_bias=2.0):  # CRYCHIC.cpp:2477-2510, 1601-1603
+        dim = int(shadow_plane.shape[0])
+        ws = self.workspace(dim, dim)
+        check(lib.crychic_draw_scene_to_shadow_map(self.ctx.handle, C.byref(pass_cb), self.items, len(self.items), _ptr(shadow_plane), dim,
+                                                   int(depth_bias), float(slope_bias), _ptr(ws), ws.numel(), _stream(self.ctx.device)))
+
+    def DrawNormalsAndDepth(self, pass_cb, normal_map, depth):  # CRYCHIC.cpp:2512-2543
+        H, W = int(depth.shape[0]), int(depth.shape[1])
+        ws = self.workspace(W, H)
+        check(lib.crychic_draw_normals_and_depth(self.ctx.handle, C.byref(pass_cb), self.items, len(self.items), _ptr(normal_map), _ptr(depth),
+                                                 W, H, _ptr(ws), ws.numel(), _stream(self.ctx.device)))
+
+    def DrawGBuffer(self, pass_cb, gbuffer, depth):  # CRYCHIC.cpp:2545-2571
+        H, W = int(depth.shape[0]), int(depth.shape[1])
+        ws = self.workspace(W, H)
+        check(lib.crychic_draw_gbuffer(self.ctx.handle, C.byref(pass_cb), self.items, len(self.items), _ptr(self.materials), self.n_materials,
+                                       self.textures, self.n_textures, _ptr(gbuffer[0]), _ptr(gbuffer[1]), _ptr(gbuffer[2]), _ptr(depth), W, H,
+                                       _ptr(ws), ws.numel(), _stream(self.ctx.device)))

@@ -228,6 +228,61 @@ typedef struct crychic_pass_times {
 int crychic_ctx_set_profiling(crychic_ctx* ctx, int enabled);
 int crychic_ctx_last_pass_times(crychic_ctx* ctx, crychic_pass_times* out);
 
+
+/* ---- producer passes: the draws that fill the hot path's input planes ------------------------- */
+/* FrameResource.h:69-75 (44 B; input layout CRYCHIC.cpp:1241-1247) */
+typedef struct crychic_vertex { float Pos[3]; float Normal[3]; float TexC[2]; float TangentU[3]; } crychic_vertex;
+/* FrameResource.h:7-15 (144 B); matrices stored transposed as UpdateInstanceData writes them (CRYCHIC.cpp:546-547) */
+typedef struct crychic_instance_data { float World[16]; float TexTransform[16]; uint32_t MaterialIndex; uint32_t pad[3]; } crychic_instance_data;
+/* FrameResource.h:17-27 (112 B); MatTransform stored transposed (CRYCHIC.cpp:582) */
+typedef struct crychic_material_data {
+    float DiffuseAlbedo[4]; float FresnelR0[3]; float Roughness; float MatTransform[16];
+    uint32_t DiffuseMapIndex; uint32_t NormalMapIndex; float Metalness; uint32_t pad;
+} crychic_material_data;
+/* One DrawIndexedInstanced(IndexCount, InstanceCount, StartIndexLocation, BaseVertexLocation, 0) with its bound vertex,
+ * index (R32_UINT) and instance buffers (CRYCHIC::DrawRenderItems, CRYCHIC.cpp:2438-2475).  All pointers are device. */
+typedef struct crychic_draw_item {
+    const crychic_vertex* vertices_dev; uint32_t vertexCount;
+    const uint32_t* indices_dev; uint32_t indexCount; uint32_t startIndexLocation; int32_t baseVertexLocation;
+    const crychic_instance_data* instances_dev; uint32_t instanceCount;
+} crychic_draw_item;
+/* A mip-0 R8G8B8A8_UNORM texture of gTextureMaps[] (Common.hlsl:52); rgba8_dev may be NULL (white / flat normal). */
+typedef struct crychic_texture { const uint8_t* rgba8_dev; uint32_t width, height; } crychic_texture;
+
+/* GeometryGenerator::CreateBox / CreateGrid (Common/GeometryGenerator.cpp:10-101, 551-614) and the Models/*.txt loader
+ * of CRYCHIC::BuildSkullGeometry (CRYCHIC.cpp:1447-1557), host memory.  Call with NULL buffers to get the counts.
+ * Return the vertex count, or a negative status. */
+int crychic_create_box(float width, float height, float depth, uint32_t numSubdivisions, crychic_vertex* vertices,
+                       uint32_t vertexCapacity, uint32_t* indices, uint32_t indexCapacity, uint32_t* indexCount);
+int crychic_create_grid(float width, float depth, uint32_t m, uint32_t n, crychic_vertex* vertices, uint32_t vertexCapacity,
+                        uint32_t* indices, uint32_t indexCapacity, uint32_t* indexCount);
+int crychic_load_mesh_text(const char* path, crychic_vertex* vertices, uint32_t vertexCapacity, uint32_t* indices,
+                           uint32_t indexCapacity, uint32_t* vertexCount, uint32_t* indexCount);
+
+/* Device workspace for one rasterised pass over `triangles` input triangles (sum over items of instanceCount *
+ * indexCount / 3) into a W x H target. */
+size_t crychic_raster_workspace_bytes(uint64_t triangles, uint32_t W, uint32_t H);
+
+/* The three producer passes.  Rasteriser state = CD3DX12_RASTERIZER_DESC(D3D12_DEFAULT): solid, cull back, clockwise
+ * front, depth clip (Common/d3dx12.h:203-216); depth LESS + write against a target cleared to 1.0 (:120-132); top-left
+ * rule, pixel centres at +0.5, 1/256-pixel vertex snap.  `passCB` supplies View / ViewProj.  Every pass clears its
+ * targets first, like the reference (CRYCHIC.cpp:2489-2492, 2526-2527, 2554-2556).
+ *   crychic_draw_scene_to_shadow_map : one cascade of CRYCHIC::DrawSceneToShadowMap (CRYCHIC.cpp:2477-2510) with the
+ *       shadow PSO's DepthBias / SlopeScaledDepthBias (CRYCHIC.cpp:1601-1603: 10000, 2.0)
+ *   crychic_draw_normals_and_depth   : CRYCHIC::DrawNormalsAndDepth (CRYCHIC.cpp:2512-2543), DrawNormals.hlsl
+ *   crychic_draw_gbuffer             : CRYCHIC::DrawGBuffer (CRYCHIC.cpp:2545-2571), GeometryPass.hlsl; depth_dev is
+ *       the depth target of this pass (may alias the normals pass's: same geometry, same values) */
+int crychic_draw_scene_to_shadow_map(crychic_ctx* ctx, const crychic_pass_constants* passCB, const crychic_draw_item* items,
+                                     uint32_t nItems, uint32_t* shadow_dev, uint32_t shadowDim, int depthBias,
+                                     float slopeScaledDepthBias, void* workspace_dev, size_t workspaceBytes, void* stream);
+int crychic_draw_normals_and_depth(crychic_ctx* ctx, const crychic_pass_constants* passCB, const crychic_draw_item* items,
+                                   uint32_t nItems, void* normal_dev, uint32_t* depth_dev, uint32_t W, uint32_t H,
+                                   void* workspace_dev, size_t workspaceBytes, void* stream);
+int crychic_draw_gbuffer(crychic_ctx* ctx, const crychic_pass_constants* passCB, const crychic_draw_item* items,
+                         uint32_t nItems, const crychic_material_data* materials_dev, uint32_t nMaterials,
+                         const crychic_texture* textures, uint32_t nTextures, float* g0_dev, float* g1_dev, float* g2_dev,
+                         uint32_t* depth_dev, uint32_t W, uint32_t H, void* workspace_dev, size_t workspaceBytes, void* stream);
+
 /* ---- multi-GPU strip plan (pure host arithmetic) ---------------------------------------------- */
 /* Full-res rows [*row0, *row0 + *rows) owned by `rank` of `nranks` for an H-row frame: strips are multiples
  * of 2 rows (half-res alignment); the last rank takes the remainder. */

@@ -169,6 +169,49 @@ void or_deferred_light(const or_pass_constants* cb, const float* g0, const float
                        float* radiance_out, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows,
                        int numDirLights, float pcfSearchRadius, int sky);
 
+
+/* ---- producer passes: D3D-rules software rasteriser ---------------------------------------- */
+/* FrameResource.h:69-75 */
+typedef struct or_vertex { float Pos[3]; float Normal[3]; float TexC[2]; float TangentU[3]; } or_vertex;          /* 44 B */
+/* FrameResource.h:7-15, matrices stored transposed (CRYCHIC.cpp:546-547) */
+typedef struct or_instance_data { float World[16]; float TexTransform[16]; uint32_t MaterialIndex; uint32_t pad[3]; } or_instance_data; /* 144 B */
+/* FrameResource.h:17-27, MatTransform stored transposed (CRYCHIC.cpp:582) */
+typedef struct or_material_data {
+    float DiffuseAlbedo[4]; float FresnelR0[3]; float Roughness; float MatTransform[16];
+    uint32_t DiffuseMapIndex; uint32_t NormalMapIndex; float Metalness; uint32_t pad;
+} or_material_data; /* 112 B */
+/* One DrawIndexedInstanced (CRYCHIC.cpp:2473). */
+typedef struct or_draw_item {
+    const or_vertex* vertices; uint32_t vertexCount;
+    const uint32_t* indices; uint32_t indexCount; uint32_t startIndexLocation; int32_t baseVertexLocation;
+    const or_instance_data* instances; uint32_t instanceCount;
+} or_draw_item;
+typedef struct or_texture { const uint8_t* rgba8; uint32_t width, height; } or_texture;
+
+/* Rasterises the items with the default rasteriser state (solid, cull back, clockwise = front, depth clip;
+ * Common/d3dx12.h:203-216), depth LESS + write against depth cleared to 1.0, top-left rule, pixel centres at +0.5,
+ * vertex positions snapped to 1/256 pixel.  Returns the number of setup triangles (after clipping/culling) or -1.
+ * mode 0: Shadows.hlsl -- depth only, with depthBias / slopeScaledDepthBias (CRYCHIC.cpp:1601-1603)
+ * mode 1: DrawNormals.hlsl -- view-space normal (4 x fp16, w = 0) + depth; clear normal (0,0,1,0) (Ssao.cpp:317)
+ * mode 2: GeometryPass.hlsl -- G0..G2 (clear 0, CRYCHIC.cpp:2554) + depth
+ * view / viewProj are the transposed cbuffer matrices (PassConstants.View / .ViewProj). */
+int or_rasterize(int mode, const float view[16], const float viewProj[16], const or_draw_item* items, uint32_t nItems,
+                 const or_material_data* materials, uint32_t nMaterials, const or_texture* textures, uint32_t nTextures,
+                 uint32_t W, uint32_t H, int depthBias, float slopeScaledDepthBias,
+                 uint32_t* depth_out, uint16_t* normal_out, float* g0, float* g1, float* g2);
+
+/* GeometryGenerator::CreateBox / CreateGrid (Common/GeometryGenerator.cpp:10-101, 214-300, 551-614).  Return the
+ * vertex count and write the index count; -1 if the capacities are too small. */
+int or_create_box(float width, float height, float depth, uint32_t numSubdivisions, or_vertex* v, uint32_t vcap,
+                  uint32_t* idx, uint32_t icap, uint32_t* nIdx);
+int or_create_grid(float width, float depth, uint32_t m, uint32_t n, or_vertex* v, uint32_t vcap, uint32_t* idx,
+                   uint32_t icap, uint32_t* nIdx);
+/* The "pos normal" + triangle-list text format of Models/skull.txt as CRYCHIC::BuildSkullGeometry parses it
+ * (CRYCHIC.cpp:1447-1557), tangent generation included.  Pass NULL buffers to query the counts. */
+int or_load_mesh_text(const char* path, or_vertex* v, uint32_t vcap, uint32_t* idx, uint32_t icap, uint32_t* nVerts,
+                      uint32_t* nIdx);
+uint16_t or_float_to_half(float f);
+
 /* Exposed pieces (unit-tested individually). */
 void  or_eval_array(int kind, size_t n, const float* in, const float* in2, float* out);
 float or_det_sinf(float x);

@@ -4,6 +4,8 @@
 #include <cstring>
 #include "ssao_core.hpp"
 #include "light_core.hpp"
+#include "raster_core.hpp"
+#include <vector>
 
 using namespace cry;
 
@@ -129,6 +131,80 @@ void hs_light(const crychic_pass_constants* cb, const float* g0, const float* g1
             if (radiance) { radiance[4 * idx] = lit.x; radiance[4 * idx + 1] = lit.y; radiance[4 * idx + 2] = lit.z; radiance[4 * idx + 3] = lit.w; }
             ((uint32_t*)out)[idx] = pack_rgba8(lit);
         }
+}
+
+// The producer passes executed sequentially on the host with the kernels' own bodies (raster_core.hpp): setup in draw
+// order into the same slot numbering as setup_kernel, coverage by min() on the 64-bit key, then the resolve stage.
+int hs_rasterize(int mode, const float* view, const float* viewProj, const crychic_draw_item* items, uint32_t nItems,
+                 const crychic_material_data* materials, uint32_t nMaterials, const crychic_texture* textures, uint32_t nTextures,
+                 uint32_t W, uint32_t H, int depthBias, float slopeBias, uint32_t* depth, uint16_t* normal, float* g0, float* g1, float* g2)
+{
+    std::vector<SetupTri> tris;
+    bool overflow = false;
+    for (uint32_t it = 0; it < nItems; ++it) {
+        const crychic_draw_item& d = items[it];
+        const uint32_t ntri = d.indexCount / 3u;
+        for (uint32_t inst = 0; inst < d.instanceCount; ++inst)
+            for (uint32_t tri = 0; tri < ntri; ++tri) {
+                const crychic_instance_data& I = d.instances_dev[inst];
+                const crychic_material_data* M = (materials && I.MaterialIndex < nMaterials) ? &materials[I.MaterialIndex] : nullptr;
+                const size_t slot0 = tris.size();
+                tris.resize(slot0 + 3);
+                tris[slot0].A2 = tris[slot0 + 1].A2 = tris[slot0 + 2].A2 = 0;
+                VsOut poly[8], tmp[8];
+                for (int c = 0; c < 3; ++c) {
+                    const int64_t vi = (int64_t)d.indices_dev[d.startIndexLocation + tri * 3u + c] + d.baseVertexLocation;
+                    if (vi < 0 || vi >= (int64_t)d.vertexCount) return -1;
+                    poly[c] = vertex_shader(d.vertices_dev[vi], I, M, viewProj);
+                }
+                int n = clip_plane(poly, 3, 0, tmp);
+                n = clip_plane(tmp, n, 1, poly);
+                for (int c = 1; c + 1 < n; ++c) {
+                    SetupTri s;
+                    if (setup_triangle(poly[0], poly[c], poly[c + 1], I.MaterialIndex, W, H, s, &overflow)) tris[slot0 + (size_t)(c - 1)] = s;
+                }
+            }
+    }
+    if (overflow) return -2;
+    std::vector<uint64_t> vis((size_t)W * H, kVisClear);
+    int live = 0;
+    for (size_t slot = 0; slot < tris.size(); ++slot) {
+        const SetupTri& t = tris[slot];
+        if (t.A2 <= 0) continue;
+        ++live;
+        const PixelBox b = triangle_box(t, W, H);
+        const EdgeFlags e = triangle_edge_flags(t);
+        const double bias = mode == 0 ? triangle_depth_bias(t, depthBias, slopeBias) : 0.0;
+        for (int y = b.y0; y <= b.y1; ++y)
+            for (int x = b.x0; x <= b.x1; ++x) {
+                const uint64_t key = fragment_key(t, e, bias, x, y, (uint32_t)slot + 1u);
+                uint64_t& v = vis[(size_t)y * W + x];
+                if (key < v) v = key;
+            }
+    }
+    const Texture* tex = reinterpret_cast<const Texture*>(textures);
+    for (uint32_t y = 0; y < H; ++y)
+        for (uint32_t x = 0; x < W; ++x) {
+            const size_t idx = (size_t)y * W + x;
+            const uint64_t key = vis[idx];
+            const uint32_t serial = (uint32_t)(key & 0xFFFFFFFFull);
+            depth[idx] = (uint32_t)(key >> 32);
+            if (mode == 0) continue;
+            if (serial == 0) {
+                if (mode == 1) { normal[idx * 4] = 0; normal[idx * 4 + 1] = 0; normal[idx * 4 + 2] = 0x3C00; normal[idx * 4 + 3] = 0; }
+                else for (int c = 0; c < 4; ++c) { g0[idx * 4 + c] = 0; g1[idx * 4 + c] = 0; g2[idx * 4 + c] = 0; }
+                continue;
+            }
+            const ResolveOut r = resolve_pixel(mode, tris[serial - 1u], (int)x, (int)y, view, materials, nMaterials, tex, nTextures);
+            if (mode == 1) {
+                normal[idx * 4] = float_to_half(r.normalV.x); normal[idx * 4 + 1] = float_to_half(r.normalV.y);
+                normal[idx * 4 + 2] = float_to_half(r.normalV.z); normal[idx * 4 + 3] = 0;
+            } else {
+                const float a[12] = { r.g0.x, r.g0.y, r.g0.z, r.g0.w, r.g1.x, r.g1.y, r.g1.z, r.g1.w, r.g2.x, r.g2.y, r.g2.z, r.g2.w };
+                for (int c = 0; c < 4; ++c) { g0[idx * 4 + c] = a[c]; g1[idx * 4 + c] = a[4 + c]; g2[idx * 4 + c] = a[8 + c]; }
+            }
+        }
+    return live;
 }
 
 }  // extern "C"

@@ -14,7 +14,7 @@ CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 
 def build():
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("devmath.hpp", "ssao_core.hpp", "light_core.hpp")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("devmath.hpp", "ssao_core.hpp", "light_core.hpp", "raster_core.hpp")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         subprocess.run([CLANG, "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math",
                         "-I", os.path.join(ROOT, "include"), "-I", CSRC, SRC, "-o", LIB], check=True)
@@ -36,6 +36,8 @@ class HostSim:
         L.hs_ssao.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, u32, u32]
         L.hs_blur.argtypes = [vp, vp, vp, vp, u32, u32, i, u32, u32]
         L.hs_blur_mode.argtypes = [vp, vp, vp, vp, u32, u32, i, i, u32, u32]
+        L.hs_rasterize.restype = i
+        L.hs_rasterize.argtypes = [i, vp, vp, vp, u32, vp, u32, vp, u32, u32, u32, i, f, vp, vp, vp, vp, vp]
         L.hs_light.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp, u32, vp, vp, u32, u32, u32, u32, i, f, u32]
 
     def eval_array(self, kind, a, b=None):
@@ -66,6 +68,32 @@ class HostSim:
         a = np.ascontiguousarray(ambient_in)
         self.lib.hs_blur_mode(C.addressof(cb), edge.ctypes.data, a.ctypes.data, out.ctypes.data, W, H, 1 if horizontal else 0, mode, 0, H // 2)
         return out
+
+    def rasterize(self, mode, view_t, viewproj_t, items, materials, textures, W, H, depth_bias=0, slope_bias=0.0):
+        from crychic_renderer_amd._lib import DrawItem, Texture
+        arr = (DrawItem * len(items))()
+        keep = []
+        for k, (v, idx, inst) in enumerate(items):
+            v = np.ascontiguousarray(v); idx = np.ascontiguousarray(idx); inst = np.ascontiguousarray(inst)
+            keep += [v, idx, inst]
+            arr[k] = DrawItem(v.ctypes.data, len(v), idx.ctypes.data, len(idx), 0, 0, inst.ctypes.data, len(inst))
+        tex = (Texture * max(1, len(textures or [])))()
+        for k, t in enumerate(textures or []):
+            if t is not None:
+                t = np.ascontiguousarray(t); keep.append(t)
+                tex[k] = Texture(t.ctypes.data, t.shape[1], t.shape[0])
+        mats = np.ascontiguousarray(materials) if materials is not None else None
+        depth = np.zeros((H, W), np.uint32)
+        normal = np.zeros((H, W, 4), np.uint16) if mode == 1 else None
+        g = [np.zeros((H, W, 4), np.float32) for _ in range(3)] if mode == 2 else [None] * 3
+        view_t = np.ascontiguousarray(view_t, np.float32); viewproj_t = np.ascontiguousarray(viewproj_t, np.float32)
+        n = self.lib.hs_rasterize(mode, view_t.ctypes.data, viewproj_t.ctypes.data, arr, len(items),
+                                  mats.ctypes.data if mats is not None else None, len(mats) if mats is not None else 0,
+                                  tex if textures else None, len(textures or []), W, H, depth_bias, slope_bias, depth.ctypes.data,
+                                  normal.ctypes.data if normal is not None else None, *[x.ctypes.data if x is not None else None for x in g])
+        if n < 0:
+            raise RuntimeError("hs_rasterize failed (%d)" % n)
+        return {"depth": depth, "normal": normal.view(np.float16) if normal is not None else None, "g0": g[0], "g1": g[1], "g2": g[2], "tris": n}
 
     def light(self, cb, g0, g1, g2, depth_u32, ambient, shadow_u32, cube_u8, num_dir_lights, pcf_radius, flags=0,
               want_radiance=False):

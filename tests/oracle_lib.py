@@ -159,3 +159,88 @@ def as_oracle_cb(product_cb, cls):
     assert C.sizeof(o) == C.sizeof(product_cb)
     C.memmove(C.addressof(o), C.addressof(product_cb), C.sizeof(o))
     return o
+
+
+# ---- producer passes (row f1) ------------------------------------------------------------------------------------
+VERTEX_DT = np.dtype([("Pos", "<f4", 3), ("Normal", "<f4", 3), ("TexC", "<f4", 2), ("TangentU", "<f4", 3)])
+INSTANCE_DT = np.dtype([("World", "<f4", 16), ("TexTransform", "<f4", 16), ("MaterialIndex", "<u4"), ("pad", "<u4", 3)])
+MATERIAL_DT = np.dtype([("DiffuseAlbedo", "<f4", 4), ("FresnelR0", "<f4", 3), ("Roughness", "<f4"), ("MatTransform", "<f4", 16),
+                        ("DiffuseMapIndex", "<u4"), ("NormalMapIndex", "<u4"), ("Metalness", "<f4"), ("pad", "<u4")])
+assert VERTEX_DT.itemsize == 44 and INSTANCE_DT.itemsize == 144 and MATERIAL_DT.itemsize == 112
+
+
+class OrDrawItem(C.Structure):
+    _fields_ = [("vertices", C.c_void_p), ("vertexCount", C.c_uint32), ("indices", C.c_void_p), ("indexCount", C.c_uint32),
+                ("startIndexLocation", C.c_uint32), ("baseVertexLocation", C.c_int32), ("instances", C.c_void_p),
+                ("instanceCount", C.c_uint32)]
+
+
+class OrTexture(C.Structure):
+    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
+
+
+def _raster_protos(L):
+    vp, u32, i, f = C.c_void_p, C.c_uint32, C.c_int, C.c_float
+    L.or_rasterize.restype = i
+    L.or_rasterize.argtypes = [i, vp, vp, vp, u32, vp, u32, vp, u32, u32, u32, i, f, vp, vp, vp, vp, vp]
+    L.or_create_box.restype = i; L.or_create_box.argtypes = [f, f, f, u32, vp, u32, vp, u32, vp]
+    L.or_create_grid.restype = i; L.or_create_grid.argtypes = [f, f, u32, u32, vp, u32, vp, u32, vp]
+    L.or_load_mesh_text.restype = i; L.or_load_mesh_text.argtypes = [C.c_char_p, vp, u32, vp, u32, vp, vp]
+    L.or_float_to_half.restype = C.c_uint16; L.or_float_to_half.argtypes = [f]
+
+
+def create_box(orc, w, h, d, subdiv):
+    _raster_protos(orc.lib)
+    ni = C.c_uint32()
+    nv = orc.lib.or_create_box(w, h, d, subdiv, None, 0, None, 0, C.byref(ni))
+    v = np.zeros(nv, VERTEX_DT); idx = np.zeros(ni.value, np.uint32)
+    assert orc.lib.or_create_box(w, h, d, subdiv, v.ctypes.data, nv, idx.ctypes.data, ni.value, C.byref(ni)) == nv
+    return v, idx
+
+
+def create_grid(orc, w, d, m, n):
+    _raster_protos(orc.lib)
+    ni = C.c_uint32()
+    nv = orc.lib.or_create_grid(w, d, m, n, None, 0, None, 0, C.byref(ni))
+    v = np.zeros(nv, VERTEX_DT); idx = np.zeros(ni.value, np.uint32)
+    assert orc.lib.or_create_grid(w, d, m, n, v.ctypes.data, nv, idx.ctypes.data, ni.value, C.byref(ni)) == nv
+    return v, idx
+
+
+def load_mesh_text(orc, path):
+    _raster_protos(orc.lib)
+    nv, ni = C.c_uint32(), C.c_uint32()
+    if orc.lib.or_load_mesh_text(path.encode(), None, 0, None, 0, C.byref(nv), C.byref(ni)) < 0:
+        raise IOError(path)
+    v = np.zeros(nv.value, VERTEX_DT); idx = np.zeros(ni.value, np.uint32)
+    assert orc.lib.or_load_mesh_text(path.encode(), v.ctypes.data, nv.value, idx.ctypes.data, ni.value, C.byref(nv), C.byref(ni)) == nv.value
+    return v, idx
+
+
+def rasterize(orc, mode, view_t, viewproj_t, items, materials, textures, W, H, depth_bias=0, slope_bias=0.0):
+    """items: list of (vertices, indices, instances) numpy arrays; textures: list of HxWx4 uint8 arrays (or None)."""
+    _raster_protos(orc.lib)
+    arr = (OrDrawItem * len(items))()
+    keep = []
+    for k, (v, idx, inst) in enumerate(items):
+        v = np.ascontiguousarray(v); idx = np.ascontiguousarray(idx); inst = np.ascontiguousarray(inst)
+        keep += [v, idx, inst]
+        arr[k] = OrDrawItem(v.ctypes.data, len(v), idx.ctypes.data, len(idx), 0, 0, inst.ctypes.data, len(inst))
+    tex = (OrTexture * max(1, len(textures or [])))()
+    for k, t in enumerate(textures or []):
+        if t is not None:
+            t = np.ascontiguousarray(t); keep.append(t)
+            tex[k] = OrTexture(t.ctypes.data, t.shape[1], t.shape[0])
+    mats = np.ascontiguousarray(materials) if materials is not None else None
+    depth = np.zeros((H, W), np.uint32)
+    normal = np.zeros((H, W, 4), np.uint16) if mode == 1 else None
+    g = [np.zeros((H, W, 4), np.float32) for _ in range(3)] if mode == 2 else [None] * 3
+    view_t = np.ascontiguousarray(view_t, np.float32); viewproj_t = np.ascontiguousarray(viewproj_t, np.float32)
+    n = orc.lib.or_rasterize(mode, view_t.ctypes.data, viewproj_t.ctypes.data, arr, len(items),
+                             mats.ctypes.data if mats is not None else None, len(mats) if mats is not None else 0,
+                             tex if textures else None, len(textures or []), W, H, depth_bias, slope_bias, depth.ctypes.data,
+                             normal.ctypes.data if normal is not None else None,
+                             *[x.ctypes.data if x is not None else None for x in g])
+    if n < 0:
+        raise RuntimeError("or_rasterize failed")
+    return {"depth": depth, "normal": normal.view(np.float16) if normal is not None else None, "g0": g[0], "g1": g[1], "g2": g[2], "tris": n}
