@@ -2,13 +2,16 @@
 // deferred hot path: same member names (mSsao, mDeferred, mShadowMap, mMainPassCB, mFrameResources ...), same
 // Initialize / OnResize / Update / Draw call sequence, D3D12 replaced by libcrychic_hip.so.
 //
-// What Draw() covers: CRYCHIC.cpp:220-221 (ComputeSsao) and :238-279 (deferred lighting + sky) on the GPU.  The
-// producer passes that fill the shadow maps, the normal/depth target and the G-buffer through the D3D rasteriser
-// (DrawSceneToShadowMap / DrawNormalsAndDepth / DrawGBuffer, CRYCHIC.cpp:208,214,236) are SURVEY.md row f1; until they
-// exist the caller writes those planes directly (Resource accessors below).
+// What Draw() covers: the whole deferred branch of CRYCHIC::Draw -- DrawSceneToShadowMap, DrawNormalsAndDepth
+// (CRYCHIC.cpp:208,214), ComputeSsao (:220-221), DrawGBuffer (:236) and the deferred lighting + sky (:238-279) -- on
+// the reference's live scene (100 instanced boxes + grid, CRYCHIC.cpp:2274-2436).  Set mRunProducerPasses = false to
+// feed externally produced planes through the Resource accessors instead.
 #pragma once
 #include <cmath>
+#include <cstring>
 #include <memory>
+#include <string>
+#include <unordered_map>
 #include <vector>
 #include "DeferredShading.h"
 #include "FrameResource.h"
@@ -40,6 +43,45 @@ private:
     crychic_camera mCam = { { 0, 0, 0 }, { 0, 0, 1 }, { 0, 1, 0 }, 0.7853981634f, 1.0f, 1.0f, 1000.0f };
 };
 
+// Common/d3dUtil.h:163-214 (the fields the draws consume)
+struct SubmeshGeometry {
+    UINT IndexCount = 0;
+    UINT StartIndexLocation = 0;
+    int BaseVertexLocation = 0;
+};
+struct MeshGeometry {
+    std::string Name;
+    std::unique_ptr<ID3D12Resource> VertexBufferGPU, IndexBufferGPU;
+    UINT VertexCount = 0, IndexCount = 0;
+    std::unordered_map<std::string, SubmeshGeometry> DrawArgs;
+};
+// Common/d3dUtil.h:240-265
+struct Material {
+    std::string Name;
+    int MatCBIndex = -1;
+    int DiffuseSrvHeapIndex = -1;
+    int NormalSrvHeapIndex = -1;
+    int NumFramesDirty = gNumFrameResources;
+    DirectX::XMFLOAT4 DiffuseAlbedo = { 1.0f, 1.0f, 1.0f, 1.0f };
+    DirectX::XMFLOAT3 FresnelR0 = { 0.01f, 0.01f, 0.01f };
+    float Roughness = .25f;
+    DirectX::XMFLOAT4X4 MatTransform = crychic_detail::Identity4x4();
+};
+// CRYCHIC.h:23-42
+struct RenderItem {
+    RenderItem() = default;
+    RenderItem(const RenderItem& rhs) = delete;
+    Material* Mat = nullptr;
+    MeshGeometry* Geo = nullptr;
+    UINT IndexCount = 0;
+    UINT StartIndexLocation = 0;
+    int BaseVertexLocation = 0;
+    UINT InstanceCount = 0;
+    std::vector<InstanceData> Instances;
+    UINT itemIndex = 0;
+};
+enum class RenderLayer : int { Opaque = 0, OpaqueShadow, Count };  // CRYCHIC.h:44-54 (the layers the deferred path draws)
+
 class CRYCHIC {
 public:
     CRYCHIC(int deviceOrdinal, UINT width, UINT height) : mClientWidth(width), mClientHeight(height)
@@ -61,7 +103,11 @@ public:
         mShadowMap = std::make_unique<ShadowMap>(md3dDevice.get(), mShadowMapSize, mShadowMapSize); // :48-49
         mSsao = std::make_unique<Ssao>(md3dDevice.get(), mCommandList.get(), mClientWidth, mClientHeight);  // :51-54
         mDeferred = std::make_unique<DeferredShading>(md3dDevice.get(), mClientWidth, mClientHeight, DXGI_FORMAT_R32G32B32A32_FLOAT);  // :56-58
-        BuildFrameResources();
+        BuildShapeGeometry();                                                                       // :65
+        BuildMaterials();                                                                           // :67
+        BuildCascadeShadowRenderItems();                                                            // :70
+        BuildCascadeShadowRenderItemsWithShadow();                                                  // :71
+        BuildFrameResources();                                                                      // :72
         OnResize();
         mCommandList->Flush();                                                                      // :83
         return true;
@@ -91,13 +137,21 @@ public:
             const DirectX::XMFLOAT3 d = mBaseLightDirections[i];
             mRotatedLightDirections[i] = { d.x * c + d.z * s, d.y, -d.x * s + d.z * c };
         }
+        UpdateInstanceData(gt);                                                                     // :164
+        UpdateMaterialBuffer(gt);                                                                   // :165
         UpdateCascadeShadowTransform(gt);
         UpdateMainPassCB(gt);
+        UpdateShadowPassCB(gt);
         UpdateSsaoCB(gt);
     }
 
     void Draw(const GameTimer&)  // CRYCHIC.cpp:172-306, deferred branch
     {
+        if (mRunProducerPasses) {
+            DrawSceneToShadowMap();                                                                 // :208
+            DrawNormalsAndDepth();                                                                  // :214
+            DrawGBuffer();                                                                          // :236
+        }
         crychic_frame_desc f = {};
         f.W = mClientWidth; f.H = mClientHeight;
         f.blurCount = mBlurCount;                                                                   // :221
@@ -137,6 +191,7 @@ public:
     ID3D12Device* Device() { return md3dDevice.get(); }
     float AspectRatio() const { return (float)mClientWidth / (float)mClientHeight; }
 
+    bool mRunProducerPasses = true;   // false: the caller fills the input planes itself (tests, external producers)
     std::unique_ptr<ShadowMap> mShadowMap;
     std::unique_ptr<Ssao> mSsao;
     std::unique_ptr<DeferredShading> mDeferred;
@@ -151,13 +206,202 @@ public:
     FrameResource* mCurrFrameResource = nullptr;
 
 private:
+    // ---- scene construction ---------------------------------------------------------------------------------------
+    void BuildShapeGeometry()  // CRYCHIC.cpp:1250-1445: box + grid concatenated into one vertex / index buffer
+    {
+        uint32_t nbI = 0, ngI = 0;
+        const int nbV = crychic_create_box(1.0f, 1.0f, 1.0f, 3, nullptr, 0, nullptr, 0, &nbI);         // :1253
+        const int ngV = crychic_create_grid(20.0f, 30.0f, 60, 40, nullptr, 0, nullptr, 0, &ngI);       // :1254
+        std::vector<crychic_vertex> v((size_t)nbV + ngV);
+        std::vector<uint32_t> idx((size_t)nbI + ngI);
+        CrychicThrowIfFailed(crychic_create_box(1.0f, 1.0f, 1.0f, 3, v.data(), nbV, idx.data(), nbI, &nbI));
+        CrychicThrowIfFailed(crychic_create_grid(20.0f, 30.0f, 60, 40, v.data() + nbV, ngV, idx.data() + nbI, ngI, &ngI));
+        auto geo = std::make_unique<MeshGeometry>();
+        geo->Name = "shapeGeo";
+        geo->VertexCount = (UINT)v.size(); geo->IndexCount = (UINT)idx.size();
+        geo->VertexBufferGPU = std::make_unique<ID3D12Resource>(v.size() * sizeof(crychic_vertex), ID3D12Resource::DEFAULT_HEAP);
+        geo->IndexBufferGPU = std::make_unique<ID3D12Resource>(idx.size() * 4, ID3D12Resource::DEFAULT_HEAP);
+        geo->VertexBufferGPU->Upload(v.data(), v.size() * sizeof(crychic_vertex), mCommandList->Stream());
+        geo->IndexBufferGPU->Upload(idx.data(), idx.size() * 4, mCommandList->Stream());
+        mCommandList->Flush();
+        geo->DrawArgs["box"] = SubmeshGeometry{ nbI, 0, 0 };                                            // :1271-1301
+        geo->DrawArgs["grid"] = SubmeshGeometry{ ngI, nbI, nbV };
+        mGeometries[geo->Name] = std::move(geo);
+    }
+    void BuildMaterials()  // CRYCHIC.cpp:1768-1821
+    {
+        auto add = [&](const char* name, int cb, int d, int n, DirectX::XMFLOAT4 alb, DirectX::XMFLOAT3 r0, float rough) {
+            auto m = std::make_unique<Material>();
+            m->Name = name; m->MatCBIndex = cb; m->DiffuseSrvHeapIndex = d; m->NormalSrvHeapIndex = n;
+            m->DiffuseAlbedo = alb; m->FresnelR0 = r0; m->Roughness = rough;
+            mMaterials[name] = std::move(m);
+        };
+        add("bricks0", 0, 0, 1, { 1.0f, 1.0f, 1.0f, 1.0f }, { 0.1f, 0.1f, 0.1f }, 0.3f);
+        add("tile0", 1, 2, 3, { 0.9f, 0.9f, 0.9f, 1.0f }, { 0.2f, 0.2f, 0.2f }, 0.7f);
+        add("mirror0", 2, 4, 5, { 0.0f, 0.0f, 0.0f, 1.0f }, { 0.98f, 0.97f, 0.95f }, 0.1f);
+        add("skullMat", 3, 4, 5, { 1.0f, 1.0f, 1.0f, 1.0f }, { 0.6f, 0.6f, 0.6f }, 0.8f);
+        add("sky", 4, 6, 7, { 1.0f, 1.0f, 1.0f, 1.0f }, { 0.1f, 0.1f, 0.1f }, 1.0f);
+    }
+    static DirectX::XMFLOAT4X4 ScaleTranslate(float s, float tx, float ty, float tz)   // XMMatrixScaling * XMMatrixTranslation
+    {
+        return DirectX::XMFLOAT4X4{ { { s, 0, 0, 0 }, { 0, s, 0, 0 }, { 0, 0, s, 0 }, { tx, ty, tz, 1 } } };
+    }
+    void AddBoxAndGrid(RenderLayer layer, int boxMaterialModulo, UINT gridMaterial)
+    {
+        MeshGeometry* geo = mGeometries["shapeGeo"].get();
+        auto box = std::make_unique<RenderItem>();
+        box->itemIndex = mItemIndex++;
+        box->Geo = geo;
+        box->IndexCount = geo->DrawArgs["box"].IndexCount;
+        box->StartIndexLocation = geo->DrawArgs["box"].StartIndexLocation;
+        box->BaseVertexLocation = geo->DrawArgs["box"].BaseVertexLocation;
+        box->Instances.resize(100);
+        box->InstanceCount = 100;
+        for (int i = 0; i < 10; ++i)
+            for (int j = 0; j < 10; ++j) {                                                            // :2338-2346, 2398-2406
+                box->Instances[i * 10 + j].World = ScaleTranslate(1.6f, (-5 + i) * 5.0f, 0.8f, (-5 + j) * 5.0f);
+                box->Instances[i * 10 + j].MaterialIndex = (UINT)(i % boxMaterialModulo);
+            }
+        mInstanceCounts.push_back(100);
+        mRitemLayer[(int)layer].push_back(box.get());
+        mAllRitems.push_back(std::move(box));
+        auto grid = std::make_unique<RenderItem>();
+        grid->itemIndex = mItemIndex++;
+        grid->Geo = geo;
+        grid->IndexCount = geo->DrawArgs["grid"].IndexCount;
+        grid->StartIndexLocation = geo->DrawArgs["grid"].StartIndexLocation;
+        grid->BaseVertexLocation = geo->DrawArgs["grid"].BaseVertexLocation;
+        grid->Instances.resize(1);
+        grid->InstanceCount = 1;
+        grid->Instances[0].World = ScaleTranslate(3.0f, 0.0f, 0.0f, 0.0f);                            // :2371, 2431
+        grid->Instances[0].MaterialIndex = gridMaterial;
+        mInstanceCounts.push_back(1);
+        mRitemLayer[(int)layer].push_back(grid.get());
+        mAllRitems.push_back(std::move(grid));
+    }
+    void BuildCascadeShadowRenderItems() { AddBoxAndGrid(RenderLayer::Opaque, 2, 3); }               // CRYCHIC.cpp:2322-2375 (sky / debug quad are not drawn by the deferred path's producers)
+    void BuildCascadeShadowRenderItemsWithShadow() { AddBoxAndGrid(RenderLayer::OpaqueShadow, 3, 1); }  // :2380-2435
+
     void BuildFrameResources()  // CRYCHIC.cpp:1759-1766: 1 main + 12 shadow pass slots
     {
-        std::vector<int> instanceCounts;
         for (int i = 0; i < gNumFrameResources; ++i) {
-            mFrameResources.push_back(std::make_unique<FrameResource>(md3dDevice.get(), 1 + 12, instanceCounts, 0, 5));
+            mFrameResources.push_back(std::make_unique<FrameResource>(md3dDevice.get(), 1 + 12, mInstanceCounts, (UINT)mAllRitems.size(),
+                                                                      (UINT)mMaterials.size()));
             CrychicHipThrowIfFailed(hipEventCreateWithFlags(&mFrameResources.back()->FenceEvent, hipEventDisableTiming));
         }
+    }
+    static DirectX::XMFLOAT4X4 Transposed(const DirectX::XMFLOAT4X4& a)
+    {
+        DirectX::XMFLOAT4X4 t;
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) t.m[i][j] = a.m[j][i];
+        return t;
+    }
+    void UpdateInstanceData(const GameTimer&)  // CRYCHIC.cpp:515-564 (frustum culling off: every instance is copied; culled instances are invisible anyway)
+    {
+        for (auto& ri : mAllRitems) {
+            auto* buf = mCurrFrameResource->InstanceBuffers[ri->itemIndex].get();
+            int n = 0;
+            for (const InstanceData& src : ri->Instances) {
+                InstanceData data;
+                data.World = Transposed(src.World);                                                   // :546
+                data.TexTransform = Transposed(src.TexTransform);                                     // :547
+                data.MaterialIndex = src.MaterialIndex;
+                buf->CopyData(n++, data);
+            }
+            ri->InstanceCount = (UINT)n;
+        }
+    }
+    void UpdateMaterialBuffer(const GameTimer&)  // CRYCHIC.cpp:566-592
+    {
+        auto* buf = mCurrFrameResource->MaterialBuffer.get();
+        for (auto& e : mMaterials) {
+            Material* mat = e.second.get();
+            if (mat->NumFramesDirty > 0) {
+                MaterialData d;
+                d.DiffuseAlbedo = mat->DiffuseAlbedo; d.FresnelR0 = mat->FresnelR0; d.Roughness = mat->Roughness;
+                d.MatTransform = Transposed(mat->MatTransform);
+                d.DiffuseMapIndex = (UINT)mat->DiffuseSrvHeapIndex; d.NormalMapIndex = (UINT)mat->NormalSrvHeapIndex;
+                buf->CopyData(mat->MatCBIndex, d);                                                    // Metalness keeps its default 0.5 (Q5)
+                mat->NumFramesDirty--;
+            }
+        }
+    }
+    void UpdateShadowPassCB(const GameTimer&)  // CRYCHIC.cpp:870-901: slots 1..12, of which cascades 0..3 are meaningful
+    {
+        for (int i = 0; i < 4; ++i) {
+            PassConstants cb;
+            float vp[4][4];
+            for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) {
+                float acc = 0.0f;
+                for (int k = 0; k < 4; ++k) acc += mLightViews[i].m[r][k] * mLightProjs[i].m[k][c];
+                vp[r][c] = acc;
+            }
+            for (int r = 0; r < 4; ++r) for (int c = 0; c < 4; ++c) { cb.ViewProj.m[c][r] = vp[r][c]; cb.View.m[c][r] = mLightViews[i].m[r][c]; cb.Proj.m[c][r] = mLightProjs[i].m[r][c]; }
+            cb.RenderTargetSize = { (float)mShadowMap->Width(), (float)mShadowMap->Height() };
+            cb.InvRenderTargetSize = { 1.0f / mShadowMap->Width(), 1.0f / mShadowMap->Height() };
+            mCurrFrameResource->PassCB->CopyData(1 + i, cb);                                          // :897-898
+        }
+    }
+
+    // ---- producer passes --------------------------------------------------------------------------------------------
+    std::vector<crychic_draw_item> DrawItems(const std::vector<RenderItem*>& ritems)  // CRYCHIC::DrawRenderItems, CRYCHIC.cpp:2438-2475
+    {
+        std::vector<crychic_draw_item> out;
+        mSceneTriangles = 0;
+        for (RenderItem* ri : ritems) {
+            crychic_draw_item d = {};
+            d.vertices_dev = static_cast<const crychic_vertex*>(ri->Geo->VertexBufferGPU->Data());
+            d.vertexCount = ri->Geo->VertexCount;
+            d.indices_dev = static_cast<const uint32_t*>(ri->Geo->IndexBufferGPU->Data());
+            d.indexCount = ri->IndexCount; d.startIndexLocation = ri->StartIndexLocation; d.baseVertexLocation = ri->BaseVertexLocation;
+            d.instances_dev = reinterpret_cast<const crychic_instance_data*>(mCurrFrameResource->InstanceBuffers[ri->itemIndex]->Resource()->Data());
+            d.instanceCount = ri->InstanceCount;
+            out.push_back(d);
+            mSceneTriangles += (uint64_t)(ri->IndexCount / 3) * ri->InstanceCount;
+        }
+        return out;
+    }
+    void* RasterWorkspace(uint64_t triangles, UINT W, UINT H, size_t* bytes)
+    {
+        *bytes = crychic_raster_workspace_bytes(triangles, W, H);
+        if (!mRasterWorkspace || mRasterWorkspace->Bytes() < *bytes) mRasterWorkspace = std::make_unique<ID3D12Resource>(*bytes, ID3D12Resource::DEFAULT_HEAP);
+        return mRasterWorkspace->Data();
+    }
+    void DrawSceneToShadowMap()  // CRYCHIC.cpp:2477-2510 (the reference loops 6 times; cascades 0..3 carry data, Q8)
+    {
+        auto items = DrawItems(mRitemLayer[(int)RenderLayer::OpaqueShadow]);
+        size_t bytes;
+        void* ws = RasterWorkspace(mSceneTriangles, mShadowMap->Width(), mShadowMap->Height(), &bytes);
+        for (int i = 0; i < 4; ++i) {
+            const PassConstants& cb = mCurrFrameResource->PassCB->Element(1 + i);
+            CrychicThrowIfFailed(crychic_draw_scene_to_shadow_map(md3dDevice->Ctx(), reinterpret_cast<const crychic_pass_constants*>(&cb), items.data(),
+                                                                  (uint32_t)items.size(), static_cast<uint32_t*>(mShadowMap->Resource(i)->Data()),
+                                                                  mShadowMap->Width(), 10000, 2.0f, ws, bytes, mCommandList->Stream()));  // bias: :1601-1603
+        }
+    }
+    void DrawNormalsAndDepth()  // CRYCHIC.cpp:2512-2543
+    {
+        auto items = DrawItems(mRitemLayer[(int)RenderLayer::Opaque]);
+        size_t bytes;
+        void* ws = RasterWorkspace(mSceneTriangles, mClientWidth, mClientHeight, &bytes);
+        const PassConstants& cb = mCurrFrameResource->PassCB->Element(0);
+        CrychicThrowIfFailed(crychic_draw_normals_and_depth(md3dDevice->Ctx(), reinterpret_cast<const crychic_pass_constants*>(&cb), items.data(),
+                                                            (uint32_t)items.size(), mSsao->NormalMap()->Data(),
+                                                            static_cast<uint32_t*>(mDepthStencilBuffer->Data()), mClientWidth, mClientHeight, ws, bytes,
+                                                            mCommandList->Stream()));
+    }
+    void DrawGBuffer()  // CRYCHIC.cpp:2545-2571
+    {
+        auto items = DrawItems(mRitemLayer[(int)RenderLayer::Opaque]);
+        size_t bytes;
+        void* ws = RasterWorkspace(mSceneTriangles, mClientWidth, mClientHeight, &bytes);
+        const PassConstants& cb = mCurrFrameResource->PassCB->Element(0);
+        CrychicThrowIfFailed(crychic_draw_gbuffer(
+            md3dDevice->Ctx(), reinterpret_cast<const crychic_pass_constants*>(&cb), items.data(), (uint32_t)items.size(),
+            reinterpret_cast<const crychic_material_data*>(mCurrFrameResource->MaterialBuffer->Resource()->Data()), (uint32_t)mMaterials.size(),
+            mTextures.empty() ? nullptr : mTextures.data(), (uint32_t)mTextures.size(), static_cast<float*>(mDeferred->Resource(0)->Data()),
+            static_cast<float*>(mDeferred->Resource(1)->Data()), static_cast<float*>(mDeferred->Resource(2)->Data()),
+            static_cast<uint32_t*>(mDepthStencilBuffer->Data()), mClientWidth, mClientHeight, ws, bytes, mCommandList->Stream()));
     }
     void UpdateCascadeShadowTransform(const GameTimer&)  // CRYCHIC.cpp:634-815
     {
@@ -190,6 +434,15 @@ private:
         mCurrFrameResource->SsaoCB->CopyData(0, ssaoCB);                                            // :935-936
     }
 
+    std::unordered_map<std::string, std::unique_ptr<MeshGeometry>> mGeometries;      // CRYCHIC.h:123-125
+    std::unordered_map<std::string, std::unique_ptr<Material>> mMaterials;
+    std::vector<crychic_texture> mTextures;                                           // gTextureMaps (row f4 loads the DDS files; empty = white / flat)
+    std::vector<std::unique_ptr<RenderItem>> mAllRitems;                              // CRYCHIC.h:132-135
+    std::vector<RenderItem*> mRitemLayer[(int)RenderLayer::Count];
+    std::vector<int> mInstanceCounts;                                                 // CRYCHIC.h:183
+    UINT mItemIndex = 0;
+    uint64_t mSceneTriangles = 0;
+    std::unique_ptr<ID3D12Resource> mRasterWorkspace;
     std::unique_ptr<ID3D12Device> md3dDevice;
     std::unique_ptr<ID3D12GraphicsCommandList> mCommandList;
     std::vector<std::unique_ptr<FrameResource>> mFrameResources;

@@ -249,7 +249,7 @@ typedef struct crychic_draw_item {
 /* A mip-0 R8G8B8A8_UNORM texture of gTextureMaps[] (Common.hlsl:52); rgba8_dev may be NULL (white / flat normal). */
 typedef struct crychic_texture { const uint8_t* rgba8_dev; uint32_t width, height; } crychic_texture;
 
-/* GeometryGenerator::CreateBox / CreateGrid (Common/GeometryGenerator.cpp:10-101, 551-614) and the Models/*.txt loader
+/* GeometryGenerator::CreateBox / CreateGrid (Common/GeometryGenerator.cpp:10-101, 551-614) and the Models/<name>.txt loader
  * of CRYCHIC::BuildSkullGeometry (CRYCHIC.cpp:1447-1557), host memory.  Call with NULL buffers to get the counts.
  * Return the vertex count, or a negative status. */
 int crychic_create_box(float width, float height, float depth, uint32_t numSubdivisions, crychic_vertex* vertices,

@@ -1,7 +1,9 @@
 // veneer_driver.cpp -- exercises the C++ veneer (include/crychic/*.h) exactly as reference call sites would:
 // CRYCHIC::Initialize / Update / Draw, UploadBuffer::CopyData, Ssao::ComputeSsao ...  Input planes come from raw
 // files written by the pytest side (tests/test_cpp_veneer.py); outputs go back as raw files for comparison with
-// the oracle.  Usage: veneer_driver <dir> <W> <H> <shadowDim> <cubeDim> <blurCount> <numDirLights>
+// the oracle.  Usage: veneer_driver <dir> <W> <H> <shadowDim> <cubeDim> <blurCount> <numDirLights> [scene]
+// With the trailing word `scene` the application also runs its own producer passes on its built-in scene (100 boxes +
+// grid) instead of loading depth / normal / G-buffer / shadow planes from <dir>.
 #include <cstdio>
 #include <cstdlib>
 #include <fstream>
@@ -39,12 +41,16 @@ int main(int argc, char** argv)
         app.mBlurCount = std::atoi(argv[6]);
         app.mNumDirLights = std::atoi(argv[7]);
         app.mSkyEnabled = true;
+        const bool sceneMode = argc > 8 && std::string(argv[8]) == "scene";
+        app.mRunProducerPasses = sceneMode;
         if (!app.Initialize()) return 3;
         hipStream_t s = app.CommandList()->Stream();
-        put(app.DepthStencilBuffer(), dir + "/depth.bin", s);
-        put(app.mSsao->NormalMap(), dir + "/normal.bin", s);
-        for (int i = 0; i < 3; ++i) put(app.mDeferred->Resource(i), dir + "/g" + std::to_string(i) + ".bin", s);
-        for (int i = 0; i < 4; ++i) put(app.mShadowMap->Resource(i), dir + "/shadow" + std::to_string(i) + ".bin", s);
+        if (!sceneMode) {
+            put(app.DepthStencilBuffer(), dir + "/depth.bin", s);
+            put(app.mSsao->NormalMap(), dir + "/normal.bin", s);
+            for (int i = 0; i < 3; ++i) put(app.mDeferred->Resource(i), dir + "/g" + std::to_string(i) + ".bin", s);
+            for (int i = 0; i < 4; ++i) put(app.mShadowMap->Resource(i), dir + "/shadow" + std::to_string(i) + ".bin", s);
+        }
         auto cube = std::make_unique<ID3D12Resource>((size_t)6 * CD * CD * 4, ID3D12Resource::DEFAULT_HEAP);
         put(cube.get(), dir + "/cube.bin", s);
         app.SetCubeMap(std::move(cube), CD);
@@ -64,6 +70,18 @@ int main(int argc, char** argv)
         std::vector<uint8_t> rv(256 * 256 * 4);
         app.mSsao->RandomVectorMap()->Download(rv.data(), rv.size(), s);
         app.CommandList()->Flush();
+        if (sceneMode) {   // the planes the producer passes rendered
+            auto grab = [&](ID3D12Resource* r, const std::string& name) {
+                std::vector<char> h(r->Bytes());
+                r->Download(h.data(), h.size(), s);
+                app.CommandList()->Flush();
+                dump(dir + "/" + name, h.data(), h.size());
+            };
+            grab(app.DepthStencilBuffer(), "depth_out.bin");
+            grab(app.mSsao->NormalMap(), "normal_out.bin");
+            for (int i = 0; i < 3; ++i) grab(app.mDeferred->Resource(i), "g" + std::to_string(i) + "_out.bin");
+            for (int i = 0; i < 4; ++i) grab(app.mShadowMap->Resource(i), "shadow" + std::to_string(i) + "_out.bin");
+        }
         dump(dir + "/out.bin", out.data(), out.size());
         dump(dir + "/ao.bin", ao.data(), ao.size() * 2);
         dump(dir + "/randvec.bin", rv.data(), rv.size());

@@ -59,3 +59,35 @@ def test_veneer_frame_matches_oracle(built_lib, oracle, tmp_path):
     ref = oracle.deferred_light(pcb, p["g0"], p["g1"], p["g2"], p["depth"], ref_ao, p["shadow"], p["cube"], NL,
                                 built_lib.lib.crychic_pcf_search_radius(SD, 1), sky=True)
     assert np.array_equal(out, ref)
+
+
+@pytest.mark.gpu
+def test_veneer_full_scene_matches_oracle(built_lib, oracle, tmp_path):
+    """CRYCHIC::Initialize builds the reference's live scene (100 instanced boxes + grid in one vertex/index buffer with
+    BaseVertexLocation / StartIndexLocation), Update fills the instance / material / pass upload buffers, Draw runs the
+    producer passes and the hot path: every plane equals the all-CPU oracle frame."""
+    import ctypes as C
+    import raster_util
+    from crychic_renderer_amd import geometry as g, scene
+    import torch
+    exe = build_driver()
+    W, H, SD, CD, BC, NL = 160, 120, 256, 32, 2, 1
+    d = str(tmp_path)
+    cube = scene.make_cubemap(CD, torch.device("cpu")).numpy()
+    cube.tofile(d + "/cube.bin")
+    r = subprocess.run([exe, d, str(W), str(H), str(SD), str(CD), str(BC), str(NL), "scene"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    consts = raster_util.frame_constants(W, H, SD)
+    # the driver's own constant buffers (same builders, same camera) drive the oracle
+    C.memmove(C.addressof(consts.ssao_cb), open(d + "/ssao_cb.bin", "rb").read(), C.sizeof(consts.ssao_cb))
+    C.memmove(C.addressof(consts.pass_cb), open(d + "/pass_cb.bin", "rb").read(), C.sizeof(consts.pass_cb))
+    ref = raster_util.oracle_frame(oracle, consts, g.cascade_scene_items(), g.cascade_scene_items(shadow_layer=True), g.reference_materials(),
+                                   None, W, H, SD, cube, BC, NL, built_lib.lib.crychic_pcf_search_radius(SD, 1))
+    for k in range(4):
+        assert np.array_equal(np.fromfile(d + "/shadow%d_out.bin" % k, np.uint32).reshape(SD, SD), ref["shadow"][k]), k
+    assert np.array_equal(np.fromfile(d + "/depth_out.bin", np.uint32).reshape(H, W), ref["depth"])
+    assert np.array_equal(np.fromfile(d + "/normal_out.bin", np.uint16).reshape(H, W, 4), ref["normal"].view(np.uint16))
+    for i, k in enumerate(("g0", "g1", "g2")):
+        assert np.array_equal(np.fromfile(d + "/g%d_out.bin" % i, np.uint32).reshape(H, W, 4), ref[k].view(np.uint32)), k
+    assert np.array_equal(np.fromfile(d + "/ao.bin", np.uint16).reshape(H // 2, W // 2), ref["ao"])
+    assert np.array_equal(np.fromfile(d + "/out.bin", np.uint8).reshape(H, W, 4), ref["rgba8"])
