@@ -48,7 +48,8 @@ class FrameDesc(C.Structure):
                 ("g0_dev", C.c_void_p), ("g1_dev", C.c_void_p), ("g2_dev", C.c_void_p),
                 ("shadow_dev", C.c_void_p * 4), ("shadowDim", C.c_uint32), ("cube_dev", C.c_void_p),
                 ("cubeDim", C.c_uint32), ("ambient0_dev", C.c_void_p), ("ambient1_dev", C.c_void_p),
-                ("edge_dev", C.c_void_p), ("out_rgba8_dev", C.c_void_p)]
+                ("edge_dev", C.c_void_p), ("out_rgba8_dev", C.c_void_p),
+                ("point_lights_dev", C.c_void_p), ("numPointLights", C.c_uint32)]
 
 
 class DrawItem(C.Structure):
@@ -93,6 +94,8 @@ PROTOTYPES = {
                                   _vp]),
     "crychic_deferred_light": (_i, [_vp, _P(PassConstants), _vp, _vp, _vp, _vp, _vp, _P(_vp), _u32, _vp, _u32, _vp,
                                     _vp, _u32, _u32, _u32, _u32, _i, _f, _u32, _vp]),
+    "crychic_deferred_light_points": (_i, [_vp, _P(PassConstants), _vp, _vp, _vp, _vp, _vp, _P(_vp), _u32, _vp, _u32, _vp,
+                                           _vp, _u32, _u32, _u32, _u32, _i, _f, _u32, _vp, _u32, _vp]),
     "crychic_draw_hot_path": (_i, [_vp, _P(SsaoConstants), _P(PassConstants), _P(FrameDesc), _vp]),
     "crychic_ctx_set_profiling": (_i, [_vp, _i]),
     "crychic_ctx_last_pass_times": (_i, [_vp, _P(PassTimes)]),
@@ -132,6 +135,15 @@ def _preload_hip_runtime():
 
 def load():
     _preload_hip_runtime()
+    # Rebuild a missing / stale library when the toolchain is present (a checkout whose sources are newer than the .so);
+    # this is a build step, not a fallback: without hipcc and without a library the import fails below.
+    try:
+        from . import build as _build
+        if _build._stale() and os.path.exists(os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")):
+            _build.build(verbose=False)
+    except Exception as e:  # a failed rebuild must not be hidden behind an old binary
+        if os.path.exists(LIB_PATH):
+            raise ImportError("libcrychic_hip.so is stale and rebuilding it failed: %s" % e)
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "libcrychic_hip.so is not built (%s). Run `python -m crychic_renderer_amd.build`; "

@@ -118,6 +118,8 @@ int fill_light_params(cry::LightParams& P, const crychic_pass_constants* cb, con
     P.H = H;
     P.numDirLights = numDirLights;
     P.flags = flags;
+    P.pointLights = nullptr;
+    P.numPointLights = 0;
     return 0;
 }
 
@@ -238,6 +240,29 @@ int crychic_deferred_light(crychic_ctx* ctx, const crychic_pass_constants* cb, c
     return 0;
 }
 
+int crychic_deferred_light_points(crychic_ctx* ctx, const crychic_pass_constants* cb, const float* g0_dev, const float* g1_dev,
+                                  const float* g2_dev, const uint32_t* depth_dev, const uint16_t* ambient_dev,
+                                  const uint32_t* const shadow_dev[4], uint32_t shadowDim, const uint8_t* cube_dev,
+                                  uint32_t cubeDim, uint8_t* out_rgba8_dev, float* radiance_out_dev, uint32_t W, uint32_t H,
+                                  uint32_t row0, uint32_t rows, int numDirLights, float pcfSearchRadius, uint32_t flags,
+                                  const crychic_light* point_lights_dev, uint32_t numPointLights, void* stream)
+{
+    if (int rc = bind(ctx)) return rc;
+    if (int rc = check_dims(W, H)) return rc;
+    if (!cb || !g0_dev || !g1_dev || !g2_dev || !depth_dev || !shadow_dev || !cube_dev || !out_rgba8_dev)
+        return fail(CRYCHIC_E_INVALID_ARG, "null argument");
+    if (row0 > H || rows > H - row0) return fail(CRYCHIC_E_INVALID_ARG, "rows [%u,+%u) outside the %u-row frame", row0, rows, H);
+    if (numPointLights > cry::kMaxPointLights || (numPointLights && !point_lights_dev))
+        return fail(CRYCHIC_E_INVALID_ARG, "numPointLights %u (max %u) / null light buffer", numPointLights, cry::kMaxPointLights);
+    cry::LightParams P;
+    if (int rc = fill_light_params(P, cb, shadow_dev, shadowDim, cubeDim, W, H, numDirLights, pcfSearchRadius, flags)) return rc;
+    P.pointLights = point_lights_dev;
+    P.numPointLights = numPointLights;
+    CRY_HIP(cry::launch_light(P, g0_dev, g1_dev, g2_dev, depth_dev, ambient_dev, cube_dev, out_rgba8_dev, radiance_out_dev,
+                              row0, rows, (hipStream_t)stream));
+    return 0;
+}
+
 int crychic_draw_hot_path(crychic_ctx* ctx, const crychic_ssao_constants* ssaoCB, const crychic_pass_constants* passCB,
                           const crychic_frame_desc* f, void* stream_)
 {
@@ -255,6 +280,10 @@ int crychic_draw_hot_path(crychic_ctx* ctx, const crychic_ssao_constants* ssaoCB
     cry::LightParams P;
     if (int rc = fill_light_params(P, passCB, f->shadow_dev, f->shadowDim, f->cubeDim, W, H, f->numDirLights,
                                    f->pcfSearchRadius, f->flags)) return rc;
+    if (f->numPointLights > cry::kMaxPointLights || (f->numPointLights && !f->point_lights_dev))
+        return fail(CRYCHIC_E_INVALID_ARG, "numPointLights %u (max %u) / null light buffer", f->numPointLights, cry::kMaxPointLights);
+    P.pointLights = f->point_lights_dev;
+    P.numPointLights = f->numPointLights;
     const bool prof = ctx->profiling;
     if (prof) { ctx->times_valid = false; CRY_HIP(hipEventRecord(ctx->ev[0], stream)); }
     if (ssaoOn) {

@@ -198,6 +198,94 @@ __global__ __launch_bounds__(256) void light_kernel(LightParams P, const f4a* __
     out[idx] = pack_rgba8(lit);
 }
 
+// ---- deferred lighting with point lights (extension, BASELINE configs[4]) ------------------------------------------
+// Same pass plus NUM_POINT_LIGHTS point lights.  Tiled light culling in LDS: the 64 x 4-pixel tile of a workgroup
+// reduces the world-space bounding box of its covered pixels (wave shuffles, then LDS), every lane then tests lights
+// against the box (sphere of radius FalloffEnd vs AABB, conservatively inflated) and sets the light's bit in an LDS mask;
+// each pixel finally walks the set bits in ascending index order -- the accumulation order of the un-culled loop -- and
+// applies the exact per-pixel range test, so culling never changes a bit of the result.
+template <bool ZERO_RADIUS>
+__global__ __launch_bounds__(256) void light_points_kernel(LightParams P, const f4a* __restrict__ g0, const f4a* __restrict__ g1,
+                                                           const f4a* __restrict__ g2, const uint32_t* __restrict__ depth,
+                                                           const uint16_t* __restrict__ ambient, const uint32_t* __restrict__ cube,
+                                                           uint32_t* __restrict__ out, f4a* __restrict__ radiance, uint32_t row0,
+                                                           uint32_t row1)
+{
+    __shared__ float s_box[4][6];
+    __shared__ uint32_t s_mask[kMaxPointLights / 32];
+    uint32_t bx, by;
+    tile_origin<0>(bx, by);
+    const uint32_t x = bx * 64u + (threadIdx.x & 63u);
+    const uint32_t y = row0 + by * 4u + (threadIdx.x >> 6);
+    const bool inFrame = (x < P.W) && (y < row1);
+    const uint32_t idx = inFrame ? y * P.W + x : 0u;
+    const bool covered = inFrame && ((depth[idx] & 0x00FFFFFFu) < 0x00FFFFFFu);
+    f4a G0{ 0, 0, 0, 0 };
+    if (covered) G0 = g0[idx];
+
+    // 1. tile bounding box of the covered pixels' world positions
+    const float big = 3.0e38f;
+    float lo[3] = { covered ? G0.x : big, covered ? G0.y : big, covered ? G0.z : big };
+    float hi[3] = { covered ? G0.x : -big, covered ? G0.y : -big, covered ? G0.z : -big };
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            lo[c] = __builtin_fminf(lo[c], __shfl_xor(lo[c], off));
+            hi[c] = __builtin_fmaxf(hi[c], __shfl_xor(hi[c], off));
+        }
+    const uint32_t wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63u) == 0) { for (int c = 0; c < 3; ++c) { s_box[wave][c] = lo[c]; s_box[wave][3 + c] = hi[c]; } }
+    if (threadIdx.x < kMaxPointLights / 32) s_mask[threadIdx.x] = 0u;
+    __syncthreads();
+    float blo[3], bhi[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        blo[c] = __builtin_fminf(__builtin_fminf(s_box[0][c], s_box[1][c]), __builtin_fminf(s_box[2][c], s_box[3][c]));
+        bhi[c] = __builtin_fmaxf(__builtin_fmaxf(s_box[0][3 + c], s_box[1][3 + c]), __builtin_fmaxf(s_box[2][3 + c], s_box[3][3 + c]));
+    }
+    // 2. cull: light l touches the tile if dist(Position, box) <= FalloffEnd (inflated: the per-pixel test is the exact one)
+    const bool anyCovered = blo[0] <= bhi[0];
+    if (anyCovered)
+        for (uint32_t l = threadIdx.x; l < P.numPointLights; l += 256u) {
+            const crychic_light L = P.pointLights[l];
+            float d2 = 0.0f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const float p = L.Position[c];
+                const float e = __builtin_fmaxf(__builtin_fmaxf(blo[c] - p, p - bhi[c]), 0.0f);
+                d2 += e * e;
+            }
+            const float r = L.FalloffEnd * 1.0001f + 1.0e-3f;
+            if (d2 <= r * r) atomicOr(&s_mask[l >> 5], 1u << (l & 31u));
+        }
+    __syncthreads();
+    if (!inFrame) return;
+
+    // 3. shade
+    f4 lit;
+    if (covered) {
+        auto culled = [&](f3 pos, f3 albedo, float roughness, float metalness, f3 normal, f3 view, f3& result) {
+            const uint32_t words = (P.numPointLights + 31u) >> 5;
+            for (uint32_t w = 0; w < words; ++w) {
+                uint32_t m = s_mask[w];
+                while (m) {
+                    const uint32_t b = (uint32_t)__builtin_ctz(m);
+                    m &= m - 1u;
+                    pbr_point_light(P.pointLights[w * 32u + b], pos, albedo, roughness, metalness, normal, view, result);
+                }
+            }
+        };
+        lit = light_pixel<ZERO_RADIUS>(P, G0, g1[idx], g2[idx], ambient, cube, culled);
+    } else if (P.flags & CRYCHIC_LIGHT_SKY) {
+        lit = sky_pixel(P, cube, x, y);
+    } else {
+        lit = f4{ 0.690196097f, 0.768627524f, 0.870588303f, 1.0f };
+    }
+    if (radiance) radiance[idx] = f4a{ lit.x, lit.y, lit.z, lit.w };
+    out[idx] = pack_rgba8(lit);
+}
+
 // ---- launchers ---------------------------------------------------------------------------------------------------
 static inline dim3 grid_for(uint32_t width, uint32_t rows, uint32_t rows_per_block = 4u)
 {
@@ -246,6 +334,15 @@ hipError_t launch_light(const LightParams& P, const float* g0, const float* g1, 
 {
     if (rows == 0) return hipSuccess;
     const dim3 grid = grid_for(P.W, rows);
+    if (P.numPointLights) {
+        if (P.pcfSearchRadius == 0.0f)
+            hipLaunchKernelGGL(light_points_kernel<true>, grid, dim3(256), 0, stream, P, (const f4a*)g0, (const f4a*)g1, (const f4a*)g2,
+                               depth, ambient, (const uint32_t*)cube, (uint32_t*)out, (f4a*)radiance, row0, row0 + rows);
+        else
+            hipLaunchKernelGGL(light_points_kernel<false>, grid, dim3(256), 0, stream, P, (const f4a*)g0, (const f4a*)g1, (const f4a*)g2,
+                               depth, ambient, (const uint32_t*)cube, (uint32_t*)out, (f4a*)radiance, row0, row0 + rows);
+        return hipGetLastError();
+    }
     if (P.pcfSearchRadius == 0.0f)
         hipLaunchKernelGGL(light_kernel<true>, grid, dim3(256), 0, stream, P, (const f4a*)g0, (const f4a*)g1,
                            (const f4a*)g2, depth, ambient, (const uint32_t*)cube, (uint32_t*)out, (f4a*)radiance, row0,

@@ -23,7 +23,11 @@ struct LightParams {
     uint32_t W, H;
     int numDirLights;
     uint32_t flags;
+    const crychic_light* pointLights;   // extension (BASELINE configs[4]): NUM_POINT_LIGHTS lights in a device buffer
+    uint32_t numPointLights;
 };
+
+constexpr uint32_t kMaxPointLights = 1024;   // tile masks live in LDS: 32 words
 
 // Common.hlsl:167-171 (noise is a scalar broadcast, so abs(noise.x + noise.y) * 0.5 == noise)
 CRY_HD float nrand(float u, float v)
@@ -93,11 +97,12 @@ CRY_HD float pow5(float x) { float x2 = x * x, x4 = x2 * x2; return x4 * x; }
 
 #define CRY_PBR_PI 3.1415926f  // PBR.hlsl:2
 
-// One directional light of PBRShading (PBR.hlsl:99-106) with GetPBRDesc (:72-88) and GetBRDF (:45-70).
-CRY_HD void pbr_dir_light(const crychic_light& L, f3 albedo, float roughness, float metalness, f3 normal, f3 view,
-                          float shadow, f3& result)
+// GetPBRDesc (PBR.hlsl:72-88) + GetBRDF (:45-70) for light direction `lightDir`; adds scale * brdf * (strength * nDotl * att)
+// in the shader's association order.  Directional lights: att = 1 is skipped (POINT = false).
+template <bool POINT>
+CRY_HD void pbr_light(f3 lightDir, const float* strength, float att, f3 albedo, float roughness, float metalness, f3 normal,
+                      f3 view, float scale, f3& result)
 {
-    const f3 lightDir{ -L.Direction[0], -L.Direction[1], -L.Direction[2] };
     const f3 halfVec = normalize3(f3{ view.x + lightDir.x, view.y + lightDir.y, view.z + lightDir.z });
     const float hDotv = maxnn(dot3(halfVec, view), 0.001f);
     const float nDotl = maxnn(dot3(normal, lightDir), 0.001f);
@@ -114,7 +119,6 @@ CRY_HD void pbr_dir_light(const crychic_light& L, f3 albedo, float roughness, fl
     // GeometrySmith :29-38 (true nDotv)
     const float k = 0.125f * (roughness + 1.0f) * (roughness + 1.0f);
     const float G = (nDotv / (nDotv * (1.0f - k) + k)) * (nDotl / (nDotl * (1.0f - k) + k));
-    const float s5 = pow5(shadow);  // :105
     const float denom = nDotl * nDotvQ;
     const float invPi = 1.0f / CRY_PBR_PI;
     const float oneMinusMetal = 1.0f - metalness;
@@ -130,10 +134,32 @@ CRY_HD void pbr_dir_light(const crychic_light& L, f3 albedo, float roughness, fl
         const float fd = alb[ch] * invPi;
         const float kd = (1.0f - F) * oneMinusMetal;
         const float brdf = kd * fd + F * fs;  // ks = F (Q4)
-        const float irradiance = L.Strength[ch] * nDotl;
-        res[ch] += s5 * brdf * irradiance;
+        float lightStrength = strength[ch] * nDotl;           // :104 / :118
+        if (POINT) lightStrength = lightStrength * att;       // :120
+        res[ch] += scale * brdf * lightStrength;              // :105 / :122
     }
     result = f3{ res[0], res[1], res[2] };
+}
+
+// One directional light of PBRShading (PBR.hlsl:99-106).
+CRY_HD void pbr_dir_light(const crychic_light& L, f3 albedo, float roughness, float metalness, f3 normal, f3 view,
+                          float shadow, f3& result)
+{
+    pbr_light<false>(f3{ -L.Direction[0], -L.Direction[1], -L.Direction[2] }, L.Strength, 1.0f, albedo, roughness, metalness, normal,
+                     view, pow5(shadow), result);
+}
+
+// Point light, BUILD-DEFINED EXTENSION: the reference's branch (PBR.hlsl:109-124) is dead code; enabled as evidently
+// intended -- range test d > FalloffEnd (LightingUtil.hlsl:104-105), l /= d, linear attenuation, shadowFactor 1.
+CRY_HD void pbr_point_light(const crychic_light& L, f3 pos, f3 albedo, float roughness, float metalness, f3 normal, f3 view,
+                            f3& result)
+{
+    const f3 l{ L.Position[0] - pos.x, L.Position[1] - pos.y, L.Position[2] - pos.z };
+    const float d = __builtin_sqrtf(dot3(l, l));
+    if (d > L.FalloffEnd) return;
+    const f3 ln{ l.x / d, l.y / d, l.z / d };
+    const float att = saturate((L.FalloffEnd - d) / (L.FalloffEnd - L.FalloffStart));
+    pbr_light<true>(ln, L.Strength, att, albedo, roughness, metalness, normal, view, 1.0f, result);
 }
 
 // TextureCube.Sample(gsamLinearWrap, r): D3D major-axis face selection (ties x >= y >= z), bilinear inside the
@@ -176,9 +202,21 @@ CRY_HD float ambient_linear_clamp(const uint16_t* __restrict__ a, uint32_t w2, u
 }
 
 // DeferredShading.hlsl:23-101 for one covered pixel.
-template <bool ZERO_RADIUS>
+struct NoPointLights {
+    CRY_HD void operator()(f3, f3, float, float, f3, f3, f3&) const {}
+};
+// Iterates every point light of the buffer (what the oracle does); the tiled kernel substitutes a culled iteration.
+struct AllPointLights {
+    const crychic_light* lights; uint32_t n;
+    CRY_HD void operator()(f3 pos, f3 albedo, float roughness, float metalness, f3 normal, f3 view, f3& result) const
+    {
+        for (uint32_t i = 0; i < n; ++i) pbr_point_light(lights[i], pos, albedo, roughness, metalness, normal, view, result);
+    }
+};
+
+template <bool ZERO_RADIUS, class PointLights = NoPointLights>
 CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16_t* __restrict__ ambient,
-                      const uint32_t* __restrict__ cube)
+                      const uint32_t* __restrict__ cube, PointLights pointLights = PointLights())
 {
     const f3 posW{ G0.x, G0.y, G0.z };                         // GBuffer.hlsl:37-41
     const float metalness = G0.w;
@@ -235,6 +273,7 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
     f3 direct{ 0.0f, 0.0f, 0.0f };
     for (int i = 0; i < P.numDirLights; ++i)                    // PBR.hlsl:99-106; shadowFactors[i>0] == 1 (:46-51)
         pbr_dir_light(P.Lights[i], albedo, roughness, metalness, normalW, view, i == 0 ? shadow0 : 1.0f, direct);
+    pointLights(posW, albedo, roughness, metalness, normalW, view, direct);   // extension; a no-op in the reference configuration
 
     const float invGamma = 1.0f / 2.2f;
     f4 lit;

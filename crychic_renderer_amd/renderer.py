@@ -164,6 +164,7 @@ class Crychic:
         self.numDirLights = 1        # NUM_DIR_LIGHTS of the deferred shader, Common.hlsl:6-8
         self.pcfSearchRadius = lib.crychic_pcf_search_radius(shadow_dim, 1)  # Common.hlsl:305 as written
         self.flags = 0
+        self.mPointLights = None     # extension: torch uint8 tensor holding an array of Light structs (48 B each)
         self._desc = None
 
     def load_scene(self, planes):
@@ -197,13 +198,17 @@ class Crychic:
         f.ambient1_dev = self.mSsao.mAmbientMap1.data_ptr()
         f.edge_dev = self.mSsao.mEdge.data_ptr()
         f.out_rgba8_dev = self.mBackBuffer.data_ptr()
+        if self.mPointLights is not None:
+            f.point_lights_dev = self.mPointLights.data_ptr()
+            f.numPointLights = self.mPointLights.numel() // 48
         return f
 
     def Draw(self, row0=0, rows=None):  # CRYCHIC.cpp:172-306 (hot part)
         # The descriptor only changes when a plane is re-allocated or a knob is turned: keep it across frames so the
         # per-frame host cost is one FFI call (matters once a strip takes tens of microseconds on 8 GPUs).
         key = (row0, rows, self.mBackBuffer.data_ptr(), self.mSsao.mAmbientMap0.data_ptr(), self.mDepthStencilBuffer.data_ptr(),
-               self.mDeferred.mGBuffer[0].data_ptr(), self.blurCount, self.numDirLights, self.pcfSearchRadius, self.flags)
+               self.mDeferred.mGBuffer[0].data_ptr(), self.blurCount, self.numDirLights, self.pcfSearchRadius, self.flags,
+               0 if self.mPointLights is None else self.mPointLights.data_ptr())
         if self._desc is None:
             self._desc = {}
         f = self._desc.get(key)
@@ -213,6 +218,16 @@ class Crychic:
             f = self._desc[key] = self.frame_desc(row0, rows)
         check(lib.crychic_draw_hot_path(self.ctx.handle, C.byref(self.mSsaoCB), C.byref(self.mMainPassCB), C.byref(f),
                                         _stream(self.ctx.device)))
+
+    def set_point_lights(self, lights):
+        """Extension: `lights` is a ctypes array of Light (or None); copied to the device."""
+        if lights is None or len(lights) == 0:
+            self.mPointLights = None
+        else:
+            import numpy as np
+            host = np.frombuffer(bytes(lights), dtype=np.uint8).copy()
+            self.mPointLights = torch.from_numpy(host).to(self.ctx.device)
+        self._desc = None
 
     def set_profiling(self, enabled):
         check(lib.crychic_ctx_set_profiling(self.ctx.handle, 1 if enabled else 0))

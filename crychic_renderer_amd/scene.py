@@ -269,3 +269,19 @@ def make_scene(W, H, shadow_dim=4096, cube_dim=256, device="cpu", consts=None):
     planes["out"] = torch.zeros((H, W, 4), device=dev, dtype=torch.uint8)
     planes["consts"] = consts
     return planes
+
+
+def point_light_grid(n=8, y=3.0, falloff_start=1.0, falloff_end=10.0, strength=1.0, extent=24.5):
+    """BASELINE configs[4] lights: n x n point lights on a regular grid at height y over the box field,
+    linear falloff start..end, white strength -- seed-free.  Returns a ctypes array of Light."""
+    from ._lib import Light
+    arr = (Light * (n * n))()
+    for i in range(n):
+        for j in range(n):
+            L = arr[i * n + j]
+            L.Strength[:] = (strength, strength, strength)
+            L.FalloffStart, L.FalloffEnd = falloff_start, falloff_end
+            L.Direction[:] = (0.0, -1.0, 0.0)
+            L.Position[:] = (-extent + 2.0 * extent * i / (n - 1), y, -extent + 2.0 * extent * j / (n - 1))
+            L.SpotPower = 64.0
+    return arr

@@ -190,6 +190,18 @@ int crychic_deferred_light(crychic_ctx* ctx, const crychic_pass_constants* cb, c
                            float* radiance_out_dev, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows,
                            int numDirLights, float pcfSearchRadius, uint32_t flags, void* stream);
 
+/* crychic_deferred_light plus `numPointLights` (<= 1024) point lights read from a device array of crychic_light
+ * (Strength, FalloffStart, FalloffEnd, Position).  BUILD-DEFINED EXTENSION: the reference's NUM_POINT_LIGHTS branch
+ * (PBR.hlsl:109-124) is dead code; it is enabled here as evidently intended (range test, l /= d, linear attenuation,
+ * shadow factor 1) with per-tile light culling in LDS.  Parity is against this repo's oracle only. */
+int crychic_deferred_light_points(crychic_ctx* ctx, const crychic_pass_constants* cb, const float* g0_dev,
+                                  const float* g1_dev, const float* g2_dev, const uint32_t* depth_dev,
+                                  const uint16_t* ambient_dev, const uint32_t* const shadow_dev[4], uint32_t shadowDim,
+                                  const uint8_t* cube_dev, uint32_t cubeDim, uint8_t* out_rgba8_dev,
+                                  float* radiance_out_dev, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows,
+                                  int numDirLights, float pcfSearchRadius, uint32_t flags,
+                                  const crychic_light* point_lights_dev, uint32_t numPointLights, void* stream);
+
 /* ---- whole hot path of CRYCHIC::Draw (CRYCHIC.cpp:220-221 + 238-279) -------------------------------------- */
 typedef struct crychic_frame_desc {
     uint32_t W, H;
@@ -212,6 +224,10 @@ typedef struct crychic_frame_desc {
     uint16_t* ambient1_dev;
     void* edge_dev;
     uint8_t* out_rgba8_dev;
+    /* Extension (BASELINE configs[4], parity vs this repo's oracle only): point lights evaluated after the directional
+     * ones, with tiled light culling; NULL / 0 = the reference configuration. */
+    const crychic_light* point_lights_dev;
+    uint32_t numPointLights;
 } crychic_frame_desc;
 
 int crychic_draw_hot_path(crychic_ctx* ctx, const crychic_ssao_constants* ssaoCB,

@@ -212,6 +212,14 @@ int or_load_mesh_text(const char* path, or_vertex* v, uint32_t vcap, uint32_t* i
                       uint32_t* nIdx);
 uint16_t or_float_to_half(float f);
 
+/* or_deferred_light plus NUM_POINT_LIGHTS point lights from a separate buffer: BUILD-DEFINED EXTENSION for BASELINE
+ * configs[4] (the reference's point-light branch, PBR.hlsl:109-124, is dead code); see or_light.c. */
+void or_deferred_light_points(const or_pass_constants* cb, const float* g0, const float* g1, const float* g2,
+                              const uint32_t* depth, const uint16_t* ambient, const uint32_t* const shadow[4],
+                              uint32_t shadowDim, const uint8_t* cube, uint32_t cubeDim, uint8_t* out_rgba8,
+                              float* radiance_out, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows,
+                              int numDirLights, float pcfSearchRadius, int sky, const or_light* pointLights, uint32_t numPointLights);
+
 /* Exposed pieces (unit-tested individually). */
 void  or_eval_array(int kind, size_t n, const float* in, const float* in2, float* out);
 float or_det_sinf(float x);

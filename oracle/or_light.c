@@ -81,10 +81,9 @@ static inline float ndf_ggx(const float n[3], const float h[3], float a)
 static inline float geometry_schlick_ggx(float nDotvec, float k) { return nDotvec / (nDotvec * (1.0f - k) + k); }
 
 /* One directional light: PBR.hlsl:72-88 (GetPBRDesc), :45-70 (GetBRDF), :99-106 (PBRShading loop body). */
-static void pbr_dir_light(const or_light* L, const float albedo[3], float roughness, float metalness,
-                          const float normal[3], const float view[3], float shadow, float result[3])
+static void pbr_light(const float lightDir[3], const float strength[3], const float albedo[3], float roughness, float metalness,
+                      const float normal[3], const float view[3], float shadowTerm, float result[3])
 {
-    float lightDir[3] = { -L->Direction[0], -L->Direction[1], -L->Direction[2] };
     float vl[3] = { view[0] + lightDir[0], view[1] + lightDir[1], view[2] + lightDir[2] }, halfVec[3];
     or_normalize3(vl, halfVec);
     float hDotv = or_max0(or_dot3(halfVec, view), 0.001f);
@@ -96,7 +95,7 @@ static void pbr_dir_light(const or_light* L, const float albedo[3], float roughn
     float fr = pow5(or_saturate(1.0f - nDotvQ)); /* FresnelSchlick :40-43 */
     float k = 0.125f * (roughness + 1.0f) * (roughness + 1.0f);
     float G = geometry_schlick_ggx(nDotv, k) * geometry_schlick_ggx(nDotl, k); /* true nDotv :29-38 */
-    float s5 = pow5(shadow);                 /* pow(shadowFactor[i], 5.0f) :105 */
+    float s5 = shadowTerm;
     for (int c = 0; c < 3; ++c) {
         float f0 = or_lerp(0.04f, albedo[c], metalness);
         float F = f0 + (1.0f - f0) * fr;
@@ -106,8 +105,52 @@ static void pbr_dir_light(const or_light* L, const float albedo[3], float roughn
         float ks = F;                         /* quirk Q4: F applied twice */
         float kd = (1.0f - F) * (1.0f - metalness);
         float brdf = kd * fd + ks * fs;
-        float irradiance = L->Strength[c] * nDotl;
+        float irradiance = strength[c] * nDotl;
         result[c] += s5 * brdf * irradiance;
+    }
+}
+
+static void pbr_dir_light(const or_light* L, const float albedo[3], float roughness, float metalness,
+                          const float normal[3], const float view[3], float shadow, float result[3])
+{
+    float lightDir[3] = { -L->Direction[0], -L->Direction[1], -L->Direction[2] };   /* PBR.hlsl:101 */
+    pbr_light(lightDir, L->Strength, albedo, roughness, metalness, normal, view, pow5(shadow) /* :105 */, result);
+}
+
+/* BUILD-DEFINED EXTENSION (BASELINE configs[4], parity unpinned): the reference's point-light branch (PBR.hlsl:109-124) does
+ * not compile (`pbr.nDotl`, :117) and its accumulation is commented out (:122).  The extension enables it as evidently
+ * intended: l = Position - pos, d = |l|, range test d > FalloffEnd -> no contribution (LightingUtil.hlsl:104-105 and the
+ * spot branch :133-137), l /= d, BRDF as for directional lights, strength * nDotl * CalcAttenuation, shadowFactor 1. */
+static void pbr_point_light(const or_light* L, const float pos[3], const float albedo[3], float roughness, float metalness,
+                            const float normal[3], const float view[3], float result[3])
+{
+    float l[3] = { L->Position[0] - pos[0], L->Position[1] - pos[1], L->Position[2] - pos[2] };
+    float d = sqrtf(or_dot3(l, l));
+    if (d > L->FalloffEnd) return;
+    float ln[3] = { l[0] / d, l[1] / d, l[2] / d };
+    float att = or_saturate((L->FalloffEnd - d) / (L->FalloffEnd - L->FalloffStart));   /* CalcAttenuation, LightingUtil.hlsl:44-48 */
+    /* GetPBRDesc / GetBRDF exactly as for a directional light (PBR.hlsl:72-88, 45-70), with l as the light direction */
+    float vl[3] = { view[0] + ln[0], view[1] + ln[1], view[2] + ln[2] }, halfVec[3];
+    or_normalize3(vl, halfVec);
+    float hDotv = or_max0(or_dot3(halfVec, view), 0.001f);
+    float nDotl = or_max0(or_dot3(normal, ln), 0.001f);
+    float nDotv = or_max0(or_dot3(normal, view), 0.001f);
+    float nDotvQ = hDotv;
+    float D = ndf_ggx(normal, halfVec, roughness);
+    float fr = pow5(or_saturate(1.0f - nDotvQ));
+    float k = 0.125f * (roughness + 1.0f) * (roughness + 1.0f);
+    float G = geometry_schlick_ggx(nDotv, k) * geometry_schlick_ggx(nDotl, k);
+    for (int c = 0; c < 3; ++c) {
+        float f0 = or_lerp(0.04f, albedo[c], metalness);
+        float F = f0 + (1.0f - f0) * fr;
+        float fs = 0.25f * D * G * F;
+        fs = fs / (nDotl * nDotvQ);
+        float fd = albedo[c] * (1.0f / OR_PI);
+        float kd = (1.0f - F) * (1.0f - metalness);
+        float brdf = kd * fd + F * fs;
+        float lightStrength = L->Strength[c] * nDotl;      /* PBR.hlsl:118 */
+        lightStrength = lightStrength * att;               /* :120 */
+        result[c] += 1.0f * brdf * lightStrength;          /* :122 with shadowFactor[i] = 1 */
     }
 }
 
@@ -119,7 +162,7 @@ static void cube4(const uint8_t* cube, uint32_t dim, const float dir[3], float r
 static void light_pixel(const or_pass_constants* cb, const float* g0, const float* g1, const float* g2,
                         const uint16_t* ambient, const uint32_t* const shadow[4], uint32_t shadowDim,
                         const uint8_t* cube, uint32_t cubeDim, uint32_t W, uint32_t H, size_t idx,
-                        int numDirLights, float pcfRadius, float lit[4])
+                        int numDirLights, float pcfRadius, const or_light* pointLights, uint32_t numPointLights, float lit[4])
 {
     /* DeferredShading.hlsl:25-30: the anisotropic-wrap fetch at exact texel centres is the texel itself. */
     const float* G0 = g0 + idx * 4; const float* G1 = g1 + idx * 4; const float* G2 = g2 + idx * 4;
@@ -177,6 +220,8 @@ static void light_pixel(const or_pass_constants* cb, const float* g0, const floa
     float direct[3] = { 0.0f, 0.0f, 0.0f };
     for (int i = 0; i < numDirLights; ++i)                            /* PBR.hlsl:99-106; NUM_DIR_LIGHTS (Q6) */
         pbr_dir_light(&cb->Lights[i], albedo, roughness, metalness, normalW, view, shadowFactors[i], direct);
+    for (uint32_t i = 0; i < numPointLights; ++i)                     /* extension: NUM_POINT_LIGHTS lights from a separate buffer */
+        pbr_point_light(&pointLights[i], posW, albedo, roughness, metalness, normalW, view, direct);
     for (int c = 0; c < 3; ++c) {
         float d = direct[c] / (direct[c] + 1.0f);                     /* :89 */
         d = or_det_powf_(d, 1.0f / 2.2f);                             /* :90 */
@@ -218,6 +263,16 @@ void or_deferred_light(const or_pass_constants* cb, const float* g0, const float
                        float* radiance_out, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows,
                        int numDirLights, float pcfSearchRadius, int sky)
 {
+    or_deferred_light_points(cb, g0, g1, g2, depth, ambient, shadow, shadowDim, cube, cubeDim, out_rgba8, radiance_out, W, H, row0, rows,
+                             numDirLights, pcfSearchRadius, sky, NULL, 0);
+}
+
+void or_deferred_light_points(const or_pass_constants* cb, const float* g0, const float* g1, const float* g2,
+                              const uint32_t* depth, const uint16_t* ambient, const uint32_t* const shadow[4],
+                              uint32_t shadowDim, const uint8_t* cube, uint32_t cubeDim, uint8_t* out_rgba8,
+                              float* radiance_out, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows,
+                              int numDirLights, float pcfSearchRadius, int sky, const or_light* pointLights, uint32_t numPointLights)
+{
     uint32_t row1 = row0 + rows; if (row1 > H) row1 = H;
     /* Colors::LightSteelBlue (CRYCHIC.cpp:247) */
     static const float clearColor[4] = { 0.690196097f, 0.768627524f, 0.870588303f, 1.0f };
@@ -231,7 +286,7 @@ void or_deferred_light(const or_pass_constants* cb, const float* g0, const float
              * is below the clear value. */
             if ((depth[idx] & 0x00FFFFFFu) < 0x00FFFFFFu)
                 light_pixel(cb, g0, g1, g2, ambient, shadow, shadowDim, cube, cubeDim, W, H, idx, numDirLights,
-                            pcfSearchRadius, lit);
+                            pcfSearchRadius, pointLights, numPointLights, lit);
             else if (sky)
                 sky_pixel(cb, cube, cubeDim, W, H, x, (uint32_t)y, lit);
             else

@@ -106,7 +106,8 @@ void hs_blur_mode(const crychic_ssao_constants* cb, void* edge_base, const uint1
 void hs_light(const crychic_pass_constants* cb, const float* g0, const float* g1, const float* g2,
               const uint32_t* depth, const uint16_t* ambient, const uint32_t* const shadow[4], uint32_t shadowDim,
               const uint8_t* cube, uint32_t cubeDim, uint8_t* out, float* radiance, uint32_t W, uint32_t H,
-              uint32_t row0, uint32_t rows, int numDirLights, float pcfSearchRadius, uint32_t flags)
+              uint32_t row0, uint32_t rows, int numDirLights, float pcfSearchRadius, uint32_t flags, const crychic_light* pointLights,
+              uint32_t numPointLights)
 {
     LightParams P;
     std::memcpy(P.ViewProjTex, cb->ViewProjTex, sizeof P.ViewProjTex);
@@ -119,13 +120,15 @@ void hs_light(const crychic_pass_constants* cb, const float* g0, const float* g1
     std::memcpy(P.Lights, cb->Lights, sizeof P.Lights);
     for (int i = 0; i < 4; ++i) P.shadow[i] = shadow[i];
     P.shadowDim = shadowDim; P.cubeDim = cubeDim; P.W = W; P.H = H; P.numDirLights = numDirLights; P.flags = flags;
+    P.pointLights = pointLights; P.numPointLights = numPointLights;
+    const AllPointLights pl{ pointLights, numPointLights };
     const f4a* G0 = (const f4a*)g0; const f4a* G1 = (const f4a*)g1; const f4a* G2 = (const f4a*)g2;
     for (uint32_t y = row0; y < row0 + rows; ++y)
         for (uint32_t x = 0; x < W; ++x) {
             const uint32_t idx = y * W + x;
             f4 lit;
-            if ((depth[idx] & 0x00FFFFFFu) < 0x00FFFFFFu) lit = (pcfSearchRadius == 0.0f) ? light_pixel<true>(P, G0[idx], G1[idx], G2[idx], ambient, (const uint32_t*)cube)
-                                                                                        : light_pixel<false>(P, G0[idx], G1[idx], G2[idx], ambient, (const uint32_t*)cube);
+            if ((depth[idx] & 0x00FFFFFFu) < 0x00FFFFFFu) lit = (pcfSearchRadius == 0.0f) ? light_pixel<true>(P, G0[idx], G1[idx], G2[idx], ambient, (const uint32_t*)cube, pl)
+                                                                                        : light_pixel<false>(P, G0[idx], G1[idx], G2[idx], ambient, (const uint32_t*)cube, pl);
             else if (flags & CRYCHIC_LIGHT_SKY) lit = sky_pixel(P, (const uint32_t*)cube, x, y);
             else lit = f4{ 0.690196097f, 0.768627524f, 0.870588303f, 1.0f };
             if (radiance) { radiance[4 * idx] = lit.x; radiance[4 * idx + 1] = lit.y; radiance[4 * idx + 2] = lit.z; radiance[4 * idx + 3] = lit.w; }

@@ -38,7 +38,7 @@ class HostSim:
         L.hs_blur_mode.argtypes = [vp, vp, vp, vp, u32, u32, i, i, u32, u32]
         L.hs_rasterize.restype = i
         L.hs_rasterize.argtypes = [i, vp, vp, vp, u32, vp, u32, vp, u32, u32, u32, i, f, vp, vp, vp, vp, vp]
-        L.hs_light.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp, u32, vp, vp, u32, u32, u32, u32, i, f, u32]
+        L.hs_light.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp, u32, vp, vp, u32, u32, u32, u32, i, f, u32, vp, u32]
 
     def eval_array(self, kind, a, b=None):
         a = np.ascontiguousarray(a); out = np.zeros(a.shape, dtype=np.float32)
@@ -96,7 +96,7 @@ class HostSim:
         return {"depth": depth, "normal": normal.view(np.float16) if normal is not None else None, "g0": g[0], "g1": g[1], "g2": g[2], "tris": n}
 
     def light(self, cb, g0, g1, g2, depth_u32, ambient, shadow_u32, cube_u8, num_dir_lights, pcf_radius, flags=0,
-              want_radiance=False):
+              want_radiance=False, point_lights=None):
         H, W = depth_u32.shape
         out = np.zeros((H, W, 4), dtype=np.uint8)
         rad = np.zeros((H, W, 4), dtype=np.float32) if want_radiance else None
@@ -107,7 +107,8 @@ class HostSim:
         self.lib.hs_light(C.addressof(cb), g0.ctypes.data, g1.ctypes.data, g2.ctypes.data, d.ctypes.data,
                           a.ctypes.data if a is not None else None, sh, s.shape[1], c.ctypes.data, c.shape[1],
                           out.ctypes.data, rad.ctypes.data if rad is not None else None, W, H, 0, H, num_dir_lights,
-                          pcf_radius, flags)
+                          pcf_radius, flags, C.addressof(point_lights) if point_lights is not None else None,
+                          len(point_lights) if point_lights is not None else 0)
         return (out, rad) if want_radiance else out
 
 

@@ -81,6 +81,7 @@ class Oracle:
         L.or_ssao_blur.argtypes = [vp, vp, vp, vp, vp, u32, u32, i, u32, u32]
         L.or_compute_ssao.argtypes = [vp, vp, vp, vp, u32, u32, vp, vp, i]
         L.or_deferred_light.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp, u32, vp, vp, u32, u32, u32, u32, i, f, i]
+        L.or_deferred_light_points.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp, u32, vp, vp, u32, u32, u32, u32, i, f, i, vp, u32]
         L.or_mat_perspective_fov_lh.argtypes = [f, f, f, f, vp]
         L.or_num_threads.restype = i
         L.or_set_num_threads.argtypes = [i]
@@ -127,7 +128,7 @@ class Oracle:
         return a0
 
     def deferred_light(self, cb, g0, g1, g2, depth_u32, ambient, shadow_u32, cube_u8, num_dir_lights, pcf_radius,
-                       sky=False, want_radiance=False, row0=0, rows=None):
+                       sky=False, want_radiance=False, row0=0, rows=None, point_lights=None):
         H, W = depth_u32.shape
         rows = H - row0 if rows is None else rows
         out = np.zeros((H, W, 4), dtype=np.uint8)
@@ -136,10 +137,12 @@ class Oracle:
         d = _np(depth_u32, np.uint32); s = _np(shadow_u32, np.uint32); c = _np(cube_u8, np.uint8)
         a = _np(ambient, np.uint16) if ambient is not None else None
         sh = (C.c_void_p * 4)(*[s[k].ctypes.data for k in range(4)])
-        self.lib.or_deferred_light(C.addressof(cb), g0.ctypes.data, g1.ctypes.data, g2.ctypes.data, d.ctypes.data,
-                                   a.ctypes.data if a is not None else None, sh, s.shape[1], c.ctypes.data, c.shape[1],
-                                   out.ctypes.data, rad.ctypes.data if rad is not None else None, W, H, row0, rows,
-                                   num_dir_lights, pcf_radius, 1 if sky else 0)
+        self.lib.or_deferred_light_points(C.addressof(cb), g0.ctypes.data, g1.ctypes.data, g2.ctypes.data, d.ctypes.data,
+                                          a.ctypes.data if a is not None else None, sh, s.shape[1], c.ctypes.data, c.shape[1],
+                                          out.ctypes.data, rad.ctypes.data if rad is not None else None, W, H, row0, rows,
+                                          num_dir_lights, pcf_radius, 1 if sky else 0,
+                                          C.addressof(point_lights) if point_lights is not None else None,
+                                          len(point_lights) if point_lights is not None else 0)
         return (out, rad) if want_radiance else out
 
 
