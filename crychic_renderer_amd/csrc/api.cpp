@@ -36,7 +36,8 @@ int check_dims(uint32_t W, uint32_t H)
 {
     if (W == 0 || H == 0 || (W & 1u) || (H & 1u))
         return fail(CRYCHIC_E_INVALID_ARG, "frame size %ux%u must be non-zero and even (half-res maps are W/2 x H/2)", W, H);
-    if ((uint64_t)W * H > 0x7FFFFFFFull) return fail(CRYCHIC_E_UNSUPPORTED, "frame %ux%u exceeds 2^31 pixels", W, H);
+    if ((uint64_t)W * H > (1ull << 28) || W >= (1u << 20) || H >= (1u << 20))
+        return fail(CRYCHIC_E_UNSUPPORTED, "frame %ux%u exceeds 2^28 pixels (32-bit plane offsets)", W, H);
     return 0;
 }
 
@@ -98,7 +99,8 @@ int fill_light_params(cry::LightParams& P, const crychic_pass_constants* cb, con
 {
     if (numDirLights < 0 || numDirLights > CRYCHIC_MAX_LIGHTS)
         return fail(CRYCHIC_E_INVALID_ARG, "numDirLights %d outside [0,%d]", numDirLights, CRYCHIC_MAX_LIGHTS);
-    if (shadowDim == 0 || cubeDim == 0) return fail(CRYCHIC_E_INVALID_ARG, "shadowDim/cubeDim must be non-zero");
+    if (shadowDim < 2 || cubeDim < 2 || shadowDim > 16384 || cubeDim > 8192)
+        return fail(CRYCHIC_E_INVALID_ARG, "shadowDim %u / cubeDim %u outside [2, 16384] / [2, 8192]", shadowDim, cubeDim);
     if (!(pcfSearchRadius >= 0.0f)) return fail(CRYCHIC_E_INVALID_ARG, "pcfSearchRadius must be >= 0");
     memcpy(P.ViewProjTex, cb->ViewProjTex, sizeof P.ViewProjTex);
     memcpy(P.ShadowTransforms, cb->ShadowTransforms, sizeof P.ShadowTransforms);  // cascades 0..3

@@ -48,6 +48,26 @@ CRY_HD float mulcol(float x, float y, float z, float w, const float* col)
     return ((x * col[0] + y * col[1]) + z * col[2]) + w * col[3];
 }
 
+// ---- two-wide packed fp32 ---------------------------------------------------------------------------------------
+// On gfx950 a wave64 VALU instruction occupies its SIMD for 4 cycles whether it is v_mul_f32 or v_pk_mul_f32 (measured:
+// 4.1 cycles per VALU instruction in the VALU-bound SSAO loop), and the packed forms do two lanes' worth of IEEE-754
+// work per instruction.  The tap loops therefore process independent work items in pairs: `v2f` arithmetic compiles to
+// v_pk_mul_f32 / v_pk_add_f32 (never fused: -ffp-contract=off), each lane bit-identical to the scalar expression.
+typedef float v2f __attribute__((ext_vector_type(2)));
+typedef int v2i __attribute__((ext_vector_type(2)));
+
+CRY_HD v2f splat(float a) { return v2f{ a, a }; }
+CRY_HD v2f select2(v2i m, v2f a, v2f b) { return m ? a : b; }          // per lane: mask all-ones -> a
+CRY_HD v2f saturate2(v2f x) { return select2(x > 0.0f, select2(x < 1.0f, x, splat(1.0f)), splat(0.0f)); }   // NaN -> 0
+CRY_HD v2f max0_2(v2f x) { return select2(x > 0.0f, x, splat(0.0f)); }  // HLSL max(x, 0): NaN -> 0
+CRY_HD v2f sign2(v2f x) { return select2(x > 0.0f, splat(1.0f), splat(0.0f)) - select2(x < 0.0f, splat(1.0f), splat(0.0f)); }
+CRY_HD v2f floor2(v2f x) { return v2f{ __builtin_floorf(x.x), __builtin_floorf(x.y) }; }
+CRY_HD v2f sqrt2(v2f x) { return v2f{ __builtin_sqrtf(x.x), __builtin_sqrtf(x.y) }; }
+CRY_HD v2f lerp2(v2f a, v2f b, v2f t) { return a + t * (b - a); }
+struct f3x2 { v2f x, y, z; };                                          // two 3-vectors, component-packed
+CRY_HD v2f dot3x2(f3x2 a, f3x2 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+CRY_HD f3x2 splat3(f3 a) { return f3x2{ splat(a.x), splat(a.y), splat(a.z) }; }
+
 // ---- format decoders -------------------------------------------------------------------------------
 // D24 -> float == (float)u / 16777215.0f for every u in [0, 2^24): q = u * 2^-24 is exact and the quotient
 // is q * (1 + 2^-24 + ...), i.e. q plus a correction strictly between 0.5 and 1 ulp(q), so the correctly
@@ -188,32 +208,51 @@ CRY_HD float bilerp(float t00, float t10, float t01, float t11, float fx, float 
 }
 CRY_HD int clampi(int i, int lo, int hi) { return i < lo ? lo : (i > hi ? hi : i); }
 
+// Plane addressing.  Texel indices are combined with 24-bit multiplies (full-rate v_mul_u32_u24; rows and widths are
+// far below 2^24) into 32-bit BYTE offsets from a wave-uniform base, which the compiler turns into
+// `global_load ... v_off, s[base]` (SGPR base + 32-bit VGPR offset) instead of quarter-rate 64-bit pointer arithmetic
+// (v_mul_lo_u32 + v_lshl_add_u64 per texel: measured 4.8 cycles per VALU instruction in the SSAO tap loop before this).
+// Every plane the kernels gather from is smaller than 4 GiB (checked at the API).
+CRY_HD uint32_t mul24(uint32_t a, uint32_t b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umul24(a, b);
+#else
+    return a * b;
+#endif
+}
+template <class T>
+CRY_HD T load_at(const void* __restrict__ base, uint32_t byteOffset)
+{
+    T v;
+    __builtin_memcpy(&v, (const char*)base + byteOffset, sizeof(T));
+    return v;
+}
+
 // Two horizontally adjacent texels of a row-major 32-bit plane with one 8-byte load (the address is only 4-byte
-// aligned: gfx950 global loads allow that).  `row` points at texel 0 of an in-range row, width >= 2.
+// aligned: gfx950 global loads allow that).  `row` is an in-range row index, width >= 2.
 struct TexelPair { uint32_t a, b; };
 struct RawPair { uint32_t lo, hi; };
-CRY_HD RawPair load_pair(const uint32_t* __restrict__ p)
+CRY_HD RawPair load_pair(const uint32_t* __restrict__ plane, uint32_t texelIndex)
 {
-    RawPair v;
-    __builtin_memcpy(&v, p, 8);
-    return v;
+    return load_at<RawPair>(plane, texelIndex * 4u);
 }
 // BORDER / range-checked variant: returns texels i0 and i0+1 where they exist (the caller replaces out-of-range
 // ones by the border value; what is returned for them is unspecified but always read from valid memory).
-CRY_HD TexelPair pair_at(const uint32_t* __restrict__ row, uint32_t width, int i0)
+CRY_HD TexelPair pair_at(const uint32_t* __restrict__ plane, uint32_t row, uint32_t width, int i0)
 {
     const int cx = clampi(i0, 0, (int)width - 2);
-    const RawPair v = load_pair(row + cx);
+    const RawPair v = load_pair(plane, mul24(row, width) + (uint32_t)cx);
     TexelPair t;
     t.a = (i0 == cx) ? v.lo : v.hi;      // i0 == width-1 -> hi
     t.b = (i0 + 1 == cx) ? v.lo : v.hi;  // i0 == -1      -> lo
     return t;
 }
 // CLAMP variant: texels clamp(i0) and clamp(i0+1).
-CRY_HD TexelPair pair_at_clamped(const uint32_t* __restrict__ row, uint32_t width, int i0)
+CRY_HD TexelPair pair_at_clamped(const uint32_t* __restrict__ plane, uint32_t row, uint32_t width, int i0)
 {
     const int cx = clampi(i0, 0, (int)width - 2);
-    const RawPair v = load_pair(row + cx);
+    const RawPair v = load_pair(plane, mul24(row, width) + (uint32_t)cx);
     TexelPair t;
     t.a = (i0 > (int)width - 2) ? v.hi : v.lo;
     t.b = (i0 < 0) ? v.lo : v.hi;

@@ -43,8 +43,8 @@ CRY_HD float shadow_cmp_linear(const uint32_t* __restrict__ s, uint32_t dim, flo
 {
     const Bilin b = bilinear_setup(u, v, dim, dim);
     const uint32_t r0 = (uint32_t)clampi(b.j0, 0, (int)dim - 1), r1 = (uint32_t)clampi(b.j0 + 1, 0, (int)dim - 1);
-    const TexelPair p0 = pair_at(s + r0 * dim, dim, b.i0);   // one 8-byte load per footprint row
-    const TexelPair p1 = pair_at(s + r1 * dim, dim, b.i0);
+    const TexelPair p0 = pair_at(s, r0, dim, b.i0);   // one 8-byte load per footprint row
+    const TexelPair p1 = pair_at(s, r1, dim, b.i0);
     const bool xa = (uint32_t)b.i0 < dim, xb = (uint32_t)(b.i0 + 1) < dim;
     const bool y0 = (uint32_t)b.j0 < dim, y1 = (uint32_t)(b.j0 + 1) < dim;
     // the BORDER colour 0 is D24 0: select on the integer texel, then decode unconditionally
@@ -175,9 +175,9 @@ CRY_HD f4 cube_linear(const uint32_t* __restrict__ cube, uint32_t dim, f3 r)
     const float v = 0.5f * (tc / ma + 1.0f);
     const Bilin b = bilinear_setup(u, v, dim, dim);
     const uint32_t y0 = (uint32_t)clampi(b.j0, 0, (int)dim - 1), y1 = (uint32_t)clampi(b.j0 + 1, 0, (int)dim - 1);
-    const uint32_t* f = cube + face * dim * dim;
-    const TexelPair p0 = pair_at_clamped(f + y0 * dim, dim, b.i0);
-    const TexelPair p1 = pair_at_clamped(f + y1 * dim, dim, b.i0);
+    const uint32_t faceRow = mul24(face, dim);   // faces are stacked: row index face*dim + y
+    const TexelPair p0 = pair_at_clamped(cube, faceRow + y0, dim, b.i0);
+    const TexelPair p1 = pair_at_clamped(cube, faceRow + y1, dim, b.i0);
     const uint32_t t00 = p0.a, t10 = p0.b, t01 = p1.a, t11 = p1.b;
     f4 o;
     o.x = bilerp(unorm8_to_float(t00 & 255u), unorm8_to_float(t10 & 255u), unorm8_to_float(t01 & 255u),
@@ -197,8 +197,9 @@ CRY_HD float ambient_linear_clamp(const uint16_t* __restrict__ a, uint32_t w2, u
     const Bilin b = bilinear_setup(u, v, w2, h2);
     const uint32_t x0 = (uint32_t)clampi(b.i0, 0, (int)w2 - 1), x1 = (uint32_t)clampi(b.i0 + 1, 0, (int)w2 - 1);
     const uint32_t y0 = (uint32_t)clampi(b.j0, 0, (int)h2 - 1), y1 = (uint32_t)clampi(b.j0 + 1, 0, (int)h2 - 1);
-    return bilerp(unorm16_to_float(a[y0 * w2 + x0]), unorm16_to_float(a[y0 * w2 + x1]),
-                  unorm16_to_float(a[y1 * w2 + x0]), unorm16_to_float(a[y1 * w2 + x1]), b.fx, b.fy);
+    const uint32_t r0 = mul24(y0, w2), r1 = mul24(y1, w2);
+    return bilerp(unorm16_to_float(load_at<uint16_t>(a, (r0 + x0) * 2u)), unorm16_to_float(load_at<uint16_t>(a, (r0 + x1) * 2u)),
+                  unorm16_to_float(load_at<uint16_t>(a, (r1 + x0) * 2u)), unorm16_to_float(load_at<uint16_t>(a, (r1 + x1) * 2u)), b.fx, b.fy);
 }
 
 // DeferredShading.hlsl:23-101 for one covered pixel.

@@ -68,7 +68,7 @@ CRY_HD float depth_texel(const uint32_t* __restrict__ depth, uint32_t W, uint32_
     // issue back to back instead of sitting in four dependent exec-masked branches.
     const bool in = ((uint32_t)x < W) && ((uint32_t)y < H);
     const uint32_t cx = (uint32_t)clampi(x, 0, (int)W - 1), cy = (uint32_t)clampi(y, 0, (int)H - 1);
-    const uint32_t t = depth[cy * W + cx];
+    const uint32_t t = load_at<uint32_t>(depth, (mul24(cy, W) + cx) * 4u);
     return d24_to_float(in ? t : 0x00FFFFFFu);
 }
 CRY_HD float depth_linear_border(const uint32_t* __restrict__ depth, uint32_t W, uint32_t H, float u, float v)
@@ -76,8 +76,8 @@ CRY_HD float depth_linear_border(const uint32_t* __restrict__ depth, uint32_t W,
     const Bilin b = bilinear_setup(u, v, W, H);
     // rows j0, j0+1: one 8-byte load each (texels i0, i0+1), fetched from clamped addresses, border selected after
     const uint32_t r0 = (uint32_t)clampi(b.j0, 0, (int)H - 1), r1 = (uint32_t)clampi(b.j0 + 1, 0, (int)H - 1);
-    const TexelPair p0 = pair_at(depth + r0 * W, W, b.i0);
-    const TexelPair p1 = pair_at(depth + r1 * W, W, b.i0);
+    const TexelPair p0 = pair_at(depth, r0, W, b.i0);
+    const TexelPair p1 = pair_at(depth, r1, W, b.i0);
     const bool xa = (uint32_t)b.i0 < W, xb = (uint32_t)(b.i0 + 1) < W;
     const bool y0 = (uint32_t)b.j0 < H, y1 = (uint32_t)(b.j0 + 1) < H;
     // the BORDER colour 1.0 is exactly D24 0xFFFFFF: select on the integer texel, then decode unconditionally
@@ -93,8 +93,9 @@ CRY_HD float depth_at_half_pixel(const uint32_t* __restrict__ depth, uint32_t W,
 {
     const bool in = ((uint32_t)(2 * xi) < W) & ((uint32_t)(2 * yi) < H);   // even sizes: all four in or all four out
     const uint32_t cx = (uint32_t)clampi(2 * xi, 0, (int)W - 2), cy = (uint32_t)clampi(2 * yi, 0, (int)H - 2);
-    const RawPair p0 = load_pair(depth + cy * W + cx);
-    const RawPair p1 = load_pair(depth + (cy + 1) * W + cx);
+    const uint32_t t0 = mul24(cy, W) + cx;
+    const RawPair p0 = load_pair(depth, t0);
+    const RawPair p1 = load_pair(depth, t0 + W);
     const float t00 = d24_to_float(in ? p0.lo : 0x00FFFFFFu), t10 = d24_to_float(in ? p0.hi : 0x00FFFFFFu);
     const float t01 = d24_to_float(in ? p1.lo : 0x00FFFFFFu), t11 = d24_to_float(in ? p1.hi : 0x00FFFFFFu);
     return bilerp(t00, t10, t01, t11, 0.5f, 0.5f);
@@ -106,7 +107,7 @@ CRY_HD u2 normal_texel_bits(const u2* __restrict__ normal, uint32_t W, uint32_t 
 {
     int tx = clampi(2 * xi + 1, 0, (int)W - 1);
     int ty = clampi(2 * yi + 1, 0, (int)H - 1);
-    return normal[(uint32_t)ty * W + (uint32_t)tx];
+    return load_at<u2>(normal, (mul24((uint32_t)ty, W) + (uint32_t)tx) * 8u);
 }
 
 // gsamLinearWrap on the 256x256 RGBA8 random-vector map  (CRYCHIC.cpp:1068-1073)
@@ -116,7 +117,8 @@ CRY_HD f3 randvec_linear_wrap(const uint32_t* __restrict__ rv, float u, float v)
     Bilin b = bilinear_setup(uw, vw, 256, 256);
     uint32_t x0 = (uint32_t)b.i0 & 255u, x1 = (uint32_t)(b.i0 + 1) & 255u;
     uint32_t y0 = (uint32_t)b.j0 & 255u, y1 = (uint32_t)(b.j0 + 1) & 255u;
-    uint32_t t00 = rv[y0 * 256 + x0], t10 = rv[y0 * 256 + x1], t01 = rv[y1 * 256 + x0], t11 = rv[y1 * 256 + x1];
+    const uint32_t t00 = load_at<uint32_t>(rv, (y0 * 256u + x0) * 4u), t10 = load_at<uint32_t>(rv, (y0 * 256u + x1) * 4u);
+    const uint32_t t01 = load_at<uint32_t>(rv, (y1 * 256u + x0) * 4u), t11 = load_at<uint32_t>(rv, (y1 * 256u + x1) * 4u);
     f3 o;
     o.x = bilerp(unorm8_to_float(t00 & 255u), unorm8_to_float(t10 & 255u), unorm8_to_float(t01 & 255u),
                  unorm8_to_float(t11 & 255u), b.fx, b.fy);
@@ -169,25 +171,66 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
     const float eps = cb.SurfaceEpsilon, fadeEnd = cb.OcclusionFadeEnd;
     const float fadeLength = cb.OcclusionFadeEnd - cb.OcclusionFadeStart;  // :100
 
+    // Taps are evaluated two at a time in packed fp32 (devmath.hpp "two-wide packed fp32"); lane .x is tap i, lane .y tap
+    // i+1, and the occlusion terms are added to the sum in tap order, so every bit equals the one-tap-at-a-time loop.
+    const f3x2 n2 = splat3(n), p2 = splat3(p), rv2 = splat3(randVec);
+    const float A = cb.Proj[4 * 2 + 2], B = cb.Proj[4 * 2 + 3];   // Ssao.hlsl:110-115
+    const float* PT = cb.ProjTex;
     float occlusionSum = 0.0f;
-#pragma unroll 2
-    for (int i = 0; i < 14; ++i) {
-        const f3 o{ cb.OffsetVectors[i][0], cb.OffsetVectors[i][1], cb.OffsetVectors[i][2] };
-        const f3 offset = reflect3(o, randVec);                                  // :148
-        const float fr = signf(dot3(offset, n)) * cb.OcclusionRadius;            // :151,154
-        const f3 q{ p.x + fr * offset.x, p.y + fr * offset.y, p.z + fr * offset.z };
-        const float pqx = mulcol(q.x, q.y, q.z, 1.0f, cb.ProjTex + 0);           // :157
-        const float pqy = mulcol(q.x, q.y, q.z, 1.0f, cb.ProjTex + 4);
-        const float pqw = mulcol(q.x, q.y, q.z, 1.0f, cb.ProjTex + 12);
-        const float rz = ndc_to_view(cb, depth_linear_border(depth, W, H, pqx / pqw, pqy / pqw));  // :158-165
-        const float s = rz / q.z;                                                // :171
-        const f3 r{ s * q.x, s * q.y, s * q.z };
-        const float distZ = p.z - r.z;                                           // :185
-        const f3 dn = normalize3(f3{ r.x - p.x, r.y - p.y, r.z - p.z });
-        const float dp = maxnn(dot3(n, dn), 0.0f);                               // :186
-        const float fade = saturate((fadeEnd - distZ) / fadeLength);             // :76-108
-        const float occ = (distZ > eps) ? fade : 0.0f;
-        occlusionSum += dp * occ;                                                // :188-190
+#pragma unroll 1
+    for (int i = 0; i < 14; i += 2) {
+        const f3x2 o{ v2f{ cb.OffsetVectors[i][0], cb.OffsetVectors[i + 1][0] }, v2f{ cb.OffsetVectors[i][1], cb.OffsetVectors[i + 1][1] },
+                      v2f{ cb.OffsetVectors[i][2], cb.OffsetVectors[i + 1][2] } };
+        const v2f d2 = 2.0f * dot3x2(rv2, o);                                     // reflect(o, randVec)  :148
+        const f3x2 offset{ o.x - d2 * rv2.x, o.y - d2 * rv2.y, o.z - d2 * rv2.z };
+        const v2f fr = sign2(dot3x2(offset, n2)) * cb.OcclusionRadius;            // :151,154
+        const f3x2 q{ p2.x + fr * offset.x, p2.y + fr * offset.y, p2.z + fr * offset.z };
+        const v2f pqx = ((q.x * PT[0] + q.y * PT[1]) + q.z * PT[2]) + PT[3];      // mul(float4(q,1), gProjTex)  :157
+        const v2f pqy = ((q.x * PT[4] + q.y * PT[5]) + q.z * PT[6]) + PT[7];
+        const v2f pqw = ((q.x * PT[12] + q.y * PT[13]) + q.z * PT[14]) + PT[15];
+        const v2f tu = pqx / pqw, tv = pqy / pqw;                                 // :158
+
+        // gsamDepthMap, both taps: bilinear setup in packed form, the 2 x 2 footprints through the paired loads
+        const v2f tx = tu * (float)W - 0.5f, ty = tv * (float)H - 0.5f;
+        const v2f flx = floor2(tx), fly = floor2(ty);
+        v2f fx = tx - flx, fy = ty - fly;
+        const v2i bad = (fx != fx) | (fy != fy);
+        fx = select2(bad, splat(0.0f), fx);
+        fy = select2(bad, splat(0.0f), fy);
+        v2f cxf = select2(flx >= -2.0f, flx, splat(-2.0f)), cyf = select2(fly >= -2.0f, fly, splat(-2.0f));
+        cxf = select2(cxf > (float)W + 1.0f, splat((float)W + 1.0f), cxf);
+        cyf = select2(cyf > (float)H + 1.0f, splat((float)H + 1.0f), cyf);
+        const int i0a = bad.x ? -2 : (int)cxf.x, j0a = bad.x ? -2 : (int)cyf.x;
+        const int i0b = bad.y ? -2 : (int)cxf.y, j0b = bad.y ? -2 : (int)cyf.y;
+        v2f t00, t10, t01, t11;
+        {
+            const uint32_t r0 = (uint32_t)clampi(j0a, 0, (int)H - 1), r1 = (uint32_t)clampi(j0a + 1, 0, (int)H - 1);
+            const TexelPair a0 = pair_at(depth, r0, W, i0a), a1 = pair_at(depth, r1, W, i0a);
+            const bool xa = (uint32_t)i0a < W, xb = (uint32_t)(i0a + 1) < W, y0 = (uint32_t)j0a < H, y1 = (uint32_t)(j0a + 1) < H;
+            t00.x = d24_to_float((xa && y0) ? a0.a : 0x00FFFFFFu); t10.x = d24_to_float((xb && y0) ? a0.b : 0x00FFFFFFu);
+            t01.x = d24_to_float((xa && y1) ? a1.a : 0x00FFFFFFu); t11.x = d24_to_float((xb && y1) ? a1.b : 0x00FFFFFFu);
+        }
+        {
+            const uint32_t r0 = (uint32_t)clampi(j0b, 0, (int)H - 1), r1 = (uint32_t)clampi(j0b + 1, 0, (int)H - 1);
+            const TexelPair a0 = pair_at(depth, r0, W, i0b), a1 = pair_at(depth, r1, W, i0b);
+            const bool xa = (uint32_t)i0b < W, xb = (uint32_t)(i0b + 1) < W, y0 = (uint32_t)j0b < H, y1 = (uint32_t)(j0b + 1) < H;
+            t00.y = d24_to_float((xa && y0) ? a0.a : 0x00FFFFFFu); t10.y = d24_to_float((xb && y0) ? a0.b : 0x00FFFFFFu);
+            t01.y = d24_to_float((xa && y1) ? a1.a : 0x00FFFFFFu); t11.y = d24_to_float((xb && y1) ? a1.b : 0x00FFFFFFu);
+        }
+        const v2f zndc = lerp2(lerp2(t00, t10, fx), lerp2(t01, t11, fx), fy);
+        const v2f rz = B / (zndc - A);                                            // :164-165
+        const v2f sc = rz / q.z;                                                  // :171
+        const f3x2 r{ sc * q.x, sc * q.y, sc * q.z };
+        const v2f distZ = p2.z - r.z;                                             // :185
+        const f3x2 dv{ r.x - p2.x, r.y - p2.y, r.z - p2.z };
+        const v2f inv = 1.0f / sqrt2(dot3x2(dv, dv));                             // normalize(r - p)
+        const f3x2 dn{ dv.x * inv, dv.y * inv, dv.z * inv };
+        const v2f dp = max0_2(dot3x2(n2, dn));                                    // :186
+        const v2f fade = saturate2((fadeEnd - distZ) / fadeLength);               // :76-108
+        const v2f occ = select2(distZ > eps, fade, splat(0.0f));
+        const v2f term = dp * occ;
+        occlusionSum += term.x;                                                   // :188-190, tap i then tap i+1
+        occlusionSum += term.y;
     }
     occlusionSum = occlusionSum / 14.0f;                                         // :193
     const float access = 1.0f - occlusionSum;                                    // :195
@@ -209,7 +252,7 @@ CRY_HD BlurTap blur_fetch(const EdgePlane& e, const uint16_t* __restrict__ amb, 
 {
     BlurTap t;
     const int cx = clampi(xi, 0, w2 - 1), cy = clampi(yi, 0, h2 - 1);
-    const uint32_t idx = (uint32_t)cy * (uint32_t)w2 + (uint32_t)cx;
+    const uint32_t idx = mul24((uint32_t)cy, (uint32_t)w2) + (uint32_t)cx;
     const u2* src = e.nrm + idx;                       // one load through a selected address (no divergent branches)
     src = (yi < 0) ? e.grow + cx : src;
     src = (xi < 0) ? e.gcol + cy : src;
