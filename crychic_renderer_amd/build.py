@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcrychic_hip.so")
-SOURCES = ["kernels.hip", "raster.hip", "api.cpp", "host_constants.cpp", "host_geometry.cpp"]
+SOURCES = ["kernels.hip", "raster.hip", "api.cpp", "host_constants.cpp", "host_geometry.cpp", "host_textures.cpp"]
 HEADERS = ["devmath.hpp", "ssao_core.hpp", "light_core.hpp", "raster_core.hpp", "kernels.hpp"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
          "-Wall", "-Wno-unused-function"]

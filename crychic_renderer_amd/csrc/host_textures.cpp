@@ -1,0 +1,131 @@
+// host_textures.cpp -- material-texture loader: the subset of Common/DDSTextureLoader.cpp the reference's
+// six material textures need (CRYCHIC::LoadTextures, CRYCHIC.cpp:939-973): DDS containers holding DXT1 (BC1), DXT5 (BC3)
+// or uncompressed 32-bit masks, decoded on the host to the R8G8B8A8 mip-0 image the G-buffer pass samples.
+// Block decompression follows the D3D10 BC1/BC3 definition with 5:6:5 -> 8:8:8 bit replication and round-to-nearest
+// integer interpolation ((2a + b + 1) / 3, (wa*a + wb*b + 3) / 7); D3D leaves the low bits of these to the hardware.
+#include <cstdint>
+#include <cstring>
+#include <fstream>
+#include <vector>
+#include "crychic_hip.h"
+
+namespace {
+
+struct DdsInfo {
+    uint32_t width = 0, height = 0;
+    enum Kind { BC1, BC3, RGBA_MASKS } kind = BC1;
+    uint32_t bitCount = 0, rMask = 0, gMask = 0, bMask = 0, aMask = 0;
+    size_t dataOffset = 128;
+};
+
+uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+bool parse_header(const std::vector<uint8_t>& f, DdsInfo& d)
+{
+    if (f.size() < 128 || std::memcmp(f.data(), "DDS ", 4) != 0 || rd32(&f[4]) != 124) return false;
+    d.height = rd32(&f[12]);
+    d.width = rd32(&f[16]);
+    const uint32_t pfFlags = rd32(&f[80]);
+    if (pfFlags & 0x4u) {                       // DDPF_FOURCC
+        if (std::memcmp(&f[84], "DXT1", 4) == 0) d.kind = DdsInfo::BC1;
+        else if (std::memcmp(&f[84], "DXT5", 4) == 0) d.kind = DdsInfo::BC3;
+        else return false;                      // DX10 header and the other FourCCs are not used by the reference's textures
+    } else if (pfFlags & 0x40u) {               // DDPF_RGB
+        d.kind = DdsInfo::RGBA_MASKS;
+        d.bitCount = rd32(&f[88]);
+        d.rMask = rd32(&f[92]); d.gMask = rd32(&f[96]); d.bMask = rd32(&f[100]); d.aMask = (pfFlags & 0x1u) ? rd32(&f[104]) : 0;
+        if (d.bitCount != 32) return false;
+    } else {
+        return false;
+    }
+    return d.width > 0 && d.height > 0;
+}
+
+inline void expand565(uint16_t c, int rgb[3])
+{
+    const int r = (c >> 11) & 31, g = (c >> 5) & 63, b = c & 31;
+    rgb[0] = (r << 3) | (r >> 2); rgb[1] = (g << 2) | (g >> 4); rgb[2] = (b << 3) | (b >> 2);
+}
+
+// 8-byte colour block -> 16 RGBA texels (alpha 255, or 0 for BC1's transparent index)
+void decode_color_block(const uint8_t* blk, bool bc1, uint8_t out[16][4])
+{
+    const uint16_t c0 = (uint16_t)(blk[0] | (blk[1] << 8)), c1 = (uint16_t)(blk[2] | (blk[3] << 8));
+    int pal[4][4];
+    expand565(c0, pal[0]); expand565(c1, pal[1]);
+    pal[0][3] = pal[1][3] = 255;
+    if (!bc1 || c0 > c1) {
+        for (int k = 0; k < 3; ++k) { pal[2][k] = (2 * pal[0][k] + pal[1][k] + 1) / 3; pal[3][k] = (pal[0][k] + 2 * pal[1][k] + 1) / 3; }
+        pal[2][3] = pal[3][3] = 255;
+    } else {
+        for (int k = 0; k < 3; ++k) { pal[2][k] = (pal[0][k] + pal[1][k] + 1) / 2; pal[3][k] = 0; }
+        pal[2][3] = 255; pal[3][3] = 0;
+    }
+    const uint32_t bits = rd32(blk + 4);
+    for (int t = 0; t < 16; ++t) {
+        const int* p = pal[(bits >> (2 * t)) & 3u];
+        for (int k = 0; k < 4; ++k) out[t][k] = (uint8_t)p[k];
+    }
+}
+
+void decode_alpha_block(const uint8_t* blk, uint8_t out[16])
+{
+    const int a0 = blk[0], a1 = blk[1];
+    int pal[8] = { a0, a1 };
+    if (a0 > a1) for (int k = 1; k < 7; ++k) pal[k + 1] = ((7 - k) * a0 + k * a1 + 3) / 7;
+    else { for (int k = 1; k < 5; ++k) pal[k + 1] = ((5 - k) * a0 + k * a1 + 2) / 5; pal[6] = 0; pal[7] = 255; }
+    uint64_t bits = 0;
+    for (int k = 0; k < 6; ++k) bits |= (uint64_t)blk[2 + k] << (8 * k);
+    for (int t = 0; t < 16; ++t) out[t] = (uint8_t)pal[(bits >> (3 * t)) & 7u];
+}
+
+int channel_shift(uint32_t mask) { int s = 0; while (mask && !(mask & 1u)) { mask >>= 1; ++s; } return s; }
+
+}  // namespace
+
+extern "C" int crychic_load_dds_rgba8(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32_t* width, uint32_t* height)
+{
+    if (!path) return CRYCHIC_E_INVALID_ARG;
+    std::ifstream in(path, std::ios::binary);
+    if (!in) return CRYCHIC_E_INVALID_ARG;
+    std::vector<uint8_t> f((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    DdsInfo d;
+    if (!parse_header(f, d)) return CRYCHIC_E_UNSUPPORTED;
+    if (width) *width = d.width;
+    if (height) *height = d.height;
+    if (!rgba8) return 0;
+    const size_t need = (size_t)d.width * d.height * 4;
+    if (capacityBytes < need) return CRYCHIC_E_INVALID_ARG;
+    const uint8_t* src = f.data() + d.dataOffset;
+    const size_t avail = f.size() - d.dataOffset;
+    if (d.kind == DdsInfo::RGBA_MASKS) {
+        if (avail < need) return CRYCHIC_E_INVALID_ARG;
+        const int rs = channel_shift(d.rMask), gs = channel_shift(d.gMask), bs = channel_shift(d.bMask), as = channel_shift(d.aMask);
+        for (size_t i = 0; i < (size_t)d.width * d.height; ++i) {
+            const uint32_t px = rd32(src + 4 * i);
+            rgba8[4 * i + 0] = (uint8_t)((px & d.rMask) >> rs);
+            rgba8[4 * i + 1] = (uint8_t)((px & d.gMask) >> gs);
+            rgba8[4 * i + 2] = (uint8_t)((px & d.bMask) >> bs);
+            rgba8[4 * i + 3] = d.aMask ? (uint8_t)((px & d.aMask) >> as) : 255;
+        }
+        return 0;
+    }
+    const uint32_t bw = (d.width + 3) / 4, bh = (d.height + 3) / 4;
+    const size_t blockBytes = d.kind == DdsInfo::BC1 ? 8 : 16;
+    if (avail < (size_t)bw * bh * blockBytes) return CRYCHIC_E_INVALID_ARG;
+    for (uint32_t by = 0; by < bh; ++by)
+        for (uint32_t bx = 0; bx < bw; ++bx) {
+            const uint8_t* blk = src + ((size_t)by * bw + bx) * blockBytes;
+            uint8_t texels[16][4], alpha[16];
+            if (d.kind == DdsInfo::BC3) { decode_alpha_block(blk, alpha); decode_color_block(blk + 8, false, texels); }
+            else decode_color_block(blk, true, texels);
+            for (int t = 0; t < 16; ++t) {
+                const uint32_t x = bx * 4 + (uint32_t)(t & 3), y = by * 4 + (uint32_t)(t >> 2);
+                if (x >= d.width || y >= d.height) continue;
+                uint8_t* o = rgba8 + ((size_t)y * d.width + x) * 4;
+                o[0] = texels[t][0]; o[1] = texels[t][1]; o[2] = texels[t][2];
+                o[3] = d.kind == DdsInfo::BC3 ? alpha[t] : texels[t][3];
+            }
+        }
+    return 0;
+}

@@ -188,7 +188,7 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
         const v2f pqx = ((q.x * PT[0] + q.y * PT[1]) + q.z * PT[2]) + PT[3];      // mul(float4(q,1), gProjTex)  :157
         const v2f pqy = ((q.x * PT[4] + q.y * PT[5]) + q.z * PT[6]) + PT[7];
         const v2f pqw = ((q.x * PT[12] + q.y * PT[13]) + q.z * PT[14]) + PT[15];
-        const v2f tu = pqx / pqw, tv = pqy / pqw;                                 // :158
+        const v2f tu = div2(pqx, pqw), tv = div2(pqy, pqw);                       // :158
 
         // gsamDepthMap, both taps: bilinear setup in packed form, the 2 x 2 footprints through the paired loads
         const v2f tx = tu * (float)W - 0.5f, ty = tv * (float)H - 0.5f;
@@ -218,15 +218,15 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
             t01.y = d24_to_float((xa && y1) ? a1.a : 0x00FFFFFFu); t11.y = d24_to_float((xb && y1) ? a1.b : 0x00FFFFFFu);
         }
         const v2f zndc = lerp2(lerp2(t00, t10, fx), lerp2(t01, t11, fx), fy);
-        const v2f rz = B / (zndc - A);                                            // :164-165
-        const v2f sc = rz / q.z;                                                  // :171
+        const v2f rz = div2(B, zndc - A);                                         // :164-165
+        const v2f sc = div2(rz, q.z);                                             // :171
         const f3x2 r{ sc * q.x, sc * q.y, sc * q.z };
         const v2f distZ = p2.z - r.z;                                             // :185
         const f3x2 dv{ r.x - p2.x, r.y - p2.y, r.z - p2.z };
-        const v2f inv = 1.0f / sqrt2(dot3x2(dv, dv));                             // normalize(r - p)
+        const v2f inv = div2(1.0f, sqrt2(dot3x2(dv, dv)));                        // normalize(r - p)
         const f3x2 dn{ dv.x * inv, dv.y * inv, dv.z * inv };
         const v2f dp = max0_2(dot3x2(n2, dn));                                    // :186
-        const v2f fade = saturate2((fadeEnd - distZ) / fadeLength);               // :76-108
+        const v2f fade = saturate2(div2(fadeEnd - distZ, fadeLength));            // :76-108
         const v2f occ = select2(distZ > eps, fade, splat(0.0f));
         const v2f term = dp * occ;
         occlusionSum += term.x;                                                   // :188-190, tap i then tap i+1

@@ -116,3 +116,20 @@ def procedural_textures(size=64):
             t[..., 0] = nx; t[..., 1] = ny; t[..., 2] = 250; t[..., 3] = 255
         out.append(t)
     return out
+
+
+def load_dds(path):
+    """A reference material texture as an H x W x 4 uint8 array (crychic_load_dds_rgba8, row f4)."""
+    w, h = C.c_uint32(), C.c_uint32()
+    check(lib.crychic_load_dds_rgba8(path.encode(), None, 0, C.byref(w), C.byref(h)))
+    out = np.zeros((h.value, w.value, 4), np.uint8)
+    check(lib.crychic_load_dds_rgba8(path.encode(), out.ctypes.data, out.nbytes, C.byref(w), C.byref(h)))
+    return out
+
+
+def reference_textures(texture_dir):
+    """gTextureMaps in heap order (CRYCHIC::LoadTextures, CRYCHIC.cpp:954-959): bricks2, bricks2_nmap, tile, tile_nmap,
+    white1x1, default_nmap."""
+    import os
+    names = ["bricks2.dds", "bricks2_nmap.dds", "tile.dds", "tile_nmap.dds", "white1x1.dds", "default_nmap.dds"]
+    return [load_dds(os.path.join(texture_dir, n)) for n in names]

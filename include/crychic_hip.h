@@ -275,6 +275,12 @@ int crychic_create_grid(float width, float depth, uint32_t m, uint32_t n, crychi
 int crychic_load_mesh_text(const char* path, crychic_vertex* vertices, uint32_t vertexCapacity, uint32_t* indices,
                            uint32_t indexCapacity, uint32_t* vertexCount, uint32_t* indexCount);
 
+/* Material textures: a DDS file holding DXT1, DXT5 or 32-bit-mask pixels (the formats of the six
+ * textures CRYCHIC::LoadTextures opens, CRYCHIC.cpp:939-973) decoded on the host to the R8G8B8A8 mip-0 image that
+ * crychic_draw_gbuffer samples.  NULL buffer: only *width / *height are written.  Replaces the subset of
+ * Common/DDSTextureLoader.cpp + GPU block decompression the path depends on. */
+int crychic_load_dds_rgba8(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32_t* width, uint32_t* height);
+
 /* Device workspace for one rasterised pass over `triangles` input triangles (sum over items of instanceCount *
  * indexCount / 3) into a W x H target. */
 size_t crychic_raster_workspace_bytes(uint64_t triangles, uint32_t W, uint32_t H);

@@ -211,6 +211,8 @@ int or_create_grid(float width, float depth, uint32_t m, uint32_t n, or_vertex* 
 int or_load_mesh_text(const char* path, or_vertex* v, uint32_t vcap, uint32_t* idx, uint32_t icap, uint32_t* nVerts,
                       uint32_t* nIdx);
 uint16_t or_float_to_half(float f);
+/* DDS (DXT1 / DXT5 / 32-bit masks) -> R8G8B8A8 mip 0 (row f4); NULL buffer queries the size.  0 on success. */
+int or_load_dds_rgba8(const char* path, uint8_t* rgba8, size_t capacity, uint32_t* width, uint32_t* height);
 
 /* or_deferred_light plus NUM_POINT_LIGHTS point lights from a separate buffer: BUILD-DEFINED EXTENSION for BASELINE
  * configs[4] (the reference's point-light branch, PBR.hlsl:109-124, is dead code); see or_light.c. */

@@ -1,0 +1,101 @@
+/*
+ * or_textures.c -- oracle restatement of the material-texture path: DDS (DXT1 / DXT5 / 32-bit masks) ->
+ * R8G8B8A8 mip 0, for the files CRYCHIC::LoadTextures opens (CRYCHIC.cpp:939-973).  TEST INFRASTRUCTURE, parity unpinned:
+ * the reference decodes block-compressed textures in GPU hardware; the interpolation rounding used here
+ * (bit-replicated 5:6:5, (2a+b+1)/3, (wa*a+wb*b+3)/7) is the oracle's definition.
+ */
+#include "crychic_oracle.h"
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+static uint32_t le32(const unsigned char* p) { return p[0] | (p[1] << 8) | (p[2] << 16) | ((uint32_t)p[3] << 24); }
+
+static void color565(unsigned c, int* r, int* g, int* b)
+{
+    int r5 = (c >> 11) & 31, g6 = (c >> 5) & 63, b5 = c & 31;
+    *r = (r5 << 3) | (r5 >> 2); *g = (g6 << 2) | (g6 >> 4); *b = (b5 << 3) | (b5 >> 2);
+}
+
+static void bc_color(const unsigned char* blk, int is_bc1, int x, int y, unsigned char out[4])
+{
+    unsigned c0 = blk[0] | (blk[1] << 8), c1 = blk[2] | (blk[3] << 8);
+    unsigned sel = (le32(blk + 4) >> (2 * (4 * y + x))) & 3u;
+    int r0, g0, b0, r1, g1, b1;
+    color565(c0, &r0, &g0, &b0); color565(c1, &r1, &g1, &b1);
+    int four = !is_bc1 || c0 > c1;
+    int r, g, b, a = 255;
+    switch (sel) {
+    case 0: r = r0; g = g0; b = b0; break;
+    case 1: r = r1; g = g1; b = b1; break;
+    case 2:
+        if (four) { r = (2 * r0 + r1 + 1) / 3; g = (2 * g0 + g1 + 1) / 3; b = (2 * b0 + b1 + 1) / 3; }
+        else { r = (r0 + r1 + 1) / 2; g = (g0 + g1 + 1) / 2; b = (b0 + b1 + 1) / 2; }
+        break;
+    default:
+        if (four) { r = (r0 + 2 * r1 + 1) / 3; g = (g0 + 2 * g1 + 1) / 3; b = (b0 + 2 * b1 + 1) / 3; }
+        else { r = g = b = 0; a = 0; }
+    }
+    out[0] = (unsigned char)r; out[1] = (unsigned char)g; out[2] = (unsigned char)b; out[3] = (unsigned char)a;
+}
+
+static unsigned char bc3_alpha(const unsigned char* blk, int x, int y)
+{
+    int a0 = blk[0], a1 = blk[1];
+    unsigned long long bits = 0;
+    for (int k = 0; k < 6; ++k) bits |= (unsigned long long)blk[2 + k] << (8 * k);
+    unsigned sel = (unsigned)((bits >> (3 * (4 * y + x))) & 7u);
+    if (sel == 0) return (unsigned char)a0;
+    if (sel == 1) return (unsigned char)a1;
+    if (a0 > a1) return (unsigned char)(((8 - sel) * a0 + (sel - 1) * a1 + 3) / 7);
+    if (sel == 6) return 0;
+    if (sel == 7) return 255;
+    return (unsigned char)(((6 - sel) * a0 + (sel - 1) * a1 + 2) / 5);
+}
+
+int or_load_dds_rgba8(const char* path, uint8_t* rgba8, size_t capacity, uint32_t* width, uint32_t* height)
+{
+    FILE* f = fopen(path, "rb");
+    if (!f) return -1;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    unsigned char* d = (unsigned char*)malloc((size_t)n);
+    if (fread(d, 1, (size_t)n, f) != (size_t)n) { fclose(f); free(d); return -1; }
+    fclose(f);
+    int rc = -4;
+    if (n >= 128 && memcmp(d, "DDS ", 4) == 0) {
+        uint32_t h = le32(d + 12), w = le32(d + 16), pf = le32(d + 80);
+        if (width) *width = w;
+        if (height) *height = h;
+        if (!rgba8) rc = 0;
+        else if (capacity < (size_t)w * h * 4) rc = -1;
+        else if ((pf & 4u) && (memcmp(d + 84, "DXT1", 4) == 0 || memcmp(d + 84, "DXT5", 4) == 0)) {
+            int bc1 = d[87] == '1';
+            size_t bsz = bc1 ? 8 : 16;
+            uint32_t bw = (w + 3) / 4;
+            for (uint32_t y = 0; y < h; ++y)
+                for (uint32_t x = 0; x < w; ++x) {
+                    const unsigned char* blk = d + 128 + ((size_t)(y / 4) * bw + x / 4) * bsz;
+                    unsigned char* o = rgba8 + ((size_t)y * w + x) * 4;
+                    bc_color(bc1 ? blk : blk + 8, bc1, (int)(x & 3), (int)(y & 3), o);
+                    if (!bc1) o[3] = bc3_alpha(blk, (int)(x & 3), (int)(y & 3));
+                }
+            rc = 0;
+        } else if ((pf & 0x40u) && le32(d + 88) == 32) {
+            uint32_t m[4] = { le32(d + 92), le32(d + 96), le32(d + 100), (pf & 1u) ? le32(d + 104) : 0 };
+            for (size_t i = 0; i < (size_t)w * h; ++i) {
+                uint32_t px = le32(d + 128 + 4 * i);
+                for (int c = 0; c < 4; ++c) {
+                    if (!m[c]) { rgba8[4 * i + c] = 255; continue; }
+                    uint32_t v = px & m[c], mm = m[c];
+                    while (!(mm & 1u)) { mm >>= 1; v >>= 1; }
+                    rgba8[4 * i + c] = (uint8_t)v;
+                }
+            }
+            rc = 0;
+        }
+    }
+    free(d);
+    return rc;
+}

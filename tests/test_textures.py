@@ -1,0 +1,106 @@
+"""Material textures: the product's DDS decoder against the oracle's, on hand-built DXT1 / DXT5 /
+32-bit-mask files (known answers) and, where the reference checkout is present, on its six material textures."""
+import ctypes as C
+import os
+import struct
+
+import numpy as np
+import pytest
+
+REF_TEX = "/root/reference/Textures"
+
+
+def dds_header(w, h, fourcc=None, masks=None):
+    pf_flags = 0x4 if fourcc else (0x41 if masks[3] else 0x40)
+    pf = struct.pack("<II4sIIIII", 32, pf_flags, fourcc or b"\0\0\0\0", 0 if fourcc else 32, *(masks or (0, 0, 0, 0)))
+    hdr = struct.pack("<IIIIIII", 124, 0x1007, h, w, 0, 0, 0) + b"\0" * 44 + pf + struct.pack("<IIIII", 0x1000, 0, 0, 0, 0)
+    assert len(hdr) == 124
+    return b"DDS " + hdr
+
+
+def oracle_load(oracle, path):
+    L = oracle.lib
+    L.or_load_dds_rgba8.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+    w, h = C.c_uint32(), C.c_uint32()
+    assert L.or_load_dds_rgba8(path.encode(), None, 0, C.byref(w), C.byref(h)) == 0
+    out = np.zeros((h.value, w.value, 4), np.uint8)
+    assert L.or_load_dds_rgba8(path.encode(), out.ctypes.data, out.nbytes, C.byref(w), C.byref(h)) == 0
+    return out
+
+
+def test_known_blocks(built_lib, oracle, tmp_path):
+    from crychic_renderer_amd import geometry as g
+    # DXT1, one block: c0 = pure red (0xF800) > c1 = pure blue (0x001F): palette red, blue, 2/3 red + 1/3 blue, 1/3 + 2/3
+    idx = 0
+    for t in range(16):
+        idx |= (t % 4) << (2 * t)
+    p = tmp_path / "bc1.dds"
+    p.write_bytes(dds_header(4, 4, b"DXT1") + struct.pack("<HHI", 0xF800, 0x001F, idx))
+    img = g.load_dds(str(p))
+    assert img.shape == (4, 4, 4)
+    assert img[0, 0].tolist() == [255, 0, 0, 255] and img[0, 1].tolist() == [0, 0, 255, 255]
+    assert img[0, 2].tolist() == [170, 0, 85, 255] and img[0, 3].tolist() == [85, 0, 170, 255]
+    assert np.array_equal(img, oracle_load(oracle, str(p)))
+    # DXT1 three-colour mode (c0 <= c1): index 3 is transparent black
+    p.write_bytes(dds_header(4, 4, b"DXT1") + struct.pack("<HHI", 0x001F, 0xF800, idx))
+    img = g.load_dds(str(p))
+    assert img[0, 2].tolist() == [128, 0, 128, 255] and img[0, 3].tolist() == [0, 0, 0, 0]
+    assert np.array_equal(img, oracle_load(oracle, str(p)))
+    # DXT5: alpha endpoints 255 > 0 with all eight selectors in texels 0..7
+    abits = 0
+    for t in range(16):
+        abits |= (t % 8) << (3 * t)
+    p5 = tmp_path / "bc3.dds"
+    p5.write_bytes(dds_header(4, 4, b"DXT5") + bytes([255, 0]) + abits.to_bytes(6, "little") + struct.pack("<HHI", 0xFFFF, 0x0000, idx))
+    img = g.load_dds(str(p5))
+    assert img[..., 3].reshape(-1)[:8].tolist() == [255, 0, 219, 182, 146, 109, 73, 36]
+    assert img[0, 0, :3].tolist() == [255, 255, 255] and img[0, 2, :3].tolist() == [170, 170, 170]
+    assert np.array_equal(img, oracle_load(oracle, str(p5)))
+    # A8R8G8B8 masks: memory order B, G, R, A
+    pm = tmp_path / "argb.dds"
+    px = np.arange(2 * 3 * 4, dtype=np.uint8).reshape(2, 3, 4)
+    pm.write_bytes(dds_header(3, 2, None, (0xFF0000, 0xFF00, 0xFF, 0xFF000000)) + px.tobytes())
+    img = g.load_dds(str(pm))
+    assert img.shape == (2, 3, 4) and img[0, 0].tolist() == [2, 1, 0, 3] and img[1, 2].tolist() == [22, 21, 20, 23]
+    assert np.array_equal(img, oracle_load(oracle, str(pm)))
+    # errors
+    bad = tmp_path / "bad.dds"
+    bad.write_bytes(b"nope")
+    w, h = C.c_uint32(), C.c_uint32()
+    assert built_lib.lib.crychic_load_dds_rgba8(str(bad).encode(), None, 0, C.byref(w), C.byref(h)) == -4
+    assert built_lib.lib.crychic_load_dds_rgba8(b"/nonexistent.dds", None, 0, C.byref(w), C.byref(h)) == -1
+    small = np.zeros(8, np.uint8)
+    assert built_lib.lib.crychic_load_dds_rgba8(str(p5).encode(), small.ctypes.data, 8, C.byref(w), C.byref(h)) == -1
+
+
+@pytest.mark.skipif(not os.path.exists(REF_TEX), reason="reference textures are not on this machine")
+def test_reference_material_textures(built_lib, oracle):
+    from crychic_renderer_amd import geometry as g
+    tex = g.reference_textures(REF_TEX)
+    shapes = [t.shape[:2] for t in tex]
+    assert shapes == [(512, 512), (256, 256), (512, 512), (512, 512), (1, 1), (1, 1)]
+    for name, t in zip(["bricks2.dds", "bricks2_nmap.dds", "tile.dds", "tile_nmap.dds", "white1x1.dds", "default_nmap.dds"], tex):
+        assert np.array_equal(t, oracle_load(oracle, os.path.join(REF_TEX, name))), name
+    assert tex[4][0, 0].tolist() == [255, 255, 255, 255]                 # white1x1
+    assert tex[5][0, 0, 2] > 200                                         # default normal map points along +z
+    assert tex[1][..., 2].mean() > 180 and 100 < tex[1][..., 0].mean() < 155   # a normal map: mostly +z, xy around 0.5
+    assert tex[0].std() > 10                                             # bricks have contrast
+
+
+@pytest.mark.skipif(not os.path.exists(REF_TEX), reason="reference textures are not on this machine")
+def test_gbuffer_with_reference_textures(built_lib, oracle, hostsim):
+    """The G-buffer pass sampling the real brick / tile textures: kernel bodies vs oracle, bit for bit."""
+    import oracle_lib
+    import scene_util
+    from crychic_renderer_amd import geometry as g
+    W, H = 160, 90
+    cs = scene_util.cpu_scene(W, H, 128, 16)["consts"]
+    tex = g.reference_textures(REF_TEX)
+    items, mats = g.cascade_scene_items(), g.reference_materials()
+    view = np.array(cs.pass_cb.View, np.float32); vp = np.array(cs.pass_cb.ViewProj, np.float32)
+    a = oracle_lib.rasterize(oracle, 2, view, vp, items, mats.view(oracle_lib.MATERIAL_DT), tex, W, H)
+    b = hostsim.rasterize(2, view, vp, items, mats, tex, W, H)
+    for k in ("g0", "g1", "g2"):
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    cov = a["depth"] < 0xFFFFFF
+    assert len(np.unique(a["g1"][cov][:, 0])) > 50                       # brick / tile texels modulate the albedo
