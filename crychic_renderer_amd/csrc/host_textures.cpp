@@ -129,3 +129,20 @@ extern "C" int crychic_load_dds_rgba8(const char* path, uint8_t* rgba8, size_t c
         }
     return 0;
 }
+
+// Present stand-in: the reference hands the back buffer to the swap chain (CRYCHIC.cpp:294-297); a
+// headless build writes it out instead.  Binary PPM (P6), alpha dropped.
+extern "C" int crychic_save_ppm(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height)
+{
+    if (!path || !rgba8 || !width || !height) return CRYCHIC_E_INVALID_ARG;
+    std::ofstream out(path, std::ios::binary);
+    if (!out) return CRYCHIC_E_INVALID_ARG;
+    out << "P6\n" << width << " " << height << "\n255\n";
+    std::vector<uint8_t> row((size_t)width * 3);
+    for (uint32_t y = 0; y < height; ++y) {
+        for (uint32_t x = 0; x < width; ++x)
+            for (int c = 0; c < 3; ++c) row[(size_t)x * 3 + c] = rgba8[((size_t)y * width + x) * 4 + c];
+        out.write(reinterpret_cast<const char*>(row.data()), (std::streamsize)row.size());
+    }
+    return out ? 0 : CRYCHIC_E_INVALID_ARG;
+}

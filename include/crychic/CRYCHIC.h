@@ -183,6 +183,15 @@ public:
         CrychicHipThrowIfFailed(hipEventRecord(mCurrFrameResource->FenceEvent, mCommandList->Stream()));
     }
 
+    // mSwapChain->Present (CRYCHIC.cpp:294-297) for a headless build: read the back buffer back and write it as PPM.
+    void Present(const std::string& path)
+    {
+        std::vector<uint8_t> host((size_t)mClientWidth * mClientHeight * 4);
+        mBackBuffer->Download(host.data(), host.size(), mCommandList->Stream());
+        mCommandList->Flush();
+        CrychicThrowIfFailed(crychic_save_ppm(path.c_str(), host.data(), mClientWidth, mClientHeight));
+    }
+
     // ---- planes the producer passes would fill (row f1) + the result ----
     ID3D12Resource* DepthStencilBuffer() { return mDepthStencilBuffer.get(); }
     ID3D12Resource* CurrentBackBuffer() { return mBackBuffer.get(); }

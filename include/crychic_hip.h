@@ -281,6 +281,10 @@ int crychic_load_mesh_text(const char* path, crychic_vertex* vertices, uint32_t 
  * Common/DDSTextureLoader.cpp + GPU block decompression the path depends on. */
 int crychic_load_dds_rgba8(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32_t* width, uint32_t* height);
 
+/* Present stand-in (row f3; the reference calls IDXGISwapChain::Present, CRYCHIC.cpp:294-297): writes a HOST R8G8B8A8
+ * image as binary PPM (alpha dropped). */
+int crychic_save_ppm(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height);
+
 /* Device workspace for one rasterised pass over `triangles` input triangles (sum over items of instanceCount *
  * indexCount / 3) into a W x H target. */
 size_t crychic_raster_workspace_bytes(uint64_t triangles, uint32_t W, uint32_t H);
