@@ -43,6 +43,10 @@ def parse():
     ap.add_argument("--pcf", choices=["literal", "intended"], default="literal")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-producers", action="store_true", help="skip the informational timing of the producer passes")
+    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
+                    help="replay the frame's launches from a captured hipGraph (auto: when N > 1, where a strip is short enough "
+                         "for host launch cost to show)")
+    ap.add_argument("--point-lights", type=int, default=0, help="extension (BASELINE configs[4]): n x n point-light grid, e.g. 8")
     ap.add_argument("--dump-scene", default="", help="write the input planes + constants for tools/prof_driver and exit")
     ap.add_argument("--cpu-band-rows", type=int, default=0, help="full-res rows of the CPU baseline band (0 = auto)")
     return ap.parse_args()
@@ -84,6 +88,10 @@ def cpu_baseline(planes, args, pcf_radius):
         want = int(rows * target / max(dt, 1e-3))
         if want > rows * 2:
             rows, dt = run_band(min(H, want))
+        reps = 1
+        while rows == H and dt * reps < 3.0 and reps < 16:   # many-core host: the whole frame is short, average a few
+            dt = (dt * reps + run_band(H)[1]) / (reps + 1)
+            reps += 1
     return {"value": round(rows * W / dt / 1e6, 3), "unit": "Mpixels/s", "cores": int(orc.lib.or_num_threads()), "kind": "port",
             "sample": "oracle (C, OpenMP) SSAO + %d blur sweeps + lighting on a %d-row band (%d x %d px) of the same "
                       "frame, %.1f s" % (2 * bc, rows, W, rows, dt)}
@@ -209,12 +217,34 @@ def main():
     row0, rows = sharding.strip_rows(H, world, rank)
     gather = sharding.FrameGather(W, H, world, rank, dev) if world > 1 else None
 
+    if args.point_lights:
+        app.set_point_lights(scene.point_light_grid(args.point_lights))
+
+    # hipGraph: one graph per back-buffer slot replays the ~10 kernel launches of a frame with a single host call.
+    use_graph = args.graph == "on" or (args.graph == "auto" and world > 1)
+    graphs = {}
+
+    def draw(slot_buffer):
+        app.mBackBuffer = slot_buffer
+        if not use_graph:
+            app.Draw(row0, rows)
+            return
+        key = slot_buffer.data_ptr()
+        g = graphs.get(key)
+        if g is None:
+            app.Draw(row0, rows)                      # warm (also makes sure no lazy allocation happens inside the capture)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                app.Draw(row0, rows)
+            graphs[key] = g
+        g.replay()
+
     def step(i):
         if gather is None:
-            app.Draw(row0, rows)
+            draw(planes["out"])
         else:
-            app.mBackBuffer = gather.strip_buffer(i)   # double-buffered so gather(i) overlaps Draw(i+1)
-            app.Draw(row0, rows)
+            draw(gather.strip_buffer(i))               # double-buffered so gather(i) overlaps Draw(i+1)
             gather.launch(i)
 
     def fence():
@@ -277,6 +307,8 @@ def main():
                                    "blur + cascade PCF (%s radius), 4x%d^2 D24 shadow maps" % (W, H, args.lights, args.blur_count,
                                                                                              args.pcf, args.shadow_dim),
                        "sharding": "row strips x%d + RCCL all-gather of RGBA8 strips" % world if world > 1 else "single GPU",
+                       "launch": "hipGraph replay" if use_graph else "eager",
+                       "point_lights": args.point_lights * args.point_lights,
                        "frame_algorithmic_MB": round(frame_bytes / 1e6, 1),
                        "frame_hbm_roofline_frac": round(frame_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS * world, 4)
                        if world == 1 else None,
