@@ -70,7 +70,7 @@ CRY_HD v2f lerp2(v2f a, v2f b, v2f t) { return a + t * (b - a); }
 // (same operations, same special-case fix-up).  The host build simply divides.
 CRY_HD v2f div2(v2f n, v2f d)
 {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CRYCHIC_RELAXED_MATH_PROBE)   // probe build: tools/relaxed_math_probe.py
     bool na, nb, da, db;
     const v2f ds{ __builtin_amdgcn_div_scalef(n.x, d.x, false, &da), __builtin_amdgcn_div_scalef(n.y, d.y, false, &db) };
     const v2f ns{ __builtin_amdgcn_div_scalef(n.x, d.x, true, &na), __builtin_amdgcn_div_scalef(n.y, d.y, true, &nb) };

@@ -200,8 +200,13 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
         v2f cxf = select2(flx >= -2.0f, flx, splat(-2.0f)), cyf = select2(fly >= -2.0f, fly, splat(-2.0f));
         cxf = select2(cxf > (float)W + 1.0f, splat((float)W + 1.0f), cxf);
         cyf = select2(cyf > (float)H + 1.0f, splat((float)H + 1.0f), cyf);
+#if defined(CRYCHIC_PROBE_NO_GATHER)   // tools/relaxed_math_probe.py: every tap reads the pixel's own footprint (timing experiment)
+        const int i0a = 2 * (int)x + (int)(cxf.x == 12345.0f), j0a = 2 * (int)y + (int)(cyf.x == 12345.0f);
+        const int i0b = 2 * (int)x + (int)(cxf.y == 12345.0f), j0b = 2 * (int)y + (int)(cyf.y == 12345.0f);
+#else
         const int i0a = bad.x ? -2 : (int)cxf.x, j0a = bad.x ? -2 : (int)cyf.x;
         const int i0b = bad.y ? -2 : (int)cxf.y, j0b = bad.y ? -2 : (int)cyf.y;
+#endif
         v2f t00, t10, t01, t11;
         {
             const uint32_t r0 = (uint32_t)clampi(j0a, 0, (int)H - 1), r1 = (uint32_t)clampi(j0a + 1, 0, (int)H - 1);

@@ -79,3 +79,59 @@ def test_tiled_point_lights_on_device(built_lib, oracle, W, H):
     ref0 = oracle.deferred_light(pcb, p["g0"], p["g1"], p["g2"], p["depth"], ao, p["shadow"], p["cube"], 3, app.pcfSearchRadius)
     assert np.array_equal(app.mBackBuffer.cpu().numpy(), ref0)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_c5_8k_point_lights_properties(built_lib, oracle):
+    """BASELINE configs[4] size: 7680x4320, 64 point lights (8x8 grid, y = 3, falloff 1 -> 10) + PBR cubemap.
+    Full-size properties (determinism, 8-strip decomposition == whole frame, lights only add light) and the oracle on a
+    band of rows; the 8-GPU all-gather itself is covered by tests/test_sharding_gloo.py."""
+    import torch
+    from crychic_renderer_amd import Context, Crychic, scene
+    W, H, SD = 7680, 4320, 1024
+    ctx = Context(0)
+    pl = scene.make_scene(W, H, shadow_dim=SD, cube_dim=256, device=str(ctx.device))
+    c = pl["consts"]
+    app = Crychic(ctx, W, H, pl["randvec"], pl["cube"], shadow_dim=SD)
+    app.load_scene(pl)
+    app.blurCount, app.numDirLights = 4, 3
+    L = scene.point_light_grid(8)
+    app.Draw()
+    torch.cuda.synchronize()
+    base = app.mBackBuffer.cpu().numpy().copy()
+    app.set_point_lights(L)
+    app.Draw()
+    torch.cuda.synchronize()
+    full = app.mBackBuffer.cpu().numpy().copy()
+    ao = app.mSsao.mAmbientMap0.cpu().numpy().view(np.uint16).copy()
+    assert (full.astype(np.int16) >= base.astype(np.int16)).all() and (full != base).any()
+    app.Draw()
+    torch.cuda.synchronize()
+    assert np.array_equal(app.mBackBuffer.cpu().numpy(), full)
+    app.mBackBuffer.zero_()
+    for rank in range(8):
+        r0, rn = C.c_uint32(), C.c_uint32()
+        built_lib.check(built_lib.lib.crychic_strip_rows(H, 8, rank, C.byref(r0), C.byref(rn)))
+        app.mSsao.mAmbientMap0.fill_(0x5A5A)
+        app.Draw(r0.value, rn.value)
+    torch.cuda.synchronize()
+    assert np.array_equal(app.mBackBuffer.cpu().numpy(), full)
+    del base
+    # oracle on a band through the boxes (the AO plane is the device's own: its parity is test_c3 / test_compute_ssao)
+    p = scene_util.np_planes(pl)
+    pcb = oracle_lib.as_oracle_cb(c.pass_cb, oracle_lib.OrPassConstants)
+    band0, rows = H // 2 + 200, 32
+    ref = oracle.deferred_light(pcb, p["g0"], p["g1"], p["g2"], p["depth"], ao, p["shadow"], p["cube"], 3, app.pcfSearchRadius,
+                                point_lights=as_or_lights(L), row0=band0, rows=rows)
+    assert np.array_equal(full[band0:band0 + rows], ref[band0:band0 + rows])
+    scb = oracle_lib.as_oracle_cb(c.ssao_cb, oracle_lib.OrSsaoConstants)
+    ref_ssao = oracle.ssao(scb, p["normal"], p["depth"], p["randvec"], band0 // 2, rows // 2)
+    a0 = torch.zeros((H // 2, W // 2), dtype=torch.int16, device=ctx.device)
+    built_lib.check(built_lib.lib.crychic_ssao(ctx.handle, C.byref(c.ssao_cb), C.c_void_p(pl["normal"].data_ptr()),
+                                               C.c_void_p(pl["depth"].data_ptr()), C.c_void_p(pl["randvec"].data_ptr()),
+                                               C.c_void_p(a0.data_ptr()), None, W, H, band0 // 2, rows // 2,
+                                               C.c_void_p(torch.cuda.current_stream(ctx.device).cuda_stream)))
+    torch.cuda.synchronize()
+    sl = slice(band0 // 2, band0 // 2 + rows // 2)
+    assert np.array_equal(a0.cpu().numpy().view(np.uint16)[sl], ref_ssao[sl])
+    ctx.close()
