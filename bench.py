@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the frame's launches from a captured hipGraph (auto: when N > 1, where a strip is short enough "
                          "for host launch cost to show)")
+    ap.add_argument("--force-gather", action="store_true",
+                    help="run the strip all-gather (RCCL) even with one rank: exercises the N > 1 code path on a 1-GPU box")
     ap.add_argument("--point-lights", type=int, default=0, help="extension (BASELINE configs[4]): n x n point-light grid, e.g. 8")
     ap.add_argument("--dump-scene", default="", help="write the input planes + constants for tools/prof_driver and exit")
     ap.add_argument("--cpu-band-rows", type=int, default=0, help="full-res rows of the CPU baseline band (0 = auto)")
@@ -190,14 +192,18 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_gather
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
 
     from crychic_renderer_amd import build
     if rank == 0:
         build.build(verbose=False)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     from crychic_renderer_amd import Context, Crychic, scene
     from crychic_renderer_amd._lib import lib, check
@@ -215,7 +221,7 @@ def main():
         dump_scene(args.dump_scene, planes, args, app.pcfSearchRadius)
         return
     row0, rows = sharding.strip_rows(H, world, rank)
-    gather = sharding.FrameGather(W, H, world, rank, dev) if world > 1 else None
+    gather = sharding.FrameGather(W, H, world, rank, dev) if use_dist else None
 
     if args.point_lights:
         app.set_point_lights(scene.point_light_grid(args.point_lights))
@@ -223,22 +229,29 @@ def main():
     # hipGraph: one graph per back-buffer slot replays the ~10 kernel launches of a frame with a single host call.
     use_graph = args.graph == "on" or (args.graph == "auto" and world > 1)
     graphs = {}
+    if use_graph:
+        # Captured up front, before any collective is in flight (thread-local capture mode: the RCCL watchdog thread
+        # may query events meanwhile).  A failed capture falls back to eager launches of the same kernels.
+        try:
+            for buf in (gather.render if gather is not None else [planes["out"]]):
+                app.mBackBuffer = buf
+                app.Draw(row0, rows)              # warm: no lazy allocation inside the capture
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, capture_error_mode="thread_local"):
+                    app.Draw(row0, rows)
+                graphs[buf.data_ptr()] = g
+        except Exception as e:  # noqa: BLE001 -- any capture problem: report and keep going eagerly
+            print("bench.py: hipGraph capture failed (%s); launching eagerly" % e, file=sys.stderr, flush=True)
+            graphs, use_graph = {}, False
+            torch.cuda.synchronize()
 
     def draw(slot_buffer):
-        app.mBackBuffer = slot_buffer
-        if not use_graph:
+        if use_graph:
+            graphs[slot_buffer.data_ptr()].replay()
+        else:
+            app.mBackBuffer = slot_buffer
             app.Draw(row0, rows)
-            return
-        key = slot_buffer.data_ptr()
-        g = graphs.get(key)
-        if g is None:
-            app.Draw(row0, rows)                      # warm (also makes sure no lazy allocation happens inside the capture)
-            torch.cuda.synchronize()
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                app.Draw(row0, rows)
-            graphs[key] = g
-        g.replay()
 
     def step(i):
         if gather is None:
@@ -251,7 +264,7 @@ def main():
         if gather is not None:
             gather.wait_all()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -263,7 +276,7 @@ def main():
         step(i)
     fence()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -320,7 +333,16 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(planes, args, app.pcfSearchRadius)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
+        if args.force_gather and rank == 0:      # self-check of the gather path: the last gathered frame is the rendered one
+            app.mBackBuffer = planes["out"]
+            app.Draw(0, H) if world == 1 else None
+            torch.cuda.synchronize()
+            if world == 1:
+                same = bool(torch.equal(gather.frame(args.steps - 1), planes["out"]))
+                print("bench.py: gathered frame == directly rendered frame: %s" % same, file=sys.stderr, flush=True)
+                if not same:
+                    raise SystemExit(3)
         dist.barrier()
         dist.destroy_process_group()
 
