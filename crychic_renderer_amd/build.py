@@ -16,7 +16,9 @@ LIB = os.path.join(HERE, "libcrychic_hip.so")
 SOURCES = ["kernels.hip", "raster.hip", "api.cpp", "host_constants.cpp", "host_geometry.cpp", "host_textures.cpp"]
 HEADERS = ["devmath.hpp", "ssao_core.hpp", "light_core.hpp", "raster_core.hpp", "kernels.hpp"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
-         "-Wall", "-Wno-unused-function"]
+         # the SLP vectoriser packs scalar fp32 pairs into v_pk_* plus the v_mov that pairs their registers: measured 5 % slower
+         # lighting / blur (profiles/r01_e_relaxed_math_probe.json); the SSAO tap loop is packed by hand where it pays
+         "-fno-slp-vectorize", "-Wall", "-Wno-unused-function"]
 
 
 def _stale():

@@ -4,7 +4,7 @@ import collections, re, subprocess, sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "crychic_renderer_amd/csrc/kernels.hip")
 out = "/tmp/asmstat.s"
-subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-I", ROOT + "/include",
+subprocess.run(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-slp-vectorize", "-I", ROOT + "/include",
                 "-I", ROOT + "/crychic_renderer_amd/csrc", "-S", "--cuda-device-only", src, "-o", out], check=True, stderr=subprocess.DEVNULL)
 lines = open(out).read().split("\n")
 name, ins = None, []
