@@ -1,0 +1,73 @@
+"""Random (incoherent) input planes and perturbed constants for the fuzz parity tests: nothing here looks like a scene --
+the point is to drive every sampler / special-value path (border, clamp, NaN, inf, zero-length vectors, huge shadow
+coordinates) through oracle, kernel bodies and the device with the same bits."""
+import ctypes as C
+
+import numpy as np
+
+
+def random_case(seed, built_lib):
+    from crychic_renderer_amd import scene
+    rng = np.random.default_rng(seed)
+    W = int(rng.integers(17, 100)) * 2
+    H = int(rng.integers(17, 70)) * 2
+    sd = int(rng.choice([16, 64, 130]))
+    cd = int(rng.choice([2, 8, 33]))
+    c = scene.Constants(W, H, shadow_dim=sd)
+    # --- planes -------------------------------------------------------------------------------------------------
+    depth = rng.integers(0, 1 << 24, size=(H, W), dtype=np.uint32)
+    depth[rng.random((H, W)) < 0.25] = 0xFFFFFF                         # uncovered
+    depth[rng.random((H, W)) < 0.05] = 0
+    depth |= rng.integers(0, 256, size=(H, W), dtype=np.uint32) << 24      # stencil byte must be ignored
+    nrm = rng.standard_normal((H, W, 4)).astype(np.float16)
+    sel = rng.random((H, W))
+    nrm[sel < 0.03] = 0.0
+    nrm[(sel >= 0.03) & (sel < 0.04), 0] = np.nan
+    nrm[(sel >= 0.04) & (sel < 0.05), 1] = np.inf
+    nrm[(sel >= 0.05) & (sel < 0.30)] = np.array([0.0, 0.0, -1.0, 0.0], dtype=np.float16)   # flat patches: blur accepts
+    g0 = (rng.standard_normal((H, W, 4)) * 20.0).astype(np.float32); g0[..., 3] = rng.random((H, W))
+    g1 = rng.random((H, W, 4)).astype(np.float32)
+    g2 = rng.standard_normal((H, W, 4)).astype(np.float32)
+    sel = rng.random((H, W))
+    g2[sel < 0.02, :3] = 0.0
+    g0[(sel >= 0.02) & (sel < 0.03), 0] = np.inf
+    g0[(sel >= 0.03) & (sel < 0.04), 1] = np.nan
+    g0[(sel >= 0.04) & (sel < 0.05), :3] = 1e30
+    g1[(sel >= 0.05) & (sel < 0.06), 3] = 0.0
+    g1[(sel >= 0.06) & (sel < 0.07), :3] = -2.0
+    g0[(sel >= 0.07) & (sel < 0.08), :3] = np.array(list(c.cam.pos), dtype=np.float32)
+    g1[(sel >= 0.08) & (sel < 0.09), 3] = np.nan
+    shadow = rng.integers(0, 1 << 24, size=(4, sd, sd), dtype=np.uint32)
+    shadow[:, : sd // 2] |= 0x00F00000                                     # mostly-lit half so compares go both ways
+    cube = rng.integers(0, 256, size=(6, cd, cd, 4), dtype=np.uint8)
+    randvec = rng.integers(0, 256, size=(256, 256, 4), dtype=np.uint8)
+    planes = {"depth": depth, "normal": nrm, "g0": g0, "g1": g1, "g2": g2, "shadow": shadow, "cube": cube, "randvec": randvec}
+    # --- constants ----------------------------------------------------------------------------------------------
+    s, p = c.ssao_cb, c.pass_cb
+    s.OcclusionRadius = float(rng.choice([0.05, 0.5, 3.0]))
+    s.OcclusionFadeStart = float(rng.choice([0.0, 0.2, 1.0]))
+    s.OcclusionFadeEnd = float(rng.choice([1.0, 2.0, s.OcclusionFadeStart]))     # start == end: division by zero
+    s.SurfaceEpsilon = float(rng.choice([0.0, 0.05, 0.5]))
+    for i in range(3):
+        d = rng.standard_normal(3)
+        d = d / np.linalg.norm(d) if rng.random() > 0.1 else np.zeros(3)
+        p.Lights[i].Direction[:] = [float(x) for x in d]
+        p.Lights[i].Strength[:] = [float(x) for x in rng.choice([0.0, 0.1, 1.0, 2.4], size=3)]
+    p.AmbientLight[:] = [float(x) for x in rng.random(4)]
+    # shadow transforms: keep the cascade matrices but shrink them so random world positions land inside the maps
+    for k in range(4):
+        for j in range(16):
+            p.ShadowTransforms[k][j] = float(p.ShadowTransforms[k][j] * rng.choice([0.2, 1.0]))
+    knobs = {
+        "blurCount": int(rng.integers(0, 5)), "numDirLights": int(rng.integers(0, 4)),
+        "pcfSearchRadius": float(rng.choice([0.0, 2.5 / sd, 10.0 / sd])), "sky": int(rng.integers(0, 2)),
+        "ssao_on": bool(rng.random() > 0.15),
+    }
+    return W, H, planes, c, knobs
+
+
+def same_floats(a, b):
+    """Bit equality, except that any NaN equals any NaN (x86 and gfx950 disagree on the sign / payload of generated NaNs)."""
+    a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
+    an, bn = np.isnan(a), np.isnan(b)
+    return bool(np.array_equal(an, bn) and np.array_equal(a.view(np.uint32)[~an], b.view(np.uint32)[~bn]))

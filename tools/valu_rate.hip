@@ -32,6 +32,22 @@ KERNEL(k_mullo, R8, OP8("v_mul_lo_u32 %0, %0, %8\nv_mul_lo_u32 %1, %1, %8\nv_mul
 KERNEL(k_cvt, R8, OP8("v_cvt_f32_u32 %0, %0\nv_cvt_f32_u32 %1, %1\nv_cvt_f32_u32 %2, %2\nv_cvt_f32_u32 %3, %3\nv_cvt_f32_u32 %4, %4\nv_cvt_f32_u32 %5, %5\nv_cvt_f32_u32 %6, %6\nv_cvt_f32_u32 %7, %7"), S8)
 KERNEL(k_floor, R8, OP8("v_floor_f32 %0, %0\nv_floor_f32 %1, %1\nv_floor_f32 %2, %2\nv_floor_f32 %3, %3\nv_floor_f32 %4, %4\nv_floor_f32 %5, %5\nv_floor_f32 %6, %6\nv_floor_f32 %7, %7"), S8)
 
+KERNEL(k_fmac, R8, OP8("v_fmac_f32 %0, %8, %8\nv_fmac_f32 %1, %8, %8\nv_fmac_f32 %2, %8, %8\nv_fmac_f32 %3, %8, %8\nv_fmac_f32 %4, %8, %8\nv_fmac_f32 %5, %8, %8\nv_fmac_f32 %6, %8, %8\nv_fmac_f32 %7, %8, %8"), S8)
+KERNEL(k_mul64, R8, OP8("v_mul_f32_e64 %0, %0, %8\nv_mul_f32_e64 %1, %1, %8\nv_mul_f32_e64 %2, %2, %8\nv_mul_f32_e64 %3, %3, %8\nv_mul_f32_e64 %4, %4, %8\nv_mul_f32_e64 %5, %5, %8\nv_mul_f32_e64 %6, %6, %8\nv_mul_f32_e64 %7, %7, %8"), S8)
+KERNEL(k_max, R8, OP8("v_max_f32 %0, %0, %8\nv_max_f32 %1, %1, %8\nv_max_f32 %2, %2, %8\nv_max_f32 %3, %3, %8\nv_max_f32 %4, %4, %8\nv_max_f32 %5, %5, %8\nv_max_f32 %6, %6, %8\nv_max_f32 %7, %7, %8"), S8)
+KERNEL(k_and, R8, OP8("v_and_b32 %0, %0, %8\nv_and_b32 %1, %1, %8\nv_and_b32 %2, %2, %8\nv_and_b32 %3, %3, %8\nv_and_b32 %4, %4, %8\nv_and_b32 %5, %5, %8\nv_and_b32 %6, %6, %8\nv_and_b32 %7, %7, %8"), S8)
+KERNEL(k_addu, R8, OP8("v_add_u32 %0, %0, %8\nv_add_u32 %1, %1, %8\nv_add_u32 %2, %2, %8\nv_add_u32 %3, %3, %8\nv_add_u32 %4, %4, %8\nv_add_u32 %5, %5, %8\nv_add_u32 %6, %6, %8\nv_add_u32 %7, %7, %8"), S8)
+KERNEL(k_lshl, R8, OP8("v_lshlrev_b32 %0, 1, %0\nv_lshlrev_b32 %1, 1, %1\nv_lshlrev_b32 %2, 1, %2\nv_lshlrev_b32 %3, 1, %3\nv_lshlrev_b32 %4, 1, %4\nv_lshlrev_b32 %5, 1, %5\nv_lshlrev_b32 %6, 1, %6\nv_lshlrev_b32 %7, 1, %7"), S8)
+KERNEL(k_cmp, R8, OP8("v_cmp_gt_f32 vcc, %0, %8\nv_cmp_gt_f32 vcc, %1, %8\nv_cmp_gt_f32 vcc, %2, %8\nv_cmp_gt_f32 vcc, %3, %8\nv_cmp_gt_f32 vcc, %4, %8\nv_cmp_gt_f32 vcc, %5, %8\nv_cmp_gt_f32 vcc, %6, %8\nv_cmp_gt_f32 vcc, %7, %8"), S8)
+KERNEL(k_cmp64, R8, OP8("v_cmp_gt_f32_e64 s[20:21], %0, %8\nv_cmp_gt_f32_e64 s[20:21], %1, %8\nv_cmp_gt_f32_e64 s[20:21], %2, %8\nv_cmp_gt_f32_e64 s[20:21], %3, %8\nv_cmp_gt_f32_e64 s[20:21], %4, %8\nv_cmp_gt_f32_e64 s[20:21], %5, %8\nv_cmp_gt_f32_e64 s[20:21], %6, %8\nv_cmp_gt_f32_e64 s[20:21], %7, %8"), S8)
+KERNEL(k_cmpcnd, R8, OP8("v_cmp_gt_f32 vcc, %0, %8\nv_cndmask_b32 %0, %0, %8, vcc\nv_cmp_gt_f32 vcc, %1, %8\nv_cndmask_b32 %1, %1, %8, vcc\nv_cmp_gt_f32 vcc, %2, %8\nv_cndmask_b32 %2, %2, %8, vcc\nv_cmp_gt_f32 vcc, %3, %8\nv_cndmask_b32 %3, %3, %8, vcc\nv_cmp_gt_f32 vcc, %4, %8\nv_cndmask_b32 %4, %4, %8, vcc\nv_cmp_gt_f32 vcc, %5, %8\nv_cndmask_b32 %5, %5, %8, vcc\nv_cmp_gt_f32 vcc, %6, %8\nv_cndmask_b32 %6, %6, %8, vcc\nv_cmp_gt_f32 vcc, %7, %8\nv_cndmask_b32 %7, %7, %8, vcc"), S8)
+KERNEL(k_cnd64, R8, OP8("v_cndmask_b32_e64 %0, %0, %8, s[20:21]\nv_cndmask_b32_e64 %1, %1, %8, s[20:21]\nv_cndmask_b32_e64 %2, %2, %8, s[20:21]\nv_cndmask_b32_e64 %3, %3, %8, s[20:21]\nv_cndmask_b32_e64 %4, %4, %8, s[20:21]\nv_cndmask_b32_e64 %5, %5, %8, s[20:21]\nv_cndmask_b32_e64 %6, %6, %8, s[20:21]\nv_cndmask_b32_e64 %7, %7, %8, s[20:21]"), S8)
+KERNEL(k_med3, R8, OP8("v_med3_f32 %0, %0, %8, %8\nv_med3_f32 %1, %1, %8, %8\nv_med3_f32 %2, %2, %8, %8\nv_med3_f32 %3, %3, %8, %8\nv_med3_f32 %4, %4, %8, %8\nv_med3_f32 %5, %5, %8, %8\nv_med3_f32 %6, %6, %8, %8\nv_med3_f32 %7, %7, %8, %8"), S8)
+KERNEL(k_cvti, R8, OP8("v_cvt_i32_f32 %0, %0\nv_cvt_i32_f32 %1, %1\nv_cvt_i32_f32 %2, %2\nv_cvt_i32_f32 %3, %3\nv_cvt_i32_f32 %4, %4\nv_cvt_i32_f32 %5, %5\nv_cvt_i32_f32 %6, %6\nv_cvt_i32_f32 %7, %7"), S8)
+KERNEL(k_frexp, R8, OP8("v_frexp_mant_f32 %0, %0\nv_frexp_mant_f32 %1, %1\nv_frexp_mant_f32 %2, %2\nv_frexp_mant_f32 %3, %3\nv_frexp_mant_f32 %4, %4\nv_frexp_mant_f32 %5, %5\nv_frexp_mant_f32 %6, %6\nv_frexp_mant_f32 %7, %7"), S8)
+KERNEL(k_ldexp, R8, OP8("v_ldexp_f32 %0, %0, 1\nv_ldexp_f32 %1, %1, 1\nv_ldexp_f32 %2, %2, 1\nv_ldexp_f32 %3, %3, 1\nv_ldexp_f32 %4, %4, 1\nv_ldexp_f32 %5, %5, 1\nv_ldexp_f32 %6, %6, 1\nv_ldexp_f32 %7, %7, 1"), S8)
+KERNEL(k_mov, R8, OP8("v_mov_b32 %0, %8\nv_mov_b32 %1, %8\nv_mov_b32 %2, %8\nv_mov_b32 %3, %8\nv_mov_b32 %4, %8\nv_mov_b32 %5, %8\nv_mov_b32 %6, %8\nv_mov_b32 %7, %8"), S8)
+
 #define P4 v2f p0 = { a + threadIdx.x, a }, p1 = p0 + 1.0f, p2 = p0 + 2.0f, p3 = p0 + 3.0f, p4 = p0 + 4.0f, p5 = p0 + 5.0f, p6 = p0 + 6.0f, p7 = p0 + 7.0f; v2f pb = { b, b }
 #define PS ((p0 + p1 + p2 + p3 + p4 + p5 + p6 + p7).x)
 #define POP8(ASM) asm volatile(ASM "\n" : "+v"(p0), "+v"(p1), "+v"(p2), "+v"(p3), "+v"(p4), "+v"(p5), "+v"(p6), "+v"(p7) : "v"(pb))
@@ -53,6 +69,10 @@ int main()
         { "v_pk_fma_f32", k_pkfma }, { "v_rcp_f32", k_rcp }, { "v_sqrt_f32", k_sqrt }, { "v_cndmask_b32", k_cndmask },
         { "v_div_scale_f32", k_divscale }, { "v_div_fixup_f32", k_divfixup }, { "v_mul_u32_u24", k_mulu24 }, { "v_mul_lo_u32", k_mullo },
         { "v_cvt_f32_u32", k_cvt }, { "v_floor_f32", k_floor },
+        { "v_fmac_f32 (VOP2)", k_fmac }, { "v_mul_f32_e64", k_mul64 }, { "v_max_f32", k_max }, { "v_and_b32", k_and }, { "v_add_u32", k_addu },
+        { "v_lshlrev_b32", k_lshl }, { "v_cmp_gt_f32 vcc", k_cmp }, { "v_cmp_gt_f32_e64 sgpr", k_cmp64 }, { "v_cmp+v_cndmask (x2)", k_cmpcnd },
+        { "v_cndmask_e64 sgpr", k_cnd64 }, { "v_med3_f32", k_med3 }, { "v_cvt_i32_f32", k_cvti }, { "v_frexp_mant_f32", k_frexp },
+        { "v_ldexp_f32", k_ldexp }, { "v_mov_b32", k_mov },
     };
     hipEvent_t e0, e1;
     CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
