@@ -97,6 +97,7 @@ PROTOTYPES = {
     "crychic_deferred_light_points": (_i, [_vp, _P(PassConstants), _vp, _vp, _vp, _vp, _vp, _P(_vp), _u32, _vp, _u32, _vp,
                                            _vp, _u32, _u32, _u32, _u32, _i, _f, _u32, _vp, _u32, _vp]),
     "crychic_draw_hot_path": (_i, [_vp, _P(SsaoConstants), _P(PassConstants), _P(FrameDesc), _vp]),
+    "crychic_frustum_cull": (_i, [_P(Camera), _P(_f), _P(_f), _vp, _u32, _vp]),
     "crychic_ctx_set_profiling": (_i, [_vp, _i]),
     "crychic_ctx_last_pass_times": (_i, [_vp, _P(PassTimes)]),
     "crychic_strip_rows": (_i, [_u32, _i, _i, _P(_u32), _P(_u32)]),

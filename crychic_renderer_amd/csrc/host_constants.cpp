@@ -3,6 +3,7 @@
 // 392-402, 423-462) and CRYCHIC::UpdateCascadeShadowTransform / UpdateMainPassCB / UpdateSsaoCB
 // (CRYCHIC.cpp:634-937).  DirectXMath is replaced by a small row-vector Mat4 (LH, row-major) with the same
 // constructor definitions; values are stored transposed exactly where the reference calls XMMatrixTranspose.
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include "crychic_hip.h"
@@ -341,6 +342,58 @@ int crychic_update_ssao_cb(const crychic_camera* cam, uint32_t W, uint32_t H, co
     out->OcclusionFadeEnd = 1.0f;
     out->SurfaceEpsilon = 0.05f;
     return 0;
+}
+
+// CRYCHIC::UpdateInstanceData's visibility test, CRYCHIC.cpp:515-564, with the frustum of CRYCHIC.cpp:115.
+// DirectXCollision is not part of the reference checkout; this restates its published behaviour:
+//   BoundingFrustum::CreateFromMatrix(proj): origin 0, identity orientation, slopes +-1/P00 and +-1/P11, near / far;
+//   Transform(viewToLocal): rotation = the matrix's normalised rows, origin = its translation, near / far scaled by the
+//     largest row length (uniform scale assumed), slopes kept;
+//   Contains(BoundingBox) != DISJOINT: six outward planes, each normalised; the box is outside a plane when
+//     dot(center, n) + d > dot(extents, |n|).
+int crychic_frustum_cull(const crychic_camera* cam, const float boundsCenter[3], const float boundsExtents[3],
+                         const float* worlds, uint32_t count, uint8_t* visible)
+{
+    if (!cam || !boundsCenter || !boundsExtents || (count && (!worlds || !visible))) return CRYCHIC_E_INVALID_ARG;
+    const Mat4 view = camera_view(*cam);
+    const Mat4 proj = perspective_fov_lh(cam->fovY, cam->aspect, cam->nearZ, cam->farZ);
+    Mat4 invView;
+    if (!inverse(view, invView)) return CRYCHIC_E_INVALID_ARG;
+    const float rs = 1.0f / proj.m[0][0], ts = 1.0f / proj.m[1][1];
+    int nvis = 0;
+    for (uint32_t i = 0; i < count; ++i) {
+        Mat4 world, invWorld;
+        std::memcpy(world.m, worlds + 16 * (size_t)i, sizeof world.m);
+        if (!inverse(world, invWorld)) { visible[i] = 1; ++nvis; continue; }   // degenerate instance: never culled
+        const Mat4 m = invView * invWorld;                                     // view space -> the instance's local space
+        V3 r[3];
+        float scale2 = 0.0f;
+        for (int k = 0; k < 3; ++k) {
+            const V3 row{ m.m[k][0], m.m[k][1], m.m[k][2] };
+            scale2 = std::max(scale2, dot(row, row));
+            r[k] = normalize(row);
+        }
+        const float scale = std::sqrt(scale2);
+        const V3 origin{ m.m[3][0], m.m[3][1], m.m[3][2] };
+        const float zn = cam->nearZ * scale, zf = cam->farZ * scale;
+        // frustum-space planes (n, d): near, far, right, left, top, bottom
+        const float pl[6][4] = { { 0, 0, -1, zn }, { 0, 0, 1, -zf }, { 1, 0, -rs, 0 }, { -1, 0, -rs, 0 }, { 0, 1, -ts, 0 }, { 0, -1, -ts, 0 } };
+        bool outside = false;
+        for (int p = 0; p < 6 && !outside; ++p) {
+            V3 n{ pl[p][0] * r[0].x + pl[p][1] * r[1].x + pl[p][2] * r[2].x, pl[p][0] * r[0].y + pl[p][1] * r[1].y + pl[p][2] * r[2].y,
+                  pl[p][0] * r[0].z + pl[p][1] * r[1].z + pl[p][2] * r[2].z };
+            float d = pl[p][3] - dot(n, origin);
+            const float len = std::sqrt(dot(n, n));
+            n = V3{ n.x / len, n.y / len, n.z / len };
+            d /= len;
+            const float dist = n.x * boundsCenter[0] + n.y * boundsCenter[1] + n.z * boundsCenter[2] + d;
+            const float radius = std::fabs(n.x) * boundsExtents[0] + std::fabs(n.y) * boundsExtents[1] + std::fabs(n.z) * boundsExtents[2];
+            outside = dist > radius;
+        }
+        visible[i] = outside ? 0 : 1;
+        nvis += outside ? 0 : 1;
+    }
+    return nvis;
 }
 
 float crychic_pcf_search_radius(uint32_t width, int literal)

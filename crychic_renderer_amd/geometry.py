@@ -62,6 +62,28 @@ def make_instances(worlds, material_indices):
     return inst
 
 
+def mesh_bounds(vertices):
+    """BoundingBox of a mesh as the reference builds it (min / max of the positions -> center, extents; CRYCHIC.cpp:1318-1337)."""
+    pos = vertices["Pos"]
+    lo, hi = pos.min(axis=0), pos.max(axis=0)
+    return (0.5 * (lo + hi)).astype(np.float32), (0.5 * (hi - lo)).astype(np.float32)
+
+
+def frustum_cull(cam, vertices, instances):
+    """CRYCHIC::UpdateInstanceData (CRYCHIC.cpp:515-564, culling enabled as in CRYCHIC.h:188): the instances whose
+    bounding box is not DISJOINT from the camera frustum, in their original order (crychic_frustum_cull)."""
+    if len(instances) == 0:
+        return instances
+    center, extents = mesh_bounds(vertices)
+    # the instance records hold World transposed (GPU layout); the test wants the row-vector matrix back
+    worlds = np.ascontiguousarray(instances["World"].reshape(len(instances), 4, 4).transpose(0, 2, 1), dtype=np.float32)
+    vis = np.zeros(len(instances), np.uint8)
+    n = lib.crychic_frustum_cull(C.byref(cam), center.ctypes.data_as(C.POINTER(C.c_float)), extents.ctypes.data_as(C.POINTER(C.c_float)),
+                                 worlds.ctypes.data, len(instances), vis.ctypes.data)
+    check(min(n, 0))
+    return instances[vis.astype(bool)]
+
+
 def reference_materials():
     """CRYCHIC::BuildMaterials (CRYCHIC.cpp:1768-1821); Metalness is never assigned, so the MaterialData default 0.5
     reaches the GPU (FrameResource.h:25, CRYCHIC.cpp:578-586)."""
@@ -82,9 +104,10 @@ def reference_materials():
     return m
 
 
-def cascade_scene_items(shadow_layer=False):
+def cascade_scene_items(shadow_layer=False, cull_camera=None):
     """The Opaque (or OpaqueShadow) render items of CRYCHIC::BuildCascadeShadowRenderItems[WithShadow]
-    (CRYCHIC.cpp:2322-2375, 2380-2435): 100 instanced boxes + the grid.  Returns [(vertices, indices, instances), ...]."""
+    (CRYCHIC.cpp:2322-2375, 2380-2435): 100 instanced boxes + the grid.  Returns [(vertices, indices, instances), ...].
+    With `cull_camera` the instance lists are what UpdateInstanceData uploads for that camera (frustum culling on)."""
     box = create_box(1.0, 1.0, 1.0, 3)              # CRYCHIC.cpp:1253
     grid = create_grid(20.0, 30.0, 60, 40)          # CRYCHIC.cpp:1254
     worlds, mats = [], []
@@ -94,6 +117,9 @@ def cascade_scene_items(shadow_layer=False):
             mats.append(i % 3 if shadow_layer else i % 2)
     box_inst = make_instances(worlds, mats)
     grid_inst = make_instances([world_matrix((3.0, 3.0, 3.0))], [1 if shadow_layer else 3])
+    if cull_camera is not None:
+        box_inst = frustum_cull(cull_camera, box[0], box_inst)
+        grid_inst = frustum_cull(cull_camera, grid[0], grid_inst)
     return [(box[0], box[1], box_inst), (grid[0], grid[1], grid_inst)]
 
 

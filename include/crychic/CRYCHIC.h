@@ -7,6 +7,7 @@
 // the reference's live scene (100 instanced boxes + grid, CRYCHIC.cpp:2274-2436).  Set mRunProducerPasses = false to
 // feed externally produced planes through the Resource accessors instead.
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <memory>
@@ -29,25 +30,66 @@ private:
     float mTotal = 0.0f, mDelta = 0.0f;
 };
 
-class Camera {  // Common/Camera.h:20-97 (the subset the constant builders consume)
+class Camera {  // Common/Camera.h:20-97: position / look / up state; the matrices are rebuilt from it by the C ABI's builders
 public:
     void SetPosition(float x, float y, float z) { mCam.pos[0] = x; mCam.pos[1] = y; mCam.pos[2] = z; }
     void SetLens(float fovY, float aspect, float zn, float zf) { mCam.fovY = fovY; mCam.aspect = aspect; mCam.nearZ = zn; mCam.farZ = zf; }
     void LookTo(float lx, float ly, float lz, float ux, float uy, float uz) { mCam.look[0] = lx; mCam.look[1] = ly; mCam.look[2] = lz; mCam.up[0] = ux; mCam.up[1] = uy; mCam.up[2] = uz; }
+    void LookAt(const DirectX::XMFLOAT3& pos, const DirectX::XMFLOAT3& target, const DirectX::XMFLOAT3& up)   // Camera.cpp:131-154
+    {
+        SetPosition(pos.x, pos.y, pos.z);
+        LookTo(target.x - pos.x, target.y - pos.y, target.z - pos.z, up.x, up.y, up.z);
+        UpdateViewMatrix();
+    }
+    DirectX::XMFLOAT3 GetPosition3f() const { return { mCam.pos[0], mCam.pos[1], mCam.pos[2] }; }
+    DirectX::XMFLOAT3 GetLook3f() const { return { mCam.look[0], mCam.look[1], mCam.look[2] }; }
+    DirectX::XMFLOAT3 GetUp3f() const { return { mCam.up[0], mCam.up[1], mCam.up[2] }; }
+    DirectX::XMFLOAT3 GetRight3f() const { float r[3]; Cross(mCam.up, mCam.look, r); Normalize(r); return { r[0], r[1], r[2] }; }
+    void Walk(float d) { for (int i = 0; i < 3; ++i) mCam.pos[i] += d * mCam.look[i]; }                    // Camera.cpp:190-199
+    void Strafe(float d) { float r[3]; Cross(mCam.up, mCam.look, r); Normalize(r); for (int i = 0; i < 3; ++i) mCam.pos[i] += d * r[i]; }  // :179-188
+    void Pitch(float angle)                                                                                // :201-211, about the right vector
+    {
+        float r[3]; Cross(mCam.up, mCam.look, r); Normalize(r);
+        Rotate(mCam.up, r, angle); Rotate(mCam.look, r, angle);
+    }
+    void RotateY(float angle)                                                                              // :213-224, about the world y axis
+    {
+        const float y[3] = { 0.0f, 1.0f, 0.0f };
+        Rotate(mCam.up, y, angle); Rotate(mCam.look, y, angle);
+    }
+    void UpdateViewMatrix()                                                                                // :226-273: re-orthonormalise
+    {
+        float r[3], u[3];
+        Normalize(mCam.look);
+        Cross(mCam.up, mCam.look, r); Normalize(r);
+        Cross(mCam.look, r, u); Normalize(u);
+        for (int i = 0; i < 3; ++i) mCam.up[i] = u[i];
+    }
     float GetNearZ() const { return mCam.nearZ; }
     float GetFarZ() const { return mCam.farZ; }
     float GetFovY() const { return mCam.fovY; }
     float GetAspect() const { return mCam.aspect; }
     const crychic_camera& Raw() const { return mCam; }
 private:
+    static void Cross(const float a[3], const float b[3], float o[3]) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; }
+    static void Normalize(float v[3]) { const float l = std::sqrt(v[0] * v[0] + v[1] * v[1] + v[2] * v[2]); v[0] /= l; v[1] /= l; v[2] /= l; }
+    static void Rotate(float v[3], const float axis[3], float angle)   // Rodrigues; left-handed like XMMatrixRotationAxis (clockwise looking along the axis towards the origin)
+    {
+        const float c = std::cos(angle), s = std::sin(angle);
+        float k[3]; Cross(axis, v, k);
+        const float d = (axis[0] * v[0] + axis[1] * v[1] + axis[2] * v[2]) * (1.0f - c);
+        for (int i = 0; i < 3; ++i) v[i] = v[i] * c + k[i] * s + axis[i] * d;
+    }
     crychic_camera mCam = { { 0, 0, 0 }, { 0, 0, 1 }, { 0, 1, 0 }, 0.7853981634f, 1.0f, 1.0f, 1000.0f };
 };
 
 // Common/d3dUtil.h:163-214 (the fields the draws consume)
+struct BoundingBox { DirectX::XMFLOAT3 Center = { 0, 0, 0 }, Extents = { 1, 1, 1 }; };   // DirectXCollision's, as far as the culling needs it
 struct SubmeshGeometry {
     UINT IndexCount = 0;
     UINT StartIndexLocation = 0;
     int BaseVertexLocation = 0;
+    BoundingBox Bounds;
 };
 struct MeshGeometry {
     std::string Name;
@@ -79,6 +121,7 @@ struct RenderItem {
     UINT InstanceCount = 0;
     std::vector<InstanceData> Instances;
     UINT itemIndex = 0;
+    BoundingBox Bounds;
 };
 enum class RenderLayer : int { Opaque = 0, OpaqueShadow, Count };  // CRYCHIC.h:44-54 (the layers the deferred path draws)
 
@@ -210,6 +253,7 @@ public:
     int mNumDirLights = 1;      // NUM_DIR_LIGHTS of the deferred shader (Common.hlsl:6-8)
     bool mPcfLiteral = true;    // Common.hlsl:305 evaluated as written
     bool mSkyEnabled = true;
+    bool mFrustumCullingEnabled = true;   // CRYCHIC.h:188
     UINT mShadowMapSize = 4096; // CRYCHIC.cpp:48-49
     DirectX::XMFLOAT4X4 mLightViews[MaxLights], mLightProjs[MaxLights], mShadowTransforms[MaxLights];  // CRYCHIC.h:166-170
     FrameResource* mCurrFrameResource = nullptr;
@@ -233,8 +277,17 @@ private:
         geo->VertexBufferGPU->Upload(v.data(), v.size() * sizeof(crychic_vertex), mCommandList->Stream());
         geo->IndexBufferGPU->Upload(idx.data(), idx.size() * 4, mCommandList->Stream());
         mCommandList->Flush();
-        geo->DrawArgs["box"] = SubmeshGeometry{ nbI, 0, 0 };                                            // :1271-1301
-        geo->DrawArgs["grid"] = SubmeshGeometry{ ngI, nbI, nbV };
+        auto bounds = [&](size_t first, size_t count) {                                                 // :1318-1337: min / max of the positions
+            float lo[3] = { 3.4e38f, 3.4e38f, 3.4e38f }, hi[3] = { -3.4e38f, -3.4e38f, -3.4e38f };
+            for (size_t k = first; k < first + count; ++k)
+                for (int c = 0; c < 3; ++c) { lo[c] = std::min(lo[c], v[k].Pos[c]); hi[c] = std::max(hi[c], v[k].Pos[c]); }
+            BoundingBox b;
+            b.Center = { 0.5f * (lo[0] + hi[0]), 0.5f * (lo[1] + hi[1]), 0.5f * (lo[2] + hi[2]) };
+            b.Extents = { 0.5f * (hi[0] - lo[0]), 0.5f * (hi[1] - lo[1]), 0.5f * (hi[2] - lo[2]) };
+            return b;
+        };
+        geo->DrawArgs["box"] = SubmeshGeometry{ nbI, 0, 0, bounds(0, (size_t)nbV) };                   // :1271-1301
+        geo->DrawArgs["grid"] = SubmeshGeometry{ ngI, nbI, nbV, bounds((size_t)nbV, (size_t)ngV) };
         mGeometries[geo->Name] = std::move(geo);
     }
     void BuildMaterials()  // CRYCHIC.cpp:1768-1821
@@ -264,6 +317,7 @@ private:
         box->IndexCount = geo->DrawArgs["box"].IndexCount;
         box->StartIndexLocation = geo->DrawArgs["box"].StartIndexLocation;
         box->BaseVertexLocation = geo->DrawArgs["box"].BaseVertexLocation;
+        box->Bounds = geo->DrawArgs["box"].Bounds;                                                   // :1882
         box->Instances.resize(100);
         box->InstanceCount = 100;
         for (int i = 0; i < 10; ++i)
@@ -280,6 +334,7 @@ private:
         grid->IndexCount = geo->DrawArgs["grid"].IndexCount;
         grid->StartIndexLocation = geo->DrawArgs["grid"].StartIndexLocation;
         grid->BaseVertexLocation = geo->DrawArgs["grid"].BaseVertexLocation;
+        grid->Bounds = geo->DrawArgs["grid"].Bounds;                                                 // :1930
         grid->Instances.resize(1);
         grid->InstanceCount = 1;
         grid->Instances[0].World = ScaleTranslate(3.0f, 0.0f, 0.0f, 0.0f);                            // :2371, 2431
@@ -305,12 +360,23 @@ private:
         for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) t.m[i][j] = a.m[j][i];
         return t;
     }
-    void UpdateInstanceData(const GameTimer&)  // CRYCHIC.cpp:515-564 (frustum culling off: every instance is copied; culled instances are invisible anyway)
+    void UpdateInstanceData(const GameTimer&)  // CRYCHIC.cpp:515-564: only instances that pass the frustum test reach the instance buffer
     {
+        std::vector<uint8_t> visible;
         for (auto& ri : mAllRitems) {
             auto* buf = mCurrFrameResource->InstanceBuffers[ri->itemIndex].get();
+            visible.assign(ri->Instances.size(), 1);
+            if (mFrustumCullingEnabled && !ri->Instances.empty()) {                                   // :543-544
+                std::vector<float> worlds(ri->Instances.size() * 16);
+                for (size_t k = 0; k < ri->Instances.size(); ++k) std::memcpy(&worlds[16 * k], ri->Instances[k].World.m, 64);
+                const float c[3] = { ri->Bounds.Center.x, ri->Bounds.Center.y, ri->Bounds.Center.z };
+                const float e[3] = { ri->Bounds.Extents.x, ri->Bounds.Extents.y, ri->Bounds.Extents.z };
+                CrychicThrowIfFailed(std::min(0, crychic_frustum_cull(&mCamera.Raw(), c, e, worlds.data(), (uint32_t)ri->Instances.size(), visible.data())));
+            }
             int n = 0;
-            for (const InstanceData& src : ri->Instances) {
+            for (size_t k = 0; k < ri->Instances.size(); ++k) {
+                if (!visible[k]) continue;
+                const InstanceData& src = ri->Instances[k];
                 InstanceData data;
                 data.World = Transposed(src.World);                                                   // :546
                 data.TexTransform = Transposed(src.TexTransform);                                     // :547

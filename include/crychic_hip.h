@@ -275,6 +275,14 @@ int crychic_create_grid(float width, float depth, uint32_t m, uint32_t n, crychi
 int crychic_load_mesh_text(const char* path, crychic_vertex* vertices, uint32_t vertexCapacity, uint32_t* indices,
                            uint32_t indexCapacity, uint32_t* vertexCount, uint32_t* indexCount);
 
+/* CRYCHIC::UpdateInstanceData's frustum culling (CRYCHIC.cpp:515-564; mFrustumCullingEnabled defaults to true,
+ * CRYCHIC.h:188): visible[i] = 1 when the render item's local-space bounding box (center, extents) under world matrix
+ * worlds[16 i ..] (row-major, row-vector convention, untransposed) is not DISJOINT from the camera frustum.  Only visible
+ * instances are copied to the frame's instance buffer, so a culled instance is also missing from the shadow pass.
+ * Returns the number of visible instances (>= 0) or a negative status. */
+int crychic_frustum_cull(const crychic_camera* cam, const float boundsCenter[3], const float boundsExtents[3],
+                         const float* worlds, uint32_t count, uint8_t* visible);
+
 /* Material textures: a DDS file holding DXT1, DXT5 or 32-bit-mask pixels (the formats of the six
  * textures CRYCHIC::LoadTextures opens, CRYCHIC.cpp:939-973) decoded on the host to the R8G8B8A8 mip-0 image that
  * crychic_draw_gbuffer samples.  NULL buffer: only *width / *height are written.  Replaces the subset of

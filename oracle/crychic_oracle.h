@@ -122,6 +122,8 @@ void or_cascade_shadow_transforms(const or_camera* cam, const float lightDir[3],
 
 /* CRYCHIC::UpdateMainPassCB  CRYCHIC.cpp:817-868 (ShadowTransforms[4..11] are zero-filled here; the
  * reference copies uninitialised members, CRYCHIC.cpp:837-841). */
+int or_frustum_cull(const or_camera* cam, const float center[3], const float extents[3], const float* worlds, uint32_t count,
+                    uint8_t* visible, double* margin);
 void or_build_pass_constants(const or_camera* cam, uint32_t W, uint32_t H, const float shadowTransform[4][16],
                              const float lightDirs[3][3], or_pass_constants* out);
 

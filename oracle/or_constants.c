@@ -312,3 +312,37 @@ _Static_assert(offsetof(or_pass_constants, Lights) == 1280, "Lights@1280");
 _Static_assert(offsetof(or_ssao_constants, OffsetVectors) == 192, "OffsetVectors@192");
 _Static_assert(offsetof(or_ssao_constants, BlurWeights) == 416, "BlurWeights@416");
 _Static_assert(offsetof(or_ssao_constants, OcclusionRadius) == 480, "OcclusionRadius@480");
+
+/* CRYCHIC::UpdateInstanceData visibility (CRYCHIC.cpp:515-564), stated geometrically and in double precision: the
+ * instance's bounding box is DISJOINT from the frustum exactly when all eight corners lie outside one of the six clip
+ * planes of world * view * proj.  margin[i] (optional) = min over planes of the largest corner "insideness"
+ * (>= 0 <=> visible); the product's float plane test may only disagree where |margin| is at rounding level. */
+int or_frustum_cull(const or_camera* cam, const float center[3], const float extents[3], const float* worlds, uint32_t count,
+                    uint8_t* visible, double* margin)
+{
+    float view[16], proj[16];
+    camera_view(cam, view);
+    or_mat_perspective_fov_lh(cam->fovY, cam->aspect, cam->nearZ, cam->farZ, proj);
+    int nvis = 0;
+    for (uint32_t i = 0; i < count; ++i) {
+        const float* w = worlds + 16 * (size_t)i;
+        double best[6];
+        for (int p = 0; p < 6; ++p) best[p] = -1e300;
+        for (int c = 0; c < 8; ++c) {
+            double l[4] = { center[0] + ((c & 1) ? extents[0] : -extents[0]), center[1] + ((c & 2) ? extents[1] : -extents[1]),
+                            center[2] + ((c & 4) ? extents[2] : -extents[2]), 1.0 };
+            double a[4], b[4], h[4];
+            for (int j = 0; j < 4; ++j) a[j] = l[0] * w[j] + l[1] * w[4 + j] + l[2] * w[8 + j] + l[3] * w[12 + j];
+            for (int j = 0; j < 4; ++j) b[j] = a[0] * view[j] + a[1] * view[4 + j] + a[2] * view[8 + j] + a[3] * view[12 + j];
+            for (int j = 0; j < 4; ++j) h[j] = b[0] * proj[j] + b[1] * proj[4 + j] + b[2] * proj[8 + j] + b[3] * proj[12 + j];
+            const double s[6] = { h[2], h[3] - h[2], h[3] - h[0], h[3] + h[0], h[3] - h[1], h[3] + h[1] };
+            for (int p = 0; p < 6; ++p) if (s[p] > best[p]) best[p] = s[p];
+        }
+        double m = best[0];
+        for (int p = 1; p < 6; ++p) if (best[p] < m) m = best[p];
+        if (margin) margin[i] = m;
+        visible[i] = m >= 0.0 ? 1 : 0;
+        nvis += visible[i];
+    }
+    return nvis;
+}

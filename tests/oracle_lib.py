@@ -77,6 +77,7 @@ class Oracle:
         L.or_cascade_shadow_transforms.argtypes = [vp, vp, u32, vp, vp, vp]
         L.or_build_pass_constants.argtypes = [vp, u32, u32, vp, vp, vp]
         L.or_build_ssao_constants.argtypes = [vp, u32, u32, vp, vp]
+        L.or_frustum_cull.restype = i; L.or_frustum_cull.argtypes = [vp, vp, vp, vp, u32, vp, vp]
         L.or_ssao.argtypes = [vp, vp, vp, vp, u32, u32, vp, u32, u32]
         L.or_ssao_blur.argtypes = [vp, vp, vp, vp, vp, u32, u32, i, u32, u32]
         L.or_compute_ssao.argtypes = [vp, vp, vp, vp, u32, u32, vp, vp, i]

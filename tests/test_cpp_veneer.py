@@ -81,7 +81,11 @@ def test_veneer_full_scene_matches_oracle(built_lib, oracle, tmp_path):
     # the driver's own constant buffers (same builders, same camera) drive the oracle
     C.memmove(C.addressof(consts.ssao_cb), open(d + "/ssao_cb.bin", "rb").read(), C.sizeof(consts.ssao_cb))
     C.memmove(C.addressof(consts.pass_cb), open(d + "/pass_cb.bin", "rb").read(), C.sizeof(consts.pass_cb))
-    ref = raster_util.oracle_frame(oracle, consts, g.cascade_scene_items(), g.cascade_scene_items(shadow_layer=True), g.reference_materials(),
+    # UpdateInstanceData culls against the camera frustum (CRYCHIC.h:188): culled boxes are missing from the shadow pass too
+    cam = scene.default_camera(W, H)
+    items, shadow_items = g.cascade_scene_items(cull_camera=cam), g.cascade_scene_items(shadow_layer=True, cull_camera=cam)
+    assert len(items[0][2]) < 100
+    ref = raster_util.oracle_frame(oracle, consts, items, shadow_items, g.reference_materials(),
                                    None, W, H, SD, cube, BC, NL, built_lib.lib.crychic_pcf_search_radius(SD, 1))
     for k in range(4):
         assert np.array_equal(np.fromfile(d + "/shadow%d_out.bin" % k, np.uint32).reshape(SD, SD), ref["shadow"][k]), k
