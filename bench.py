@@ -136,8 +136,7 @@ def time_producers(ctx, planes, args, torch):
     def run():
         for k in range(4):
             sgeo.DrawSceneToShadowMap(cbs[k], shadow[k])
-        geo.DrawNormalsAndDepth(consts.pass_cb, normal, depth)
-        geo.DrawGBuffer(consts.pass_cb, gb, depth)
+        geo.DrawNormalsDepthAndGBuffer(consts.pass_cb, normal, gb, depth)
 
     run()
     torch.cuda.synchronize()
@@ -149,8 +148,7 @@ def time_producers(ctx, planes, args, torch):
         for k in range(4):
             sgeo.DrawSceneToShadowMap(cbs[k], shadow[k])
         e1.record()
-        geo.DrawNormalsAndDepth(consts.pass_cb, normal, depth)
-        geo.DrawGBuffer(consts.pass_cb, gb, depth)
+        geo.DrawNormalsDepthAndGBuffer(consts.pass_cb, normal, gb, depth)
         e2.record()
         torch.cuda.synchronize()
         t_sh += e0.elapsed_time(e1) / n

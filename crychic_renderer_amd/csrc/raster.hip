@@ -7,8 +7,9 @@
 //                  cull; up to 3 setup triangles land in slots fixed by draw order (slot = serial, so equal depths
 //                  resolve to the earlier primitive exactly like in-order LESS testing); live slots are appended to
 //                  a list with one atomic each
-//   raster_kernel  persistent workgroups walk the live list; a 64 x 4 lane footprint sweeps the triangle's pixel box
-//                  with 64-bit integer edge functions and atomicMin()s the 64-bit key (d24 << 32 | serial)
+//   raster_kernel  persistent workgroups walk the live list, one wavefront per small triangle (a workgroup per large one); a 16 x 4 lane footprint sweeps
+//                  the triangle's pixel box with 64-bit integer edge functions and atomicMin()s the 64-bit key
+//                  (d24 << 32 | serial); the shadow pass atomicMin()s the D24 value straight into the depth plane
 //   resolve_kernel one lane per pixel: depth plane from the key, perspective-correct attributes of the winning
 //                  primitive, then the pass's pixel shader (DrawNormals.hlsl / GeometryPass.hlsl)
 #include <hip/hip_runtime.h>
@@ -17,20 +18,28 @@
 
 namespace cry {
 
-struct RasterCounters { uint32_t nlive; uint32_t overflow; uint32_t pad[2]; };
+constexpr int kLargeBox = 2048;   // pixel-box area above which a triangle gets a whole workgroup
+struct RasterCounters { uint32_t nlive; uint32_t overflow; uint32_t nlarge; uint32_t pad; };
 
 __global__ __launch_bounds__(256) void clear_vis_kernel(uint64_t* __restrict__ vis, uint32_t n, RasterCounters* c)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n) vis[i] = kVisClear;
-    if (i == 0) { c->nlive = 0; c->overflow = 0; }
+    if (i == 0) { c->nlive = 0; c->overflow = 0; c->nlarge = 0; }
 }
 
 __global__ __launch_bounds__(128) void setup_kernel(crychic_draw_item item, const crychic_material_data* __restrict__ materials,
                                                     uint32_t nMaterials, crychic_pass_constants_viewproj vp, uint32_t W, uint32_t H,
                                                     SetupTri* __restrict__ tris, uint32_t slotBase, uint32_t* __restrict__ live,
-                                                    RasterCounters* __restrict__ counters)
+                                                    uint32_t liveCapacity, RasterCounters* __restrict__ counters)
 {
+    // small triangles are listed from the front of `live`, large ones (pixel box > kLargeBox) from its back
+    auto append = [&](const SetupTri& s, uint32_t slot) {
+        const PixelBox b = triangle_box(s, W, H);
+        if (b.x0 > b.x1 || b.y0 > b.y1) return;                       // covers no pixel centre inside the target
+        if ((b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1) > kLargeBox) live[liveCapacity - 1u - atomicAdd(&counters->nlarge, 1u)] = slot;
+        else live[atomicAdd(&counters->nlive, 1u)] = slot;
+    };
     const uint32_t ntri = item.indexCount / 3u;
     const uint64_t gid = (uint64_t)blockIdx.x * 128u + threadIdx.x;
     if (gid >= (uint64_t)ntri * item.instanceCount) return;
@@ -57,7 +66,7 @@ __global__ __launch_bounds__(128) void setup_kernel(crychic_draw_item item, cons
         SetupTri s;
         if (setup_triangle(v[0], v[1], v[2], I.MaterialIndex, W, H, s, &overflow)) {
             tris[slot0] = s;
-            live[atomicAdd(&counters->nlive, 1u)] = slot0;
+            append(s, slot0);
         }
     } else {
         VsOut poly[8], tmp[8];
@@ -68,32 +77,52 @@ __global__ __launch_bounds__(128) void setup_kernel(crychic_draw_item item, cons
             SetupTri s;
             if (setup_triangle(poly[0], poly[c], poly[c + 1], I.MaterialIndex, W, H, s, &overflow)) {
                 tris[slot0 + (uint32_t)(c - 1)] = s;
-                live[atomicAdd(&counters->nlive, 1u)] = slot0 + (uint32_t)(c - 1);
+                append(s, slot0 + (uint32_t)(c - 1));
             }
         }
     }
     if (overflow) atomicOr(&counters->overflow, 1u);
 }
 
-__global__ __launch_bounds__(256) void raster_kernel(const SetupTri* __restrict__ tris, const uint32_t* __restrict__ live,
-                                                     const RasterCounters* __restrict__ counters, unsigned long long* __restrict__ vis,
-                                                     uint32_t W, uint32_t H, int shadowMode, int depthBias, float slopeBias)
+__global__ __launch_bounds__(256) void clear_depth_kernel(uint32_t* __restrict__ depth, uint32_t n, RasterCounters* c)
 {
-    const uint32_t nlive = counters->nlive;          // written by the setup kernels that precede this launch in the stream
-    const int lx = (int)(threadIdx.x & 63u), ly = (int)(threadIdx.x >> 6);
-    for (uint32_t k = blockIdx.x; k < nlive; k += gridDim.x) {    // every workgroup reaches the same exit condition
-        const uint32_t slot = live[k];
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) depth[i] = 0x00FFFFFFu;
+    if (i == 0) { c->nlive = 0; c->overflow = 0; c->nlarge = 0; }
+}
+
+// Small triangles (pixel box <= kLargeBox): one wavefront per triangle with a 2^FWL2-wide lane footprint (16 x 4), four
+// triangles per workgroup step.  Large triangles: one workgroup per triangle, its four waves sweeping interleaved
+// footprint-high stripes.  Which lane tests which pixel does not matter: the result is an atomicMin over
+// order-independent keys.  SHADOW: depth-only pass -- the minimum of the D24 values is all the pass needs (equal depths
+// carry the same value whichever primitive wins), so the atomics go straight to the 32-bit depth plane and neither the
+// 64-bit visibility buffer nor the resolve pass exist.
+template <bool SHADOW, int FWL2>
+__global__ __launch_bounds__(256) void raster_kernel(const SetupTri* __restrict__ tris, const uint32_t* __restrict__ live, uint32_t liveCapacity,
+                                                     const RasterCounters* __restrict__ counters, unsigned long long* __restrict__ vis,
+                                                     uint32_t* __restrict__ depth, uint32_t W, uint32_t H, int depthBias, float slopeBias)
+{
+    const uint32_t nsmall = counters->nlive, nlarge = counters->nlarge;   // written by the setup kernels that precede this launch
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    constexpr int FW = 1 << FWL2, FH = 64 >> FWL2;     // footprint of one wavefront
+    const int lx = lane & (FW - 1), ly = lane >> FWL2;
+    auto sweep = [&](uint32_t slot, int yfirst, int ystep) {
         const SetupTri t = tris[slot];
         const PixelBox b = triangle_box(t, W, H);
-        if (b.x0 > b.x1 || b.y0 > b.y1) continue;
         const EdgeFlags e = triangle_edge_flags(t);
-        const double bias = shadowMode ? triangle_depth_bias(t, depthBias, slopeBias) : 0.0;
-        for (int y = b.y0 + ly; y <= b.y1; y += 4)
-            for (int x = b.x0 + lx; x <= b.x1; x += 64) {
+        const double bias = SHADOW ? triangle_depth_bias(t, depthBias, slopeBias) : 0.0;
+        for (int y = b.y0 + ly + yfirst; y <= b.y1; y += ystep)
+            for (int x = b.x0 + lx; x <= b.x1; x += FW) {
                 const uint64_t key = fragment_key(t, e, bias, x, y, slot + 1u);
-                if (key != ~0ull) atomicMin(&vis[(uint32_t)y * W + (uint32_t)x], (unsigned long long)key);
+                if (key == ~0ull) continue;
+                if (SHADOW) atomicMin(&depth[(uint32_t)y * W + (uint32_t)x], (uint32_t)(key >> 32));
+                else atomicMin(&vis[(uint32_t)y * W + (uint32_t)x], (unsigned long long)key);
             }
-    }
+    };
+    // every workgroup / wave reaches the same exit conditions (the counters are fixed for the whole launch)
+    for (uint32_t k = blockIdx.x; k < nlarge; k += gridDim.x) sweep(live[liveCapacity - 1u - k], FH * wave, 4 * FH);
+    for (uint32_t k = blockIdx.x * 4u + (uint32_t)wave; k < nsmall; k += gridDim.x * 4u)
+        sweep((uint32_t)__builtin_amdgcn_readfirstlane((int)live[k]), 0, FH);       // wave-uniform: the triangle record comes in by scalar loads
 }
 
 __global__ __launch_bounds__(256) void resolve_kernel(int mode, const unsigned long long* __restrict__ vis, const SetupTri* __restrict__ tris,
@@ -110,14 +139,14 @@ __global__ __launch_bounds__(256) void resolve_kernel(int mode, const unsigned l
     depth[idx] = (uint32_t)(key >> 32);
     if (mode == 0) return;
     if (serial == 0) {                       // nothing drawn here: the pass's clear values
-        if (mode == 1) normal[idx] = u2{ 0u, 0x00003C00u };                      // (0, 0, 1, 0) in fp16, Ssao.cpp:317
-        else { g0[idx] = f4a{ 0, 0, 0, 0 }; g1[idx] = f4a{ 0, 0, 0, 0 }; g2[idx] = f4a{ 0, 0, 0, 0 }; }   // CRYCHIC.cpp:2554
+        if (mode & 1) normal[idx] = u2{ 0u, 0x00003C00u };                      // (0, 0, 1, 0) in fp16, Ssao.cpp:317
+        if (mode & 2) { g0[idx] = f4a{ 0, 0, 0, 0 }; g1[idx] = f4a{ 0, 0, 0, 0 }; g2[idx] = f4a{ 0, 0, 0, 0 }; }   // CRYCHIC.cpp:2554
         return;
     }
     const ResolveOut r = resolve_pixel(mode, tris[serial - 1u], (int)x, (int)y, view.m, materials, nMaterials, textures, nTextures);
-    if (mode == 1) {
+    if (mode & 1)
         normal[idx] = u2{ (uint32_t)float_to_half(r.normalV.x) | ((uint32_t)float_to_half(r.normalV.y) << 16), (uint32_t)float_to_half(r.normalV.z) };
-    } else {
+    if (mode & 2) {
         g0[idx] = f4a{ r.g0.x, r.g0.y, r.g0.z, r.g0.w };
         g1[idx] = f4a{ r.g1.x, r.g1.y, r.g1.z, r.g1.w };
         g2[idx] = f4a{ r.g2.x, r.g2.y, r.g2.z, r.g2.w };
@@ -147,7 +176,9 @@ hipError_t launch_raster_pass(const RasterPass& p, hipStream_t stream)
     RasterCounters* counters = (RasterCounters*)(base + off);
 
     const uint32_t npx = p.W * p.H;
-    hipLaunchKernelGGL(clear_vis_kernel, dim3((npx + 255u) / 256u), dim3(256), 0, stream, (uint64_t*)vis, npx, counters);
+    const bool shadow = p.mode == 0;
+    if (shadow) hipLaunchKernelGGL(clear_depth_kernel, dim3((npx + 255u) / 256u), dim3(256), 0, stream, p.depth, npx, counters);
+    else hipLaunchKernelGGL(clear_vis_kernel, dim3((npx + 255u) / 256u), dim3(256), 0, stream, (uint64_t*)vis, npx, counters);
     if (p.nTextures) {
         hipError_t e = hipMemcpyAsync(texDev, p.textures, p.nTextures * sizeof(Texture), hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) return e;
@@ -159,13 +190,15 @@ hipError_t launch_raster_pass(const RasterPass& p, hipStream_t stream)
         const uint64_t n = (uint64_t)(p.items[i].indexCount / 3u) * p.items[i].instanceCount;
         if (n == 0) continue;
         hipLaunchKernelGGL(setup_kernel, dim3((uint32_t)((n + 127u) / 128u)), dim3(128), 0, stream, p.items[i], p.materials, p.nMaterials,
-                           vp, p.W, p.H, tris, slotBase, live, counters);
+                           vp, p.W, p.H, tris, slotBase, live, (uint32_t)slots, counters);
         slotBase += (uint32_t)(n * 3u);
     }
     if (slots) {
-        hipLaunchKernelGGL(raster_kernel, dim3(256u * 8u), dim3(256), 0, stream, tris, live, counters, vis, p.W, p.H,
-                           p.mode == 0 ? 1 : 0, p.depthBias, p.slopeScaledDepthBias);
+#define CRY_RASTER(S, F) hipLaunchKernelGGL((raster_kernel<S, F>), dim3(256u * 8u), dim3(256), 0, stream, tris, live, (uint32_t)slots, counters, vis, p.depth, p.W, p.H, p.depthBias, p.slopeScaledDepthBias)
+        if (shadow) CRY_RASTER(true, 4); else CRY_RASTER(false, 4);     // 16 x 4 footprint: measured best of 8x8 / 16x4 / 64x1
+#undef CRY_RASTER
     }
+    if (shadow) return hipGetLastError();
     hipLaunchKernelGGL(resolve_kernel, dim3((p.W + 63u) / 64u, (p.H + 3u) / 4u), dim3(256), 0, stream, p.mode, vis, tris, view,
                        p.materials, p.nMaterials, p.nTextures ? texDev : nullptr, p.nTextures, p.W, p.H, p.depth, (u2*)p.normal,
                        (f4a*)p.g0, (f4a*)p.g1, (f4a*)p.g2);

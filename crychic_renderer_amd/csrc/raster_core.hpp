@@ -204,8 +204,8 @@ CRY_HD f4 sample_texture(const Texture* tex, uint32_t nTextures, uint32_t index,
 }
 
 struct ResolveOut {
-    f3 normalV;         // mode 1
-    f4 g0, g1, g2;      // mode 2
+    f3 normalV;         // mode bit 0 (DrawNormals.hlsl)
+    f4 g0, g1, g2;      // mode bit 1 (GeometryPass.hlsl); mode 3 = both pixel shaders on the one visibility result
 };
 
 // Pixel stage for the winning primitive of pixel (px, py): perspective-correct attributes, then the pass's PS.
@@ -225,13 +225,13 @@ CRY_HD ResolveOut resolve_pixel(int mode, const SetupTri& t, int px, int py, con
     ResolveOut r{};
     const f3 N = normalize3(f3{ interp(t.normalW[0][0], t.normalW[1][0], t.normalW[2][0]), interp(t.normalW[0][1], t.normalW[1][1], t.normalW[2][1]),
                                 interp(t.normalW[0][2], t.normalW[1][2], t.normalW[2][2]) });   // DrawNormals.hlsl:85, GeometryPass.hlsl:58
-    if (mode == 1) {
+    if (mode & 1) {
         const float n3[3] = { N.x, N.y, N.z };
         float nv[3];
         mul3x3(n3, view, nv);                                                                  // DrawNormals.hlsl:92
         r.normalV = f3{ nv[0], nv[1], nv[2] };
-        return r;
     }
+    if (!(mode & 2)) return r;
     const f3 posW{ interp(t.posW[0][0], t.posW[1][0], t.posW[2][0]), interp(t.posW[0][1], t.posW[1][1], t.posW[2][1]),
                    interp(t.posW[0][2], t.posW[1][2], t.posW[2][2]) };
     const f3 tanW{ interp(t.tangentW[0][0], t.tangentW[1][0], t.tangentW[2][0]), interp(t.tangentW[0][1], t.tangentW[1][1], t.tangentW[2][1]),

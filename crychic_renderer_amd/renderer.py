@@ -293,6 +293,16 @@ class SceneGeometry:
         check(lib.crychic_draw_normals_and_depth(self.ctx.handle, C.byref(pass_cb), self.items, len(self.items), _ptr(normal_map), _ptr(depth),
                                                  W, H, _ptr(ws), ws.numel(), _stream(self.ctx.device)))
 
+    def DrawNormalsDepthAndGBuffer(self, pass_cb, normal, gbuffer, depth):
+        """DrawNormalsAndDepth + DrawGBuffer on one rasterisation (same items, same ViewProj => same visibility); every plane is
+        bit-identical to the two separate passes."""
+        H, W = int(depth.shape[0]), int(depth.shape[1])
+        ws = self.workspace(W, H)
+        check(lib.crychic_draw_normals_depth_and_gbuffer(self.ctx.handle, C.byref(pass_cb), self.items, len(self.items), _ptr(self.materials),
+                                                         self.n_materials, self.textures, self.n_textures, _ptr(normal), _ptr(gbuffer[0]),
+                                                         _ptr(gbuffer[1]), _ptr(gbuffer[2]), _ptr(depth), W, H, _ptr(ws), ws.numel(),
+                                                         _stream(self.ctx.device)))
+
     def DrawGBuffer(self, pass_cb, gbuffer, depth):  # CRYCHIC.cpp:2545-2571
         H, W = int(depth.shape[0]), int(depth.shape[1])
         ws = self.workspace(W, H)

@@ -192,8 +192,8 @@ public:
     {
         if (mRunProducerPasses) {
             DrawSceneToShadowMap();                                                                 // :208
-            DrawNormalsAndDepth();                                                                  // :214
-            DrawGBuffer();                                                                          // :236
+            if (mFuseCameraPasses) DrawNormalsDepthAndGBuffer();                                    // :214 + :236 on one rasterisation
+            else { DrawNormalsAndDepth(); DrawGBuffer(); }
         }
         crychic_frame_desc f = {};
         f.W = mClientWidth; f.H = mClientHeight;
@@ -254,6 +254,7 @@ public:
     bool mPcfLiteral = true;    // Common.hlsl:305 evaluated as written
     bool mSkyEnabled = true;
     bool mFrustumCullingEnabled = true;   // CRYCHIC.h:188
+    bool mFuseCameraPasses = true;        // false: DrawNormalsAndDepth and DrawGBuffer rasterise separately, as the reference records them
     UINT mShadowMapSize = 4096; // CRYCHIC.cpp:48-49
     DirectX::XMFLOAT4X4 mLightViews[MaxLights], mLightProjs[MaxLights], mShadowTransforms[MaxLights];  // CRYCHIC.h:166-170
     FrameResource* mCurrFrameResource = nullptr;
@@ -477,6 +478,20 @@ private:
             mTextures.empty() ? nullptr : mTextures.data(), (uint32_t)mTextures.size(), static_cast<float*>(mDeferred->Resource(0)->Data()),
             static_cast<float*>(mDeferred->Resource(1)->Data()), static_cast<float*>(mDeferred->Resource(2)->Data()),
             static_cast<uint32_t*>(mDepthStencilBuffer->Data()), mClientWidth, mClientHeight, ws, bytes, mCommandList->Stream()));
+    }
+    void DrawNormalsDepthAndGBuffer()  // DrawNormalsAndDepth + DrawGBuffer: same items, same ViewProj, same visibility -> one rasterisation
+    {
+        auto items = DrawItems(mRitemLayer[(int)RenderLayer::Opaque]);
+        size_t bytes;
+        void* ws = RasterWorkspace(mSceneTriangles, mClientWidth, mClientHeight, &bytes);
+        const PassConstants& cb = mCurrFrameResource->PassCB->Element(0);
+        CrychicThrowIfFailed(crychic_draw_normals_depth_and_gbuffer(
+            md3dDevice->Ctx(), reinterpret_cast<const crychic_pass_constants*>(&cb), items.data(), (uint32_t)items.size(),
+            reinterpret_cast<const crychic_material_data*>(mCurrFrameResource->MaterialBuffer->Resource()->Data()), (uint32_t)mMaterials.size(),
+            mTextures.empty() ? nullptr : mTextures.data(), (uint32_t)mTextures.size(), mSsao->NormalMap()->Data(),
+            static_cast<float*>(mDeferred->Resource(0)->Data()), static_cast<float*>(mDeferred->Resource(1)->Data()),
+            static_cast<float*>(mDeferred->Resource(2)->Data()), static_cast<uint32_t*>(mDepthStencilBuffer->Data()), mClientWidth, mClientHeight,
+            ws, bytes, mCommandList->Stream()));
     }
     void UpdateCascadeShadowTransform(const GameTimer&)  // CRYCHIC.cpp:634-815
     {

@@ -317,6 +317,15 @@ int crychic_draw_gbuffer(crychic_ctx* ctx, const crychic_pass_constants* passCB,
                          const crychic_texture* textures, uint32_t nTextures, float* g0_dev, float* g1_dev, float* g2_dev,
                          uint32_t* depth_dev, uint32_t W, uint32_t H, void* workspace_dev, size_t workspaceBytes, void* stream);
 
+/* DrawNormalsAndDepth + DrawGBuffer in one rasterisation: the two passes draw the same items with the same ViewProj into
+ * depth targets cleared to 1.0, so their visibility is identical; this entry rasterises once and runs both pixel shaders
+ * on the winning primitive.  Every plane is bit-identical to calling the two passes one after the other. */
+int crychic_draw_normals_depth_and_gbuffer(crychic_ctx* ctx, const crychic_pass_constants* passCB, const crychic_draw_item* items,
+                                           uint32_t nItems, const crychic_material_data* materials_dev, uint32_t nMaterials,
+                                           const crychic_texture* textures, uint32_t nTextures, void* normal_dev, float* g0_dev,
+                                           float* g1_dev, float* g2_dev, uint32_t* depth_dev, uint32_t W, uint32_t H,
+                                           void* workspace_dev, size_t workspaceBytes, void* stream);
+
 /* ---- multi-GPU strip plan (pure host arithmetic) ---------------------------------------------- */
 /* Full-res rows [*row0, *row0 + *rows) owned by `rank` of `nranks` for an H-row frame: strips are multiples
  * of 2 rows (half-res alignment); the last rank takes the remainder. */

@@ -37,6 +37,14 @@ def device_frame(ctx, built_lib, consts, items, shadow_items, materials, texture
         sgeo.DrawSceneToShadowMap(shadow_cb, app.mShadowMap.mShadowMap[k])
     geo.DrawNormalsAndDepth(app.mMainPassCB, app.mSsao.mNormalMap, app.mDepthStencilBuffer)
     geo.DrawGBuffer(app.mMainPassCB, app.mDeferred.mGBuffer, app.mDepthStencilBuffer)
+    # the fused pass (one rasterisation, both pixel shaders) must reproduce the two passes bit for bit
+    n2 = torch.zeros_like(app.mSsao.mNormalMap); d2 = torch.zeros_like(app.mDepthStencilBuffer)
+    g2 = [torch.zeros_like(g) for g in app.mDeferred.mGBuffer]
+    geo.DrawNormalsDepthAndGBuffer(app.mMainPassCB, n2, g2, d2)
+    torch.cuda.synchronize()
+    assert torch.equal(n2.view(torch.int16), app.mSsao.mNormalMap.view(torch.int16)) and torch.equal(d2, app.mDepthStencilBuffer)
+    for a, b in zip(g2, app.mDeferred.mGBuffer):
+        assert torch.equal(a.view(torch.int32), b.view(torch.int32))
     app.blurCount, app.numDirLights, app.pcfSearchRadius, app.flags = blur_count, ndl, radius, (LIGHT_SKY if sky else 0)
     app.Draw()
     torch.cuda.synchronize()
