@@ -161,7 +161,8 @@ CRY_HD uint64_t fragment_key(const SetupTri& t, const EdgeFlags& e, double bias,
     const int64_t w2 = orient2d(t.X[0], t.Y[0], t.X[1], t.Y[1], cx, cy);
     if ((w0 | w1 | w2) < 0) return ~0ull;
     if ((w0 == 0 && !e.tl0) || (w1 == 0 && !e.tl1) || (w2 == 0 && !e.tl2)) return ~0ull;
-    const double l1 = (double)w1 / (double)t.A2, l2 = (double)w2 / (double)t.A2;
+    const double invA2 = 1.0 / (double)t.A2;   // loop-invariant: one reciprocal per triangle (hoisted out of the pixel loops)
+    const double l1 = (double)w1 * invA2, l2 = (double)w2 * invA2;
     double z = (double)t.z[0] + l1 * ((double)t.z[1] - (double)t.z[0]) + l2 * ((double)t.z[2] - (double)t.z[0]);
     z = z + bias;
     z = (z > 0.0) ? z : 0.0;
@@ -217,10 +218,10 @@ CRY_HD ResolveOut resolve_pixel(int mode, const SetupTri& t, int px, int py, con
     const double w0 = (double)orient2d(t.X[1], t.Y[1], t.X[2], t.Y[2], cx, cy);
     const double w1 = (double)orient2d(t.X[2], t.Y[2], t.X[0], t.Y[0], cx, cy);
     const double w2 = (double)orient2d(t.X[0], t.Y[0], t.X[1], t.Y[1], cx, cy);
-    const double A = (double)t.A2;
-    const double q0 = (w0 / A) * (double)t.invw[0], q1 = (w1 / A) * (double)t.invw[1], q2 = (w2 / A) * (double)t.invw[2];
-    const double qs = (q0 + q1) + q2;
-    auto interp = [&](float a0, float a1, float a2) { return (float)((((double)a0 * q0 + (double)a1 * q1) + (double)a2 * q2) / qs); };
+    const double invA = 1.0 / (double)t.A2;
+    const double q0 = (w0 * invA) * (double)t.invw[0], q1 = (w1 * invA) * (double)t.invw[1], q2 = (w2 * invA) * (double)t.invw[2];
+    const double invqs = 1.0 / ((q0 + q1) + q2);   // perspective correction: one reciprocal per pixel
+    auto interp = [&](float a0, float a1, float a2) { return (float)((((double)a0 * q0 + (double)a1 * q1) + (double)a2 * q2) * invqs); };
 
     ResolveOut r{};
     const f3 N = normalize3(f3{ interp(t.normalW[0][0], t.normalW[1][0], t.normalW[2][0]), interp(t.normalW[0][1], t.normalW[1][1], t.normalW[2][1]),

@@ -221,6 +221,7 @@ int or_rasterize(int mode, const float view[16], const float viewProj[16], const
             double ms = fabs(dzdx) > fabs(dzdy) ? fabs(dzdx) : fabs(dzdy);
             bias = (double)depthBias * (1.0 / 16777216.0) + (double)slopeScaledDepthBias * ms;
         }
+        const double invA2 = 1.0 / (double)T->A2;   /* barycentrics: one reciprocal per triangle, then products (all in double) */
         for (int py = y0; py <= y1; ++py) {
             for (int px = x0; px <= x1; ++px) {
                 int32_t cx = px * 256 + 128, cy = py * 256 + 128;
@@ -229,7 +230,7 @@ int or_rasterize(int mode, const float view[16], const float viewProj[16], const
                 int64_t w2 = orient(T->X[0], T->Y[0], T->X[1], T->Y[1], cx, cy);
                 if (w0 < 0 || w1 < 0 || w2 < 0) continue;
                 if ((w0 == 0 && !tl0) || (w1 == 0 && !tl1) || (w2 == 0 && !tl2)) continue;
-                double l1 = (double)w1 / (double)T->A2, l2 = (double)w2 / (double)T->A2;
+                double l1 = (double)w1 * invA2, l2 = (double)w2 * invA2;
                 double z = (double)T->z[0] + l1 * ((double)T->z[1] - (double)T->z[0]) + l2 * ((double)T->z[2] - (double)T->z[0]);
                 z = z + bias;
                 if (!(z > 0.0)) z = 0.0;
@@ -261,10 +262,10 @@ int or_rasterize(int mode, const float view[16], const float viewProj[16], const
             double w0 = (double)orient(T->X[1], T->Y[1], T->X[2], T->Y[2], cx, cy);
             double w1 = (double)orient(T->X[2], T->Y[2], T->X[0], T->Y[0], cx, cy);
             double w2 = (double)orient(T->X[0], T->Y[0], T->X[1], T->Y[1], cx, cy);
-            double A = (double)T->A2;
-            double q0 = (w0 / A) * (double)T->invw[0], q1 = (w1 / A) * (double)T->invw[1], q2 = (w2 / A) * (double)T->invw[2];
-            double qs = (q0 + q1) + q2;
-#define OR_INTERP(a0, a1, a2) ((float)((((double)(a0) * q0 + (double)(a1) * q1) + (double)(a2) * q2) / qs))
+            double invA = 1.0 / (double)T->A2;
+            double q0 = (w0 * invA) * (double)T->invw[0], q1 = (w1 * invA) * (double)T->invw[1], q2 = (w2 * invA) * (double)T->invw[2];
+            double invqs = 1.0 / ((q0 + q1) + q2);   /* perspective correction: one reciprocal per pixel */
+#define OR_INTERP(a0, a1, a2) ((float)((((double)(a0) * q0 + (double)(a1) * q1) + (double)(a2) * q2) * invqs))
             float nW[3], N[3];
             for (int c = 0; c < 3; ++c) nW[c] = OR_INTERP(T->normalW[0][c], T->normalW[1][c], T->normalW[2][c]);
             or_normalize3(nW, N);                                        /* DrawNormals.hlsl:85 / GeometryPass.hlsl:58 */
