@@ -324,7 +324,10 @@ def main():
                        "frame_hbm_roofline_frac": round(frame_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS * world, 4)
                        if world == 1 else None,
                        "pass_ms": {k: round(v, 4) for k, v in acc.items()},
-                       "producer_passes_ms": producer_ms},
+                       "producer_passes_ms": producer_ms,
+                       "full_frame_ms_incl_producers": (round(dt / args.steps * 1e3 + producer_ms["shadow_4x%d" % args.shadow_dim]
+                                                              + producer_ms["normals_depth+gbuffer"], 3)
+                                                        if producer_ms and world == 1 else None)},
             "roofline": {"kernel": "light_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args, world)},
         }
