@@ -85,18 +85,18 @@ def cpu_baseline(planes, args, pcf_radius):
         return rows_full, time.perf_counter() - t0
 
     rows, dt = run_band(args.cpu_band_rows or 64)
+    reps = 1
     if not args.cpu_band_rows:
         target = 15.0
         want = int(rows * target / max(dt, 1e-3))
         if want > rows * 2:
             rows, dt = run_band(min(H, want))
-        reps = 1
         while rows == H and dt * reps < 3.0 and reps < 16:   # many-core host: the whole frame is short, average a few
             dt = (dt * reps + run_band(H)[1]) / (reps + 1)
             reps += 1
     return {"value": round(rows * W / dt / 1e6, 3), "unit": "Mpixels/s", "cores": int(orc.lib.or_num_threads()), "kind": "port",
             "sample": "oracle (C, OpenMP) SSAO + %d blur sweeps + lighting on a %d-row band (%d x %d px) of the same "
-                      "frame, %.1f s" % (2 * bc, rows, W, rows, dt)}
+                      "frame, %.1f s%s" % (2 * bc, rows, W, rows, dt, " (mean of %d runs)" % reps if reps > 1 else "")}
 
 
 def pmc_traffic(args, world):
