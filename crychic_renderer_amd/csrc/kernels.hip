@@ -168,6 +168,65 @@ __global__ __launch_bounds__(256) void blur_replay_kernel(crychic_ssao_constants
     }
 }
 
+// One whole replay iteration (horizontal then vertical sweep, SsaoBlur ping-pong 0 -> 1 -> 0 of Ssao.cpp:240-241) in one
+// launch: the horizontal results of the tile's rows plus a 5-row apron stay in LDS -- quantised to R16_UNORM and decoded
+// again exactly as the round trip through the ambient map does -- and feed the vertical sweep.  Bit-identical to
+// blur_replay_kernel<true> followed by blur_replay_kernel<false>; `out` must not alias `in`.
+__global__ __launch_bounds__(256) void blur_replay_pair_kernel(crychic_ssao_constants cb, EdgePlane edge,
+                                                               const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
+                                                               uint32_t W, uint32_t H, uint32_t row0, uint32_t row1)
+{
+    constexpr int BW = 64, BH = 16, R = 5;
+    constexpr int SW = BW + 2 * R, SH = BH + 2 * R;
+    __shared__ float s_in[SW * SH];
+    __shared__ float s_mid[BW * SH];
+
+    const int w2 = (int)(W / 2), h2 = (int)(H / 2);
+    uint32_t bx, by;
+    tile_origin<4>(bx, by);
+    const int x0 = (int)bx * BW, y0 = (int)row0 + (int)by * BH;
+    const int tx = (int)(threadIdx.x & 63u), tyb = (int)(threadIdx.x >> 6);
+    const int x = x0 + tx;
+    // the vertical sweep's recorded decisions of this thread's four outputs: fetched first, they fly during the staging
+    uint32_t m[BH / 4];
+    float tot[BH / 4];
+#pragma unroll
+    for (int j = 0; j < BH / 4; ++j) {
+        const int y = y0 + tyb + 4 * j;
+        const bool live = (x < w2) && (y < (int)row1);
+        const uint32_t p = live ? (uint32_t)y * (uint32_t)w2 + (uint32_t)x : 0u;
+        m[j] = edge.mask_v[p];
+        tot[j] = edge.total_v[p];
+    }
+    for (int k = (int)threadIdx.x; k < SW * SH; k += 256) {
+        const int ly = k / SW, lx = k - ly * SW;
+        const int cx = clampi(x0 - R + lx, 0, w2 - 1), cy = clampi(y0 - R + ly, 0, h2 - 1);   // ambient: point / CLAMP
+        s_in[k] = unorm16_to_float(in[(uint32_t)cy * (uint32_t)w2 + (uint32_t)cx]);
+    }
+    __syncthreads();
+    // horizontal sweep of rows y0-5 .. y0+BH+4 (CLAMPed: a vertical tap above / below the map reads the edge row's result)
+    for (int k = (int)threadIdx.x; k < BW * SH; k += 256) {
+        const int ly = k >> 6, lx = k & 63;
+        const int cy = clampi(y0 - R + ly, 0, h2 - 1), cx = x0 + lx;
+        if (cx < w2) {
+            const uint32_t p = (uint32_t)cy * (uint32_t)w2 + (uint32_t)cx;
+            const uint32_t v = blur_pixel_replay(&cb.BlurWeights[0][0], edge.mask_h[p], edge.total_h[p],
+                                                 [&](int i) { return s_in[ly * SW + lx + i]; });
+            s_mid[k] = unorm16_to_float(v);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < BH / 4; ++j) {
+        const int ty = tyb + 4 * j;
+        const int y = y0 + ty;
+        if (x < w2 && y < (int)row1) {
+            const uint32_t v = blur_pixel_replay(&cb.BlurWeights[0][0], m[j], tot[j], [&](int i) { return s_mid[(ty + i) * BW + tx]; });
+            out[(uint32_t)y * (uint32_t)w2 + (uint32_t)x] = (uint16_t)v;
+        }
+    }
+}
+
 // ---- deferred lighting -----------------------------------------------------------------------------------------
 // Shaders/DeferredShading.hlsl:23-101 as a full-screen pass over rows [row0, row1), masked by depth < 1.
 template <bool ZERO_RADIUS>
@@ -325,6 +384,15 @@ hipError_t launch_blur(const crychic_ssao_constants& cb, const void* edge_base, 
         if (horizontal) CRY_LAUNCH_BLUR((blur_kernel<true, false>)); else CRY_LAUNCH_BLUR((blur_kernel<false, false>));
     }
 #undef CRY_LAUNCH_BLUR
+    return hipGetLastError();
+}
+
+hipError_t launch_blur_replay_pair(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out,
+                                   uint32_t W, uint32_t H, uint32_t row0, uint32_t rows, hipStream_t stream)
+{
+    if (rows == 0) return hipSuccess;
+    const EdgePlane e = edge_plane_carve(const_cast<void*>(edge_base), W, H);
+    hipLaunchKernelGGL(blur_replay_pair_kernel, grid_for(W / 2, rows, 16u), dim3(256), 0, stream, cb, e, in, out, W, H, row0, row0 + rows);
     return hipGetLastError();
 }
 

@@ -15,6 +15,9 @@ hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, con
 // Plain: a self-contained sweep.  Record: same, and stores the per-pixel tap decisions + totalWeight of this
 // direction in the edge workspace.  Replay: uses what a Record sweep of the same direction stored (same geometry).
 enum class BlurMode { Plain, Record, Replay };
+// horizontal + vertical replay sweep of one iteration in one launch (in -> out, out != in)
+hipError_t launch_blur_replay_pair(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out,
+                                   uint32_t W, uint32_t H, uint32_t row0, uint32_t rows, hipStream_t stream);
 hipError_t launch_blur(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out,
                        uint32_t W, uint32_t H, bool horizontal, BlurMode mode, uint32_t row0, uint32_t rows,
                        hipStream_t stream);
