@@ -32,14 +32,28 @@ def _stale():
 def build(force=False, verbose=True):
     if not force and not _stale():
         return LIB
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
-    for s in SOURCES:
-        cmd += ["-x", "hip", os.path.join(CSRC, s)]
-    cmd += ["-o", LIB]
-    if verbose:
-        print("[crychic build]", " ".join(cmd), flush=True)
-    subprocess.run(cmd, check=True)
+    # One builder at a time (several ranks of one node may import the package together): the others wait on the lock, find
+    # the library fresh and return.  The link goes to a temporary name and is renamed into place, so a concurrent
+    # dlopen never sees a half-written file.
+    import fcntl
+    with open(os.path.join(HERE, ".build.lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        if not force and not _stale():
+            return LIB
+        hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+        tmp = LIB + ".tmp.%d" % os.getpid()
+        cmd = [hipcc] + FLAGS + ["-I", os.path.join(ROOT, "include"), "-I", CSRC]
+        for s in SOURCES:
+            cmd += ["-x", "hip", os.path.join(CSRC, s)]
+        cmd += ["-o", tmp]
+        if verbose:
+            print("[crychic build]", " ".join(cmd), flush=True)
+        try:
+            subprocess.run(cmd, check=True)
+            os.replace(tmp, LIB)
+        finally:
+            if os.path.exists(tmp):
+                os.remove(tmp)
     return LIB
 
 
