@@ -35,6 +35,30 @@ __device__ __forceinline__ void tile_origin(uint32_t& bx, uint32_t& by)
     bx = b - by * nbx;
 }
 
+// Two-dimensional variant for the SSAO pass: the (padded) grid is cut into super-tiles of SX x SY workgroup tiles; whole
+// super-tiles are dealt to the XCDs, so the depth texels an XCD's taps reach form a compact block instead of a
+// full-width stripe (at 7680 x 4320 a stripe of the depth plane no longer fits the 4 MiB L2).  gridDim is a multiple of
+// (SX, SY); tiles outside the frame exit at once.
+__device__ __forceinline__ void tile_origin_2d(uint32_t& bx, uint32_t& by, uint32_t SX, uint32_t SY)
+{
+    const uint32_t ncx = gridDim.x / SX, T = SX * SY, nst = ncx * (gridDim.y / SY);
+    const uint32_t b = blockIdx.y * gridDim.x + blockIdx.x;
+    const uint32_t full = (nst & ~7u) * T;                // workgroups in whole groups of eight super-tiles
+    uint32_t st, o;
+    if (b < full) {
+        const uint32_t xcd = b & 7u, k = b >> 3;          // k-th workgroup this XCD receives
+        const uint32_t j = k / T;
+        o = k - j * T;
+        st = j * 8u + xcd;
+    } else {                                              // the tail keeps its order (bijective)
+        st = b / T;
+        o = b - st * T;
+    }
+    const uint32_t sty = st / ncx, stx = st - sty * ncx, oy = o / SX, ox = o - oy * SX;
+    bx = stx * SX + ox;
+    by = sty * SY + oy;
+}
+
 // ---- SSAO ------------------------------------------------------------------------------------------------
 // Shaders/Ssao.hlsl:117-199 over half-res rows [row0, row1).  EMIT_AO = false builds only the edge workspace.
 template <bool EMIT_AO>
@@ -42,11 +66,11 @@ __global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, co
                                                    const uint32_t* __restrict__ depth,
                                                    const uint32_t* __restrict__ randvec,
                                                    uint16_t* __restrict__ ambient, EdgePlane edge, uint32_t W,
-                                                   uint32_t H, uint32_t row0, uint32_t row1)
+                                                   uint32_t H, uint32_t row0, uint32_t row1, uint32_t SX, uint32_t SY)
 {
     const uint32_t w2 = W / 2;
     uint32_t bx, by;
-    tile_origin<16>(bx, by);
+    tile_origin_2d(bx, by, SX, SY);
     const uint32_t x = bx * 64u + (threadIdx.x & 63u);
     const uint32_t y = row0 + by * 4u + (threadIdx.x >> 6);
     if (x >= w2 || y >= row1) return;
@@ -358,13 +382,21 @@ hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, con
     if (rows == 0) return hipSuccess;
     EdgePlane e{};
     if (edge_base) e = edge_plane_carve(edge_base, W, H);
-    const dim3 grid = grid_for(W / 2, rows);
+    dim3 grid = grid_for(W / 2, rows);
+    // super-tiles of SX x SY workgroup tiles (64 x 4 half-res pixels each) per XCD; the grid is padded to whole super-tiles
+    // 6 x 32 tiles = 384 x 128 half-res pixels (768 x 256 depth texels, 0.8 MB): measured best of 20 shapes at 4K and 8K
+    // (4K: 208 -> 186 us against full-width stripes of 16 tile rows; 8K: 1.56 -> 0.82 ms)
+    uint32_t SX = 6u, SY = 32u;
+    SX = SX > grid.x ? grid.x : SX;
+    SY = SY > grid.y ? grid.y : SY;
+    grid.x = (grid.x + SX - 1u) / SX * SX;
+    grid.y = (grid.y + SY - 1u) / SY * SY;
     if (emit_ao)
         hipLaunchKernelGGL(ssao_kernel<true>, grid, dim3(256), 0, stream, cb, (const u2*)normal, depth,
-                           (const uint32_t*)randvec, ambient, e, W, H, row0, row0 + rows);
+                           (const uint32_t*)randvec, ambient, e, W, H, row0, row0 + rows, SX, SY);
     else
         hipLaunchKernelGGL(ssao_kernel<false>, grid, dim3(256), 0, stream, cb, (const u2*)normal, depth,
-                           (const uint32_t*)randvec, ambient, e, W, H, row0, row0 + rows);
+                           (const uint32_t*)randvec, ambient, e, W, H, row0, row0 + rows, SX, SY);
     return hipGetLastError();
 }
 
