@@ -26,7 +26,10 @@ struct alignas(16) f4a { float x, y, z, w; };
 CRY_HD uint32_t f2u(float f) { uint32_t u; __builtin_memcpy(&u, &f, 4); return u; }
 CRY_HD float u2f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
 
-CRY_HD float saturate(float x) { return (x > 0.0f) ? ((x < 1.0f) ? x : 1.0f) : 0.0f; }
+// HLSL saturate(): NaN -> 0.  fmin(fmax(x, 0), 1) is one v_max_f32 ... clamp on gfx950 (the select form costs four
+// instructions).  It may return -0 where the select form returns +0; every use multiplies the result into a sum or
+// quantises it, where the sign of a zero cannot reach an output bit.
+CRY_HD float saturate(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); }
 CRY_HD float maxnn(float x, float c) { return (x > c) ? x : c; }            // HLSL max(): NaN loses
 CRY_HD float signf(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }
 CRY_HD float lerpf(float a, float b, float t) { return a + t * (b - a); }
@@ -58,9 +61,11 @@ typedef int v2i __attribute__((ext_vector_type(2)));
 
 CRY_HD v2f splat(float a) { return v2f{ a, a }; }
 CRY_HD v2f select2(v2i m, v2f a, v2f b) { return m ? a : b; }          // per lane: mask all-ones -> a
-CRY_HD v2f saturate2(v2f x) { return select2(x > 0.0f, select2(x < 1.0f, x, splat(1.0f)), splat(0.0f)); }   // NaN -> 0
+CRY_HD v2f saturate2(v2f x) { return v2f{ saturate(x.x), saturate(x.y) }; }   // NaN -> 0
 CRY_HD v2f max0_2(v2f x) { return select2(x > 0.0f, x, splat(0.0f)); }  // HLSL max(x, 0): NaN -> 0
-CRY_HD v2f sign2(v2f x) { return select2(x > 0.0f, splat(1.0f), splat(0.0f)) - select2(x < 0.0f, splat(1.0f), splat(0.0f)); }
+// sign(): +-1 with the sign bit of x copied in (v_bfi_b32), 0 for +-0 and NaN -- the same values as (x > 0) - (x < 0)
+CRY_HD float sign1(float x) { return ((x < 0.0f) | (x > 0.0f)) ? __builtin_copysignf(1.0f, x) : 0.0f; }
+CRY_HD v2f sign2(v2f x) { return v2f{ sign1(x.x), sign1(x.y) }; }
 CRY_HD v2f floor2(v2f x) { return v2f{ __builtin_floorf(x.x), __builtin_floorf(x.y) }; }
 CRY_HD v2f sqrt2(v2f x) { return v2f{ __builtin_sqrtf(x.x), __builtin_sqrtf(x.y) }; }
 CRY_HD v2f lerp2(v2f a, v2f b, v2f t) { return a + t * (b - a); }

@@ -193,20 +193,14 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
         // gsamDepthMap, both taps: bilinear setup in packed form, the 2 x 2 footprints through the paired loads
         const v2f tx = tu * (float)W - 0.5f, ty = tv * (float)H - 0.5f;
         const v2f flx = floor2(tx), fly = floor2(ty);
-        v2f fx = tx - flx, fy = ty - fly;
-        const v2i bad = (fx != fx) | (fy != fy);
-        fx = select2(bad, splat(0.0f), fx);
-        fy = select2(bad, splat(0.0f), fy);
-        v2f cxf = select2(flx >= -2.0f, flx, splat(-2.0f)), cyf = select2(fly >= -2.0f, fly, splat(-2.0f));
-        cxf = select2(cxf > (float)W + 1.0f, splat((float)W + 1.0f), cxf);
-        cyf = select2(cyf > (float)H + 1.0f, splat((float)H + 1.0f), cyf);
-#if defined(CRYCHIC_PROBE_NO_GATHER)   // tools/relaxed_math_probe.py: every tap reads the pixel's own footprint (timing experiment)
-        const int i0a = 2 * (int)x + (int)(cxf.x == 12345.0f), j0a = 2 * (int)y + (int)(cyf.x == 12345.0f);
-        const int i0b = 2 * (int)x + (int)(cxf.y == 12345.0f), j0b = 2 * (int)y + (int)(cyf.y == 12345.0f);
-#else
-        const int i0a = bad.x ? -2 : (int)cxf.x, j0a = bad.x ? -2 : (int)cyf.x;
-        const int i0b = bad.y ? -2 : (int)cxf.y, j0b = bad.y ? -2 : (int)cyf.y;
-#endif
+        // Fractions: in [0, 1) or NaN (non-finite coordinate); fmax(NaN, 0) = 0.  Texel indices: clamp(floor, -2, dim + 1)
+        // sends +-inf out of range and NaN to -2, so a non-finite coordinate addresses only BORDER texels on its own axis --
+        // which makes all four texels of the footprint the border value, the same result as the scalar sampler's joint
+        // "bad => (-2, -2)" rule (the CLAMP samplers, where the two rules differ, keep the scalar bilinear_setup).
+        const v2f fx = v2f{ __builtin_fmaxf(tx.x - flx.x, 0.0f), __builtin_fmaxf(tx.y - flx.y, 0.0f) };
+        const v2f fy = v2f{ __builtin_fmaxf(ty.x - fly.x, 0.0f), __builtin_fmaxf(ty.y - fly.y, 0.0f) };
+        const int i0a = texel_index(flx.x, W), j0a = texel_index(fly.x, H);
+        const int i0b = texel_index(flx.y, W), j0b = texel_index(fly.y, H);
         v2f t00, t10, t01, t11;
         {
             const uint32_t r0 = (uint32_t)clampi(j0a, 0, (int)H - 1), r1 = (uint32_t)clampi(j0a + 1, 0, (int)H - 1);
@@ -289,9 +283,11 @@ CRY_HD BlurOut blur_pixel_full(const float* __restrict__ w, Fetch fetch)
         if (i == 5) continue;
         const BlurTap t = fetch(i);
         const bool ok = (dot3(t.n, c.n) >= 0.8f) & (__builtin_fabsf(t.z - c.z) <= 0.2f);  // :131-132
-        const float c2 = color + w[i] * t.a, t2 = total + w[i];   // select, not branch: the wave never diverges here
-        color = ok ? c2 : color;
-        total = ok ? t2 : total;
+        // A rejected tap adds weight 0: color + 0 * a and total + 0 leave both sums bit-unchanged (a is a decoded UNORM,
+        // finite and >= 0, so neither sum is ever -0) -- one select instead of two, and the wave never diverges here.
+        const float ws = ok ? w[i] : 0.0f;
+        color = color + ws * t.a;
+        total = total + ws;
         mask |= ok ? (1u << i) : 0u;
     }
     return BlurOut{ float_to_unorm16(color / total), mask, total };  // :145
@@ -308,8 +304,10 @@ CRY_HD uint32_t blur_pixel_replay(const float* __restrict__ w, uint32_t mask, fl
 #pragma unroll
     for (int i = 0; i < 11; ++i) {
         if (i == 5) continue;
-        const float c2 = color + w[i] * amb(i);
-        color = (mask & (1u << i)) ? c2 : color;
+        // weight or +0.0 by AND-ing the weight's bits with the sign-extended mask bit (v_bfe_i32 + v_and_b32); adding 0 * a
+        // leaves the sum bit-unchanged, see blur_pixel_full
+        const uint32_t keep = (uint32_t)(((int32_t)(mask << (31 - i))) >> 31);
+        color = color + u2f(f2u(w[i]) & keep) * amb(i);
     }
     return float_to_unorm16(color / total);
 }
