@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, co
                                                    const uint32_t* __restrict__ depth,
                                                    const uint32_t* __restrict__ randvec,
                                                    uint16_t* __restrict__ ambient, EdgePlane edge, uint32_t W,
-                                                   uint32_t H, uint32_t row0, uint32_t row1, uint32_t SX, uint32_t SY)
+                                                   uint32_t H, uint32_t row0, uint32_t row1, uint32_t SX, uint32_t SY, int sparseProjTex)
 {
     const uint32_t w2 = W / 2;
     uint32_t bx, by;
@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, co
         if (x == 0) edge.gcol[y] = normal[(2u * y + 1u) * W];   // texel (0, 2y+1)
         if (y == row0) edge.grow[x] = normal[2u * x + 1u];      // texel (2x+1, 0)
     }
-    if (EMIT_AO) ambient[y * w2 + x] = (uint16_t)ssao_pixel(cb, c, depth, randvec, W, H, x, y);
+    if (EMIT_AO) ambient[y * w2 + x] = (uint16_t)ssao_pixel(cb, c, depth, randvec, W, H, x, y, sparseProjTex != 0);
 }
 
 // ---- bilateral blur ------------------------------------------------------------------------------------------
@@ -391,12 +391,13 @@ hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, con
     SY = SY > grid.y ? grid.y : SY;
     grid.x = (grid.x + SX - 1u) / SX * SX;
     grid.y = (grid.y + SY - 1u) / SY * SY;
+    const int sparse = ssao_projtex_is_sparse(cb) ? 1 : 0;
     if (emit_ao)
         hipLaunchKernelGGL(ssao_kernel<true>, grid, dim3(256), 0, stream, cb, (const u2*)normal, depth,
-                           (const uint32_t*)randvec, ambient, e, W, H, row0, row0 + rows, SX, SY);
+                           (const uint32_t*)randvec, ambient, e, W, H, row0, row0 + rows, SX, SY, sparse);
     else
         hipLaunchKernelGGL(ssao_kernel<false>, grid, dim3(256), 0, stream, cb, (const u2*)normal, depth,
-                           (const uint32_t*)randvec, ambient, e, W, H, row0, row0 + rows, SX, SY);
+                           (const uint32_t*)randvec, ambient, e, W, H, row0, row0 + rows, SX, SY, sparse);
     return hipGetLastError();
 }
 

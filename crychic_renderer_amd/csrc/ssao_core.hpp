@@ -143,10 +143,30 @@ CRY_HD SsaoCentre ssao_centre(const crychic_ssao_constants& cb, const u2* __rest
     return c;
 }
 
-// Ssao.hlsl:117-199 for half-res pixel (x, y); returns the R16_UNORM ambient value.
+// gProjTex = Proj * T (CRYCHIC.cpp:828-834,918) has seven structural zeros and a one for every perspective projection:
+//   x' = q.x PT[0] + q.z PT[2],  y' = q.y PT[5] + q.z PT[6],  w' = q.z.
+// Skipping the products with exact zeros changes no output bit as long as q is finite (x * 0 = +-0, and a +-0 term can
+// only change the sign of a zero sum; a zero x', y' or w' yields the same texel / BORDER decision under either sign, see
+// DESIGN.md) -- so the short form is used when the constants have that pattern and are bounded (checked once on the
+// host) and the pixel's p is bounded (checked per pixel; a wave with any other lane takes the general loop).
+template <bool V> struct SparseTag { static constexpr bool value = V; };
+CRY_HD bool ssao_projtex_is_sparse(const crychic_ssao_constants& cb)
+{
+    const float* PT = cb.ProjTex;
+    bool ok = PT[1] == 0.0f && PT[3] == 0.0f && PT[4] == 0.0f && PT[7] == 0.0f && PT[12] == 0.0f && PT[13] == 0.0f && PT[14] == 1.0f &&
+              PT[15] == 0.0f;
+    const float big = 1.0e12f;
+    ok = ok && __builtin_fabsf(PT[0]) < big && __builtin_fabsf(PT[2]) < big && __builtin_fabsf(PT[5]) < big && __builtin_fabsf(PT[6]) < big;
+    ok = ok && __builtin_fabsf(cb.OcclusionRadius) < big;
+    for (int i = 0; i < 14; ++i)
+        for (int k = 0; k < 3; ++k) ok = ok && __builtin_fabsf(cb.OffsetVectors[i][k]) < big;   // false for NaN too
+    return ok;
+}
+
+// Ssao.hlsl:117-199 for half-res pixel (x, y); returns the R16_UNORM ambient value.  `sparseProjTex` = ssao_projtex_is_sparse(cb).
 CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c,
                            const uint32_t* __restrict__ depth, const uint32_t* __restrict__ randvec, uint32_t W,
-                           uint32_t H, uint32_t x, uint32_t y)
+                           uint32_t H, uint32_t x, uint32_t y, bool sparseProjTex)
 {
     const uint32_t w2 = W / 2, h2 = H / 2;
     const float u = ((float)x + 0.5f) / (float)w2;
@@ -176,7 +196,15 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
     const f3x2 n2 = splat3(n), p2 = splat3(p), rv2 = splat3(randVec);
     const float A = cb.Proj[4 * 2 + 2], B = cb.Proj[4 * 2 + 3];   // Ssao.hlsl:110-115
     const float* PT = cb.ProjTex;
+    // |p| < 2^100 and bounded constants keep every q finite (|offset| <= 3e12 * 5, |fr| <= 1e12)
+    const float pmax = 1.2676506e30f;
+    bool sparse = sparseProjTex && __builtin_fabsf(p.x) < pmax && __builtin_fabsf(p.y) < pmax && __builtin_fabsf(p.z) < pmax;
+#if defined(__HIP_DEVICE_COMPILE__)
+    sparse = __builtin_amdgcn_ballot_w64(!sparse) == 0;     // wave-uniform: one loop per wave
+#endif
     float occlusionSum = 0.0f;
+    auto taps = [&](auto sparseTag) {
+    constexpr bool SPARSE = decltype(sparseTag)::value;
 #pragma unroll 1
     for (int i = 0; i < 14; i += 2) {
         const f3x2 o{ v2f{ cb.OffsetVectors[i][0], cb.OffsetVectors[i + 1][0] }, v2f{ cb.OffsetVectors[i][1], cb.OffsetVectors[i + 1][1] },
@@ -185,9 +213,16 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
         const f3x2 offset{ o.x - d2 * rv2.x, o.y - d2 * rv2.y, o.z - d2 * rv2.z };
         const v2f fr = sign2(dot3x2(offset, n2)) * cb.OcclusionRadius;            // :151,154
         const f3x2 q{ p2.x + fr * offset.x, p2.y + fr * offset.y, p2.z + fr * offset.z };
-        const v2f pqx = ((q.x * PT[0] + q.y * PT[1]) + q.z * PT[2]) + PT[3];      // mul(float4(q,1), gProjTex)  :157
-        const v2f pqy = ((q.x * PT[4] + q.y * PT[5]) + q.z * PT[6]) + PT[7];
-        const v2f pqw = ((q.x * PT[12] + q.y * PT[13]) + q.z * PT[14]) + PT[15];
+        v2f pqx, pqy, pqw;                                                        // mul(float4(q,1), gProjTex)  :157
+        if (SPARSE) {
+            pqx = q.x * PT[0] + q.z * PT[2];
+            pqy = q.y * PT[5] + q.z * PT[6];
+            pqw = q.z;
+        } else {
+            pqx = ((q.x * PT[0] + q.y * PT[1]) + q.z * PT[2]) + PT[3];
+            pqy = ((q.x * PT[4] + q.y * PT[5]) + q.z * PT[6]) + PT[7];
+            pqw = ((q.x * PT[12] + q.y * PT[13]) + q.z * PT[14]) + PT[15];
+        }
         const v2f tu = div2(pqx, pqw), tv = div2(pqy, pqw);                       // :158
 
         // gsamDepthMap, both taps: bilinear setup in packed form, the 2 x 2 footprints through the paired loads
@@ -231,6 +266,8 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
         occlusionSum += term.x;                                                   // :188-190, tap i then tap i+1
         occlusionSum += term.y;
     }
+    };
+    if (sparse) taps(SparseTag<true>{}); else taps(SparseTag<false>{});
     occlusionSum = occlusionSum / 14.0f;                                         // :193
     const float access = 1.0f - occlusionSum;                                    // :195
     const float a2 = access * access, a4 = a2 * a2;                              // :198 pow(access, 6)

@@ -48,6 +48,9 @@ def random_case(seed, built_lib):
     s.OcclusionFadeStart = float(rng.choice([0.0, 0.2, 1.0]))
     s.OcclusionFadeEnd = float(rng.choice([1.0, 2.0, s.OcclusionFadeStart]))     # start == end: division by zero
     s.SurfaceEpsilon = float(rng.choice([0.0, 0.05, 0.5]))
+    if rng.random() < 0.35:            # a sheared projection: the kernels must leave their sparse-gProjTex fast path
+        s.ProjTex[1] = float(rng.choice([0.05, -0.2]))
+        s.ProjTex[13] = float(rng.choice([0.0, 0.01]))
     for i in range(3):
         d = rng.standard_normal(3)
         d = d / np.linalg.norm(d) if rng.random() > 0.1 else np.zeros(3)

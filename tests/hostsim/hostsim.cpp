@@ -59,7 +59,7 @@ void hs_ssao(const crychic_ssao_constants* cb, const void* normal, const uint32_
                 if (x == 0) e.gcol[y] = nrm[(2u * y + 1u) * W];
                 if (y == row0) e.grow[x] = nrm[2u * x + 1u];
             }
-            if (ambient) ambient[y * w2 + x] = (uint16_t)ssao_pixel(*cb, c, depth, (const uint32_t*)randvec, W, H, x, y);
+            if (ambient) ambient[y * w2 + x] = (uint16_t)ssao_pixel(*cb, c, depth, (const uint32_t*)randvec, W, H, x, y, ssao_projtex_is_sparse(*cb));
         }
 }
 
