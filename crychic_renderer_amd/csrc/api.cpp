@@ -135,6 +135,7 @@ int fill_light_params(cry::LightParams& P, const crychic_pass_constants* cb, con
     P.flags = flags;
     P.pointLights = nullptr;
     P.numPointLights = 0;
+    P.shadowWIsOne = cry::light_shadow_w_is_one(P.ShadowTransforms) ? 1u : 0u;
     return 0;
 }
 

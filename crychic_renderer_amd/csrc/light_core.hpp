@@ -25,6 +25,7 @@ struct LightParams {
     uint32_t flags;
     const crychic_light* pointLights;   // extension (BASELINE configs[4]): NUM_POINT_LIGHTS lights in a device buffer
     uint32_t numPointLights;
+    uint32_t shadowWIsOne;     // light_shadow_w_is_one(): every cascade's ShadowTransform has the w column (0, 0, 0, 1)
 };
 
 constexpr uint32_t kMaxPointLights = 1024;   // tile masks live in LDS: 32 words
@@ -67,11 +68,13 @@ CRY_HD float shadow_cmp_linear(const uint32_t* __restrict__ s, uint32_t dim, flo
 // CalcCascadeShadowFactorWithPoisson  Common.hlsl:263-317
 // ZERO_RADIUS is a compile-time promise that radius == 0 (the reference's own value): it removes the general tap loop
 // from the instantiation the reference-literal configuration runs.
-template <bool ZERO_RADIUS>
+// W_ONE is a promise that spw == 1.0f exactly (orthographic light projection, bounded posW): x / 1 is x, so the three
+// divisions of the perspective divide are skipped without changing a bit.
+template <bool ZERO_RADIUS, bool W_ONE = false>
 CRY_HD float pcf_poisson(const uint32_t* __restrict__ s, uint32_t dim, float spx, float spy, float spz, float spw,
                          float radius)
 {
-    const float x = spx / spw, y = spy / spw, depth = spz / spw;  // :266-269
+    const float x = W_ONE ? spx : spx / spw, y = W_ONE ? spy : spy / spw, depth = W_ONE ? spz : spz / spw;  // :266-269
     float percentLit = 0.0f;
     if (ZERO_RADIUS || radius == 0.0f) {
         // Common.hlsl:305 as written (uint division) gives radius 0: every one of the 16 taps is
@@ -91,6 +94,18 @@ CRY_HD float pcf_poisson(const uint32_t* __restrict__ s, uint32_t dim, float spx
         }
     }
     return percentLit / 16.0f;                                    // :315
+}
+
+// The cascades' light projections are orthographic (CRYCHIC.cpp:804), so ShadowTransform = lightView * ortho * T has the
+// w column (0, 0, 0, 1): shadowPosH.w = ((x*0 + y*0) + z*0) + 1 is exactly 1 for every finite posW.
+CRY_HD bool light_shadow_w_is_one(const float (*T)[16])
+{
+    bool ok = true;
+    for (int j = 0; j < 4; ++j) {
+        ok = ok && T[j][12] == 0.0f && T[j][13] == 0.0f && T[j][14] == 0.0f && T[j][15] == 1.0f;
+        for (int k = 0; k < 12; ++k) ok = ok && __builtin_fabsf(T[j][k]) < 1.0e12f;
+    }
+    return ok;
 }
 
 CRY_HD float pow5(float x) { float x2 = x * x, x4 = x2 * x2; return x4 * x; }
@@ -250,23 +265,27 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
     else if (distance < 80.0f) j = 2;
     else if (distance < 100.0f) j = 3;
     if (j < 4) {
-        const float* T0 = P.ShadowTransforms[j];
-        const uint32_t* s0 = P.shadow[j];
-        const float a = pcf_poisson<ZERO_RADIUS>(s0, P.shadowDim, mulcol(posW.x, posW.y, posW.z, 1.0f, T0 + 0),
-                                    mulcol(posW.x, posW.y, posW.z, 1.0f, T0 + 4),
-                                    mulcol(posW.x, posW.y, posW.z, 1.0f, T0 + 8),
-                                    mulcol(posW.x, posW.y, posW.z, 1.0f, T0 + 12), P.pcfSearchRadius);
-        if (j < 3) {
-            const float* T1 = P.ShadowTransforms[j + 1];
-            const uint32_t* s1 = P.shadow[j + 1];
-            const float b = pcf_poisson<ZERO_RADIUS>(s1, P.shadowDim, mulcol(posW.x, posW.y, posW.z, 1.0f, T1 + 0),
-                                        mulcol(posW.x, posW.y, posW.z, 1.0f, T1 + 4),
-                                        mulcol(posW.x, posW.y, posW.z, 1.0f, T1 + 8),
-                                        mulcol(posW.x, posW.y, posW.z, 1.0f, T1 + 12), P.pcfSearchRadius);
-            shadow0 = 0.5f * (a + b);                           // :66
-        } else {
-            shadow0 = a;                                        // :73
-        }
+        // posW bounded => no product with a zero matrix entry is NaN / inf => shadowPosH.w == 1 (light_shadow_w_is_one)
+        const float pmax = 1.2676506e30f;
+        bool wOne = P.shadowWIsOne && __builtin_fabsf(posW.x) < pmax && __builtin_fabsf(posW.y) < pmax && __builtin_fabsf(posW.z) < pmax;
+#if defined(__HIP_DEVICE_COMPILE__)
+        wOne = __builtin_amdgcn_ballot_w64(!wOne) == 0;          // wave-uniform choice of the instantiation
+#endif
+        auto cascade = [&](int k) {
+            const float* T = P.ShadowTransforms[k];
+            const float spx = mulcol(posW.x, posW.y, posW.z, 1.0f, T + 0), spy = mulcol(posW.x, posW.y, posW.z, 1.0f, T + 4);
+            const float spz = mulcol(posW.x, posW.y, posW.z, 1.0f, T + 8);
+            if (wOne) return pcf_poisson<ZERO_RADIUS, true>(P.shadow[k], P.shadowDim, spx, spy, spz, 1.0f, P.pcfSearchRadius);
+            float spw = mulcol(posW.x, posW.y, posW.z, 1.0f, T + 12);
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" : "+v"(spw));   // keeps the three divisions inside this (rare) branch: the optimiser would otherwise
+                                            // speculate them above the wave-uniform test and select afterwards
+#endif
+            return pcf_poisson<ZERO_RADIUS, false>(P.shadow[k], P.shadowDim, spx, spy, spz, spw, P.pcfSearchRadius);
+        };
+        const float a = cascade(j);
+        if (j < 3) shadow0 = 0.5f * (a + cascade(j + 1));      // :66
+        else shadow0 = a;                                       // :73
     }
 
     const float shininess = (1.0f - roughness) * 1.0f;          // :84 (normalW.a == 1)
