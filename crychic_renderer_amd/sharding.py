@@ -10,11 +10,75 @@ import torch.distributed as dist
 from ._lib import check, lib
 
 
+class _Batch:
+    """The requests of one batch_isend_irecv call behind the wait() of a single Work."""
+
+    def __init__(self, reqs):
+        self.reqs = reqs
+
+    def wait(self):
+        for r in self.reqs:
+            r.wait()
+
+
 def strip_rows(H, nranks, rank):
     """Full-res rows (row0, rows) owned by `rank` (crychic_strip_rows: even-row aligned, last rank takes the rest)."""
     r0, rn = C.c_uint32(), C.c_uint32()
     check(lib.crychic_strip_rows(int(H), int(nranks), int(rank), C.byref(r0), C.byref(rn)))
     return r0.value, rn.value
+
+
+class StripBalancer:
+    """Measured load balancing of the row strips.
+
+    Keeps a cost estimate per half-res row pair, seeded from the depth plane's coverage (a covered row costs about
+    `covered_row_weight` sky rows: the lighting pass only works on covered pixels, SSAO taps reach further on near
+    geometry).  After every rank has timed its strip, update() rescales the estimates inside each strip so that they sum to
+    the measured time (the shape inside a strip is kept, so the estimate sharpens as the boundaries move) and plan() cuts
+    the cumulative cost into equal parts, moving each boundary `damping` of the way (the per-strip fixed cost -- launches,
+    blur halos -- does not move with the rows, so an undamped step overshoots).  Everything is a pure function of the
+    depth plane and the all-gathered times, so every rank derives the same plan without further communication."""
+
+    def __init__(self, depth, nranks, covered_row_weight=3.0, damping=0.7):
+        H = int(depth.shape[0])
+        self.h2, self.n, self.damping = H // 2, int(nranks), float(damping)
+        covered = ((depth.reshape(H, -1).to(torch.int64) & 0xFFFFFF) != 0xFFFFFF).sum(dim=1)     # exact integer counts
+        cov = (covered.reshape(self.h2, 2).sum(dim=1).to(torch.float64) / (2.0 * depth.shape[1])).cpu()
+        self.cost = (1.0 + (covered_row_weight - 1.0) * cov).tolist()
+        self.edges = self._cut([0] * (self.n + 1), 1.0)
+
+    def _cut(self, old_edges, damping):
+        total, edges, acc, row = sum(self.cost), [0], 0.0, 0
+        for k in range(1, self.n):
+            target = total * k / self.n
+            while row < self.h2 and acc + self.cost[row] < target:
+                acc += self.cost[row]
+                row += 1
+            pos = row + ((target - acc) / self.cost[row] if row < self.h2 else 0.0)
+            e = int(round(old_edges[k] + damping * (pos - old_edges[k])))
+            edges.append(max(edges[-1] + 1, min(e, self.h2 - (self.n - k))))      # every strip keeps at least one row pair
+        edges.append(self.h2)
+        return edges
+
+    def bounds(self):
+        """[(row0, rows)] per rank in full-res rows (even-aligned)."""
+        return [(2 * self.edges[r], 2 * (self.edges[r + 1] - self.edges[r])) for r in range(self.n)]
+
+    def update(self, times):
+        """times[r] = what rank r measured for its current strip; returns the new bounds()."""
+        for r in range(self.n):
+            a, b = self.edges[r], self.edges[r + 1]
+            est = sum(self.cost[a:b])
+            f = max(float(times[r]), 1e-9) / est
+            for i in range(a, b):
+                self.cost[i] *= f
+        self.edges = self._cut(self.edges, self.damping)
+        return self.bounds()
+
+
+def balanced_strips(depth, nranks, covered_row_weight=3.0):
+    """The coverage-based first guess of StripBalancer (no measurements)."""
+    return StripBalancer(depth, nranks, covered_row_weight).bounds()
 
 
 class FrameGather:
@@ -28,8 +92,19 @@ class FrameGather:
 
     SLOTS = 2
 
-    def __init__(self, W, H, nranks, rank, device, group=None):
+    def __init__(self, W, H, nranks, rank, device, group=None, bounds=None):
+        """bounds = [(row0, rows)] per rank selects the point-to-point mode for strips of any size (balanced_strips): every
+        rank sends its strip to each peer and receives theirs straight into its own full-frame render buffer (one grouped
+        batch of sends / receives -- on the fully connected xGMI mesh each link carries exactly one strip), so the
+        gathered frame of a slot is render[slot] itself.  Without bounds: equal strips and one all_gather_into_tensor."""
         self.W, self.H, self.nranks, self.rank, self.group = W, H, nranks, rank, group
+        self.bounds = [tuple(int(v) for v in b) for b in bounds] if bounds is not None else None
+        if self.bounds is not None:
+            assert len(self.bounds) == nranks and sum(b[1] for b in self.bounds) == H and self.bounds[0][0] == 0
+            self.row0, self.rows = self.bounds[rank]
+            self.render = [torch.zeros((H, W, 4), dtype=torch.uint8, device=device) for _ in range(self.SLOTS)]
+            self.pending = [None] * self.SLOTS
+            return
         self.row0, self.rows = strip_rows(H, nranks, rank)
         self.uniform = (H // 2) % nranks == 0
         self.max_rows = max(strip_rows(H, nranks, r)[1] for r in range(nranks))
@@ -51,6 +126,18 @@ class FrameGather:
 
     def launch(self, i):
         s = i % self.SLOTS
+        if self.bounds is not None:
+            buf = self.render[s]
+            ops = []
+            for p in range(self.nranks):
+                if p == self.rank:
+                    continue
+                r0, rn = self.bounds[p]
+                peer = p if self.group is None else dist.get_global_rank(self.group, p)
+                ops.append(dist.P2POp(dist.isend, buf[self.row0:self.row0 + self.rows], peer, self.group))
+                ops.append(dist.P2POp(dist.irecv, buf[r0:r0 + rn], peer, self.group))
+            self.pending[s] = _Batch(dist.batch_isend_irecv(ops)) if ops else None
+            return
         strip = self.render[s][self.row0:self.row0 + self.rows]
         if self.uniform:
             send = strip
@@ -68,6 +155,8 @@ class FrameGather:
     def frame(self, i):
         """The gathered H x W x 4 frame of step i (valid after wait_all / the slot's wait)."""
         s = i % self.SLOTS
+        if self.bounds is not None:
+            return self.render[s]
         f = self.frames[s]
         if self.uniform:
             return f[:self.H]

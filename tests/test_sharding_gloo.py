@@ -20,6 +20,7 @@ import oracle_lib, scene_util
 from crychic_renderer_amd import sharding
 from crychic_renderer_amd._lib import lib
 W, H = int(sys.argv[2]), int(sys.argv[3])
+mode = sys.argv[4] if len(sys.argv) > 4 else "equal"
 dist.init_process_group("gloo")
 rank, world = dist.get_rank(), dist.get_world_size()
 orc = oracle_lib.load()
@@ -27,13 +28,19 @@ pl = scene_util.cpu_scene(W, H, 256, 32); p = scene_util.np_planes(pl); c = pl["
 scb = oracle_lib.as_oracle_cb(c.ssao_cb, oracle_lib.OrSsaoConstants)
 pcb = oracle_lib.as_oracle_cb(c.pass_cb, oracle_lib.OrPassConstants)
 ao = orc.compute_ssao(scb, p["normal"], p["depth"], p["randvec"], 2)
-row0, rows = sharding.strip_rows(H, world, rank)
-g = sharding.FrameGather(W, H, world, rank, torch.device("cpu"))
+if mode == "balanced":          # cost-aware strips of different heights + point-to-point exchange
+    bounds = sharding.balanced_strips(torch.from_numpy(p["depth"].view(np.int32)), world)
+    assert sum(b[1] for b in bounds) == H and all(b[1] >= 2 and b[1] % 2 == 0 for b in bounds)
+    row0, rows = bounds[rank]
+    g = sharding.FrameGather(W, H, world, rank, torch.device("cpu"), bounds=bounds)
+else:
+    row0, rows = sharding.strip_rows(H, world, rank)
+    g = sharding.FrameGather(W, H, world, rank, torch.device("cpu"))
 assert (g.row0, g.rows) == (row0, rows)
 full = [orc.deferred_light(pcb, p["g0"], p["g1"], p["g2"], p["depth"], ao, p["shadow"], p["cube"], nl, 0.0) for nl in (1, 2, 3)]
 for i, nl in enumerate((1, 2, 3)):           # three frames through the two slots
     buf = g.strip_buffer(i)
-    buf.zero_()
+    buf.fill_(7)
     strip = orc.deferred_light(pcb, p["g0"], p["g1"], p["g2"], p["depth"], ao, p["shadow"], p["cube"], nl, 0.0, row0=row0, rows=rows)
     buf[row0:row0 + rows] = torch.from_numpy(strip[row0:row0 + rows])
     g.launch(i)
@@ -56,15 +63,16 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("world,W,H", [(2, 64, 48), (3, 64, 40), (2, 34, 34)])
-def test_strip_gather_gloo(built_lib, oracle, tmp_path, world, W, H):
+@pytest.mark.parametrize("world,W,H,mode", [(2, 64, 48, "equal"), (3, 64, 40, "equal"), (2, 34, 34, "equal"),
+                                            (2, 64, 48, "balanced"), (3, 64, 40, "balanced")])
+def test_strip_gather_gloo(built_lib, oracle, tmp_path, world, W, H, mode):
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE=str(world), OMP_NUM_THREADS="2")
     procs = []
     for r in range(world):
         e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
-        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(W), str(H)], env=e, stdout=subprocess.PIPE,
+        procs.append(subprocess.Popen([sys.executable, str(script), ROOT, str(W), str(H), mode], env=e, stdout=subprocess.PIPE,
                                       stderr=subprocess.STDOUT, text=True))
     outs = []
     for p in procs:
@@ -78,3 +86,34 @@ def test_strip_gather_gloo(built_lib, oracle, tmp_path, world, W, H):
     for r, (p, out) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, out[-3000:])
         assert "rank %d ok" % r in out
+
+
+def test_strip_balancer_converges(built_lib):
+    """sharding.StripBalancer against a synthetic cost model (fixed cost per strip + cheap sky rows, expensive ground rows):
+    plans stay valid (even rows, >= 2 each, contiguous, sum = H) and the slowest strip gets faster."""
+    import torch
+    from crychic_renderer_amd import sharding
+    H, Wd = 2160, 16
+    depth = torch.full((H, Wd), 0xFFFFFF, dtype=torch.int32)
+    depth[1000:] = 12345                                               # ground below full-res row 1000
+    cost_row = np.where(np.arange(H // 2) < 500, 0.05, 0.22)          # microseconds per half-res row
+
+    def times(bounds):
+        return [60.0 + float(cost_row[b[0] // 2:(b[0] + b[1]) // 2].sum()) for b in bounds]
+
+    for n in (2, 3, 4, 8):
+        equal = [sharding.strip_rows(H, n, r) for r in range(n)]
+        bal = sharding.StripBalancer(depth, n)
+        bounds = bal.bounds()
+        assert bounds[0][1] > bounds[-1][1]                            # the sky strip starts out taller
+        for _ in range(5):
+            bounds = bal.update(times(bounds))
+            assert sum(b[1] for b in bounds) == H and bounds[0][0] == 0
+            assert all(b[1] >= 2 and b[1] % 2 == 0 and b[0] % 2 == 0 for b in bounds)
+            assert all(bounds[i][0] + bounds[i][1] == bounds[i + 1][0] for i in range(n - 1))
+        t0, t1 = times(equal), times(bounds)
+        assert max(t1) < max(t0) * 0.93, (n, max(t0), max(t1))
+        assert max(t1) - min(t1) < 0.25 * (max(t0) - min(t0)), (n, t0, t1)
+    # same inputs -> same plan (every rank computes it independently)
+    a, b = sharding.StripBalancer(depth, 4), sharding.StripBalancer(depth, 4)
+    assert a.update([1.0, 2.0, 3.0, 4.0]) == b.update([1.0, 2.0, 3.0, 4.0])
