@@ -303,6 +303,16 @@ def main():
     for i in range(args.warmup):
         step(i)
     fence()
+    exchange_ok = None
+    if gather is not None and world > 1 and args.warmup > 0:
+        # every rank must now hold the same complete frame: compare a checksum of the last gathered frame across ranks
+        f = gather.frame(args.warmup - 1)
+        chk = (f.reshape(-1).to(torch.int64) * (torch.arange(f.numel(), device=dev, dtype=torch.int64) % 251 + 1)).sum().reshape(1)
+        allchk = torch.zeros(world, device=dev, dtype=torch.int64)
+        dist.all_gather_into_tensor(allchk, chk)
+        exchange_ok = bool((allchk == allchk[0]).all().item()) and bool((f[..., 3] == 255).all().item())
+        if not exchange_ok:
+            raise SystemExit("bench.py: the ranks disagree on the gathered frame (checksums %s)" % allchk.tolist())
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
@@ -353,6 +363,7 @@ def main():
                                                                                              args.pcf, args.shadow_dim),
                        "sharding": ("%s row strips x%d + RCCL %s of RGBA8 strips" % (args.partition, world, "point-to-point exchange"
                                     if bounds else "all-gather")) if world > 1 else "single GPU",
+                       "exchange_verified": exchange_ok,
                        "strip_rows": rows, "strip_plan": [b[1] for b in bounds] if bounds and world > 1 else None,
                        "launch": "hipGraph replay" if use_graph else "eager",
                        "strip_only": args.strip or None,
