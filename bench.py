@@ -8,7 +8,10 @@ on N MI355X GPUs of one node.
 
 A "step" is one frame: every input plane (G-buffer, view normals, depth, 4 shadow cascades, cubemap, noise) is
 already resident in HBM; the step runs crychic_draw_hot_path for this rank's row strip and, for N > 1, the RCCL
-all-gather of the composed RGBA8 strips (strong scaling of ONE frame, the only collective).
+exchange of the composed RGBA8 strips (strong scaling of ONE frame, the only collective).
+Consecutive frames are independent, so two frame pipelines (two HIP streams, each with its own ambient / edge
+workspace, --frames-in-flight) alternate: `value` is steady-state throughput; config.pass_ms is the latency view
+(one frame at a time on one stream).  N > 1: strips are cost-balanced from measured strip times (--partition).
 Workload = BASELINE.json configs[2]: 3840x2160, 3 directional lights, blurCount 4, cascade PCF.
 The PCF radius follows the reference shader as written (Common.hlsl:305 unsigned division => 16 coincident taps);
 --pcf intended benches the 2.5-texel variant instead.
@@ -46,6 +49,13 @@ def parse():
     ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
                     help="replay the frame's launches from a captured hipGraph (auto = off: on a 1/8 strip the replay measured "
                          "0.085 ms against 0.081 ms for eager launches, which the GPU already pipelines)")
+    ap.add_argument("--frames-in-flight", type=int, default=0,
+                    help="independent frame pipelines (own stream + own ambient / edge workspace) alternating frames: the head and "
+                         "tail of one frame's kernels overlap the other's (measured: -11 %% per whole 4K frame, -27 %% per 1/8 strip).  "
+                         "0 = auto: 1 at N = 1 (clean per-kernel durations for the roofline object), 2 for the strips of N > 1")
+    ap.add_argument("--also-two-in-flight", action="store_true",
+                    help="N = 1: additionally time the K frames with two frames in flight and report it as an informational field "
+                         "(off by default: its co-scheduled kernels would stretch the per-kernel averages of a rocprofv3 trace of the run)")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the strip all-gather (RCCL) even with one rank: exercises the N > 1 code path on a 1-GPU box")
     ap.add_argument("--partition", choices=["balanced", "equal"], default="balanced",
@@ -278,19 +288,38 @@ def main():
             graphs, use_graph = {}, False
             torch.cuda.synchronize()
 
-    def draw(slot_buffer):
+    # Frames in flight: consecutive frames are independent, so a second pipeline (own stream, own ambient / edge workspace,
+    # same read-only input planes) lets the short kernels of one strip fill the dispatch gaps of the other.
+    # auto: one frame at a time at N = 1 (the roofline object below needs kernel durations that are not stretched by a
+    # co-running frame, and has to agree with a rocprofv3 trace of this very command), two for the short strips of N > 1
+    nflight = args.frames_in_flight or (2 if rows < H else 1)
+    nflight = 1 if use_graph else max(1, min(nflight, 2))     # three or four measured the same as two
+    apps, streams = [app], [torch.cuda.current_stream(dev)]
+    for _ in range(nflight - 1):
+        a = Crychic(ctx, W, H, planes["randvec"], planes["cube"], shadow_dim=args.shadow_dim)
+        a.load_scene(planes)
+        a.blurCount, a.numDirLights, a.pcfSearchRadius = app.blurCount, app.numDirLights, app.pcfSearchRadius
+        if args.point_lights:
+            a.set_point_lights(scene.point_light_grid(args.point_lights))
+        apps.append(a)
+        streams.append(torch.cuda.Stream(device=dev))
+    outs = [planes["out"]] + [torch.zeros_like(planes["out"]) for _ in range(nflight - 1)]
+
+    def draw(k, slot_buffer):
         if use_graph:
             graphs[slot_buffer.data_ptr()].replay()
         else:
-            app.mBackBuffer = slot_buffer
-            app.Draw(row0, rows)
+            apps[k].mBackBuffer = slot_buffer
+            apps[k].Draw(row0, rows)
 
     def step(i):
-        if gather is None:
-            draw(planes["out"])
-        else:
-            draw(gather.strip_buffer(i))               # double-buffered so gather(i) overlaps Draw(i+1)
-            gather.launch(i)
+        k = i % nflight
+        with torch.cuda.stream(streams[k]):            # launches, the exchange's pre-sync and its wait all bind to this stream
+            if gather is None:
+                draw(k, outs[k])
+            else:
+                draw(k, gather.strip_buffer(i))        # double-buffered so the exchange of frame i overlaps Draw(i+1)
+                gather.launch(i)
 
     def fence():
         if gather is not None:
@@ -318,10 +347,36 @@ def main():
         step(i)
     fence()
     dt = time.perf_counter() - t0
+    if gather is None and nflight > 1 and not torch.equal(outs[0], outs[1]):
+        raise SystemExit("bench.py: the two frame pipelines disagree")      # same inputs, same kernels: must be the same bytes
     if use_dist:
         tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+
+    # ---- informational at N = 1: the same K frames with two frames in flight (not `value`, see --frames-in-flight) ----
+    overlapped = None
+    if args.also_two_in_flight and world == 1 and not args.strip and nflight == 1 and not use_graph:
+        app2 = Crychic(ctx, W, H, planes["randvec"], planes["cube"], shadow_dim=args.shadow_dim)
+        app2.load_scene(planes)
+        app2.blurCount, app2.numDirLights, app2.pcfSearchRadius = app.blurCount, app.numDirLights, app.pcfSearchRadius
+        if args.point_lights:
+            app2.set_point_lights(scene.point_light_grid(args.point_lights))
+        app2.mBackBuffer = torch.zeros_like(planes["out"])
+        app.mBackBuffer = planes["out"]
+        pair = [(app, torch.cuda.current_stream(dev)), (app2, torch.cuda.Stream(device=dev))]
+        for phase in range(2):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(args.steps if phase else 10):
+                a_, st_ = pair[i % 2]
+                with torch.cuda.stream(st_):
+                    a_.Draw(row0, rows)
+            torch.cuda.synchronize()
+            t_ov = time.perf_counter() - t1
+        if not torch.equal(app2.mBackBuffer, planes["out"]):
+            raise SystemExit("bench.py: the two frame pipelines disagree")
+        overlapped = {"Mpixels_per_s": round(W * H * args.steps / t_ov / 1e6, 1), "ms_per_frame": round(t_ov / args.steps * 1e3, 4)}
 
     # ---- per-pass timing of the same workload (HIP events recorded by the library on the launch stream) ----
     app.set_profiling(True)
@@ -363,7 +418,8 @@ def main():
                                                                                              args.pcf, args.shadow_dim),
                        "sharding": ("%s row strips x%d + RCCL %s of RGBA8 strips" % (args.partition, world, "point-to-point exchange"
                                     if bounds else "all-gather")) if world > 1 else "single GPU",
-                       "exchange_verified": exchange_ok,
+                       "exchange_verified": exchange_ok, "frames_in_flight": nflight,
+                       "two_frames_in_flight_informational": overlapped,
                        "strip_rows": rows, "strip_plan": [b[1] for b in bounds] if bounds and world > 1 else None,
                        "launch": "hipGraph replay" if use_graph else "eager",
                        "strip_only": args.strip or None,
@@ -371,7 +427,7 @@ def main():
                        "frame_algorithmic_MB": round(frame_bytes / 1e6, 1),
                        "frame_hbm_roofline_frac": round(frame_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS * world, 4)
                        if world == 1 else None,
-                       "pass_ms": {k: round(v, 4) for k, v in acc.items()},
+                       "pass_ms": {k: round(v, 4) for k, v in acc.items()},      # one frame at a time on one stream (latency view)
                        "producer_passes_ms": producer_ms,
                        "full_frame_ms_incl_producers": (round(dt / args.steps * 1e3 + producer_ms["shadow_4x%d" % args.shadow_dim]
                                                               + producer_ms["normals_depth+gbuffer"], 3)
