@@ -21,10 +21,10 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("graph", ["on", "off"])
-def test_bench_gather_path_single_rank_rccl(built_lib, graph):
+@pytest.mark.parametrize("graph,inflight", [("on", 1), ("off", 1), ("off", 2)])
+def test_bench_gather_path_single_rank_rccl(built_lib, graph, inflight):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-gather", "--graph", graph, "--steps", "7",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-gather", "--graph", graph, "--frames-in-flight", str(inflight), "--steps", "7",
            "--warmup", "3", "--width", "640", "--height", "360", "--shadow-dim", "512", "--cube-dim", "64",
            "--no-cpu-baseline", "--no-producers"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -35,3 +35,4 @@ def test_bench_gather_path_single_rank_rccl(built_lib, graph):
     out = json.loads(line)
     assert out["n_gpus"] == 1 and out["value"] > 0
     assert out["config"]["launch"] == ("hipGraph replay" if graph == "on" else "eager")
+    assert out["config"]["frames_in_flight"] == inflight
