@@ -329,6 +329,24 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # First exchange under guard: if the point-to-point batch of the balanced plan fails on any rank (an exception, not a
+    # hang), every rank falls back to equal strips + one all_gather_into_tensor, which uses the collective path only.
+    if gather is not None and world > 1 and bounds is not None:
+        failed = torch.zeros(1, device=dev, dtype=torch.int32)
+        try:
+            step(0)
+            gather.wait_all()
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            print("bench.py rank %d: strip exchange failed (%s); falling back to equal strips" % (rank, e), file=sys.stderr, flush=True)
+            failed.fill_(1)
+        dist.all_reduce(failed, op=dist.ReduceOp.MAX)
+        if int(failed.item()):
+            bounds = None
+            row0, rows = sharding.strip_rows(H, world, rank)
+            gather = sharding.FrameGather(W, H, world, rank, dev)
+            args.partition = "equal (fallback)"
+
     for i in range(args.warmup):
         step(i)
     fence()
