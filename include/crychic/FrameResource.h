@@ -7,77 +7,89 @@
 
 #define MaxLights 16  // Common/d3dUtil.h:226
 
-struct Light {  // Common/d3dUtil.h:216-224
-    DirectX::XMFLOAT3 Strength = { 0.5f, 0.5f, 0.5f };
-    float FalloffStart = 1.0f;
-    DirectX::XMFLOAT3 Direction = { 0.0f, -1.0f, 0.0f };
-    float FalloffEnd = 10.0f;
-    DirectX::XMFLOAT3 Position = { 0.0f, 0.0f, 0.0f };
-    float SpotPower = 64.0f;
-};
-
 namespace crychic_detail {
 inline DirectX::XMFLOAT4X4 Identity4x4() { return DirectX::XMFLOAT4X4{ { { 1, 0, 0, 0 }, { 0, 1, 0, 0 }, { 0, 0, 1, 0 }, { 0, 0, 0, 1 } } }; }
 }
 
-struct InstanceData {  // FrameResource.h:7-15
-    DirectX::XMFLOAT4X4 World = crychic_detail::Identity4x4();
-    DirectX::XMFLOAT4X4 TexTransform = crychic_detail::Identity4x4();
-    UINT MaterialIndex = 0;
-    UINT ObjPad0 = 0, ObjPad1 = 0, ObjPad2 = 0;
+// The records below are the data ABI of the path: what the reference's upload buffers hold byte for byte, hence what the
+// kernels read.  Field names follow the reference so its call sites compile; the numbers are byte offsets (checked by the
+// static_asserts underneath).  Defaults are set by the constructors.
+
+struct Light {                              // Common/d3dUtil.h:216-224, 48 B
+    DirectX::XMFLOAT3 Strength;             // +0
+    float FalloffStart;                     // +12   point / spot only
+    DirectX::XMFLOAT3 Direction;            // +16   directional / spot only
+    float FalloffEnd;                       // +28   point / spot only
+    DirectX::XMFLOAT3 Position;             // +32   point / spot only
+    float SpotPower;                        // +44   spot only
+    Light() : Strength{ 0.5f, 0.5f, 0.5f }, FalloffStart(1.0f), Direction{ 0.0f, -1.0f, 0.0f }, FalloffEnd(10.0f), Position{ 0.0f, 0.0f, 0.0f }, SpotPower(64.0f) {}
 };
 
-struct MaterialData {  // FrameResource.h:17-27
-    DirectX::XMFLOAT4 DiffuseAlbedo = { 1.0f, 1.0f, 1.0f, 1.0f };
-    DirectX::XMFLOAT3 FresnelR0 = { 0.01f, 0.01f, 0.01f };
-    float Roughness = 0.5f;
-    DirectX::XMFLOAT4X4 MatTransform = crychic_detail::Identity4x4();
-    UINT DiffuseMapIndex = 0;
-    UINT NormalMapIndex = 0;
-    float Metalness = 0.5f;
-    UINT MaterialPad0 = 0;
+struct InstanceData {                       // FrameResource.h:7-15, 144 B, one per instance in a structured buffer
+    DirectX::XMFLOAT4X4 World;              // +0    stored transposed by UpdateInstanceData (CRYCHIC.cpp:546)
+    DirectX::XMFLOAT4X4 TexTransform;       // +64
+    UINT MaterialIndex;                     // +128
+    UINT ObjPad0, ObjPad1, ObjPad2;         // +132
+    InstanceData() : World(crychic_detail::Identity4x4()), TexTransform(crychic_detail::Identity4x4()), MaterialIndex(0), ObjPad0(0), ObjPad1(0), ObjPad2(0) {}
 };
 
-struct PassConstants {  // FrameResource.h:29-51
-    DirectX::XMFLOAT4X4 View = crychic_detail::Identity4x4();
-    DirectX::XMFLOAT4X4 InvView = crychic_detail::Identity4x4();
-    DirectX::XMFLOAT4X4 Proj = crychic_detail::Identity4x4();
-    DirectX::XMFLOAT4X4 InvProj = crychic_detail::Identity4x4();
-    DirectX::XMFLOAT4X4 ViewProj = crychic_detail::Identity4x4();
-    DirectX::XMFLOAT4X4 InvViewProj = crychic_detail::Identity4x4();
-    DirectX::XMFLOAT4X4 ViewProjTex = crychic_detail::Identity4x4();
-    DirectX::XMFLOAT4X4 ShadowTransforms[12];
-    DirectX::XMFLOAT3 EyePosW = { 0.0f, 0.0f, 0.0f };
-    float cbPerObjectPad1 = 0.0f;
-    DirectX::XMFLOAT2 RenderTargetSize = { 0.0f, 0.0f };
-    DirectX::XMFLOAT2 InvRenderTargetSize = { 0.0f, 0.0f };
-    float NearZ = 0.0f;
-    float FarZ = 0.0f;
-    float TotalTime = 0.0f;
-    float DeltaTime = 0.0f;
-    DirectX::XMFLOAT4 AmbientLight = { 0.0f, 0.0f, 0.0f, 1.0f };
-    Light Lights[MaxLights];
+struct MaterialData {                       // FrameResource.h:17-27, 112 B
+    DirectX::XMFLOAT4 DiffuseAlbedo;        // +0
+    DirectX::XMFLOAT3 FresnelR0;            // +16
+    float Roughness;                        // +28
+    DirectX::XMFLOAT4X4 MatTransform;       // +32
+    UINT DiffuseMapIndex;                   // +96
+    UINT NormalMapIndex;                    // +100
+    float Metalness;                        // +104  never assigned by UpdateMaterialBuffer: stays 0.5 (quirk Q5)
+    UINT MaterialPad0;                      // +108
+    MaterialData() : DiffuseAlbedo{ 1.0f, 1.0f, 1.0f, 1.0f }, FresnelR0{ 0.01f, 0.01f, 0.01f }, Roughness(0.5f), MatTransform(crychic_detail::Identity4x4()),
+                     DiffuseMapIndex(0), NormalMapIndex(0), Metalness(0.5f), MaterialPad0(0) {}
 };
 
-struct SsaoConstants {  // FrameResource.h:53-67
-    DirectX::XMFLOAT4X4 Proj;
-    DirectX::XMFLOAT4X4 InvProj;
-    DirectX::XMFLOAT4X4 ProjTex;
-    DirectX::XMFLOAT4 OffsetVectors[14];
-    DirectX::XMFLOAT4 BlurWeights[3];
-    DirectX::XMFLOAT2 RenderTargetSize = { 0.0f, 0.0f };
-    DirectX::XMFLOAT2 InvRenderTargetSize = { 0.0f, 0.0f };
-    float OcclusionRadius = 0.5f;
-    float OcclusionFadeStart = 0.2f;
-    float OcclusionFadeEnd = 2.0f;
-    float SurfaceEpsilon = 0.05f;
+struct PassConstants {                      // cbPass, FrameResource.h:29-51, 2048 B (= crychic_pass_constants)
+    DirectX::XMFLOAT4X4 View;               // +0     every matrix: transpose of the row-vector matrix (CRYCHIC.cpp:843-849)
+    DirectX::XMFLOAT4X4 InvView;            // +64
+    DirectX::XMFLOAT4X4 Proj;               // +128
+    DirectX::XMFLOAT4X4 InvProj;            // +192
+    DirectX::XMFLOAT4X4 ViewProj;           // +256
+    DirectX::XMFLOAT4X4 InvViewProj;        // +320
+    DirectX::XMFLOAT4X4 ViewProjTex;        // +384   lighting pass: world -> ambient-map uv
+    DirectX::XMFLOAT4X4 ShadowTransforms[12];  // +448   [0..3] = the cascades; [4..11] never valid in the reference either
+    DirectX::XMFLOAT3 EyePosW;              // +1216
+    float cbPerObjectPad1;                  // +1228
+    DirectX::XMFLOAT2 RenderTargetSize;     // +1232
+    DirectX::XMFLOAT2 InvRenderTargetSize;  // +1240
+    float NearZ, FarZ;                      // +1248, +1252
+    float TotalTime, DeltaTime;             // +1256, +1260
+    DirectX::XMFLOAT4 AmbientLight;         // +1264
+    Light Lights[MaxLights];                // +1280  [0, NUM_DIR_LIGHTS) directional
+    PassConstants()
+        : View(crychic_detail::Identity4x4()), InvView(View), Proj(View), InvProj(View), ViewProj(View), InvViewProj(View), ViewProjTex(View),
+          ShadowTransforms{}, EyePosW{ 0.0f, 0.0f, 0.0f }, cbPerObjectPad1(0.0f), RenderTargetSize{ 0.0f, 0.0f }, InvRenderTargetSize{ 0.0f, 0.0f },
+          NearZ(0.0f), FarZ(0.0f), TotalTime(0.0f), DeltaTime(0.0f), AmbientLight{ 0.0f, 0.0f, 0.0f, 1.0f } {}
 };
 
-struct Vertex {  // FrameResource.h:69-75
-    DirectX::XMFLOAT3 Pos;
-    DirectX::XMFLOAT3 Normal;
-    DirectX::XMFLOAT2 TexC;
-    DirectX::XMFLOAT3 TangentU;
+struct SsaoConstants {                      // cbSsao, FrameResource.h:53-67, 496 B (= crychic_ssao_constants)
+    DirectX::XMFLOAT4X4 Proj;               // +0
+    DirectX::XMFLOAT4X4 InvProj;            // +64
+    DirectX::XMFLOAT4X4 ProjTex;            // +128   view -> depth-map uv
+    DirectX::XMFLOAT4 OffsetVectors[14];    // +192
+    DirectX::XMFLOAT4 BlurWeights[3];       // +416   11 weights, 12th float unused
+    DirectX::XMFLOAT2 RenderTargetSize;     // +464   left at (0, 0) by the reference
+    DirectX::XMFLOAT2 InvRenderTargetSize;  // +472   1 / half-res size
+    float OcclusionRadius;                  // +480
+    float OcclusionFadeStart;               // +484
+    float OcclusionFadeEnd;                 // +488
+    float SurfaceEpsilon;                   // +492
+    SsaoConstants() : Proj{}, InvProj{}, ProjTex{}, OffsetVectors{}, BlurWeights{}, RenderTargetSize{ 0.0f, 0.0f }, InvRenderTargetSize{ 0.0f, 0.0f },
+                      OcclusionRadius(0.5f), OcclusionFadeStart(0.2f), OcclusionFadeEnd(2.0f), SurfaceEpsilon(0.05f) {}
+};
+
+struct Vertex {                             // FrameResource.h:69-75, 44 B (= crychic_vertex)
+    DirectX::XMFLOAT3 Pos;                  // +0
+    DirectX::XMFLOAT3 Normal;               // +12
+    DirectX::XMFLOAT2 TexC;                 // +24
+    DirectX::XMFLOAT3 TangentU;             // +32
 };
 
 static_assert(sizeof(Light) == 48 && sizeof(Light) == sizeof(crychic_light), "Light ABI");
