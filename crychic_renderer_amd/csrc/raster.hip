@@ -28,7 +28,15 @@ __global__ __launch_bounds__(256) void clear_vis_kernel(uint64_t* __restrict__ v
     if (i == 0) { c->nlive = 0; c->overflow = 0; c->nlarge = 0; }
 }
 
-__global__ __launch_bounds__(128) void setup_kernel(crychic_draw_item item, const crychic_material_data* __restrict__ materials,
+// Up to kBatchItems render items of a pass share one setup launch (a pass of the reference scene has two: boxes + grid).
+constexpr uint32_t kBatchItems = 8;
+struct ItemBatch {
+    crychic_draw_item item[kBatchItems];
+    uint64_t first[kBatchItems + 1];      // prefix sums of instanceCount * triangles; first[n] = total of the batch
+    uint32_t n;
+};
+
+__global__ __launch_bounds__(128) void setup_kernel(ItemBatch batch, const crychic_material_data* __restrict__ materials,
                                                     uint32_t nMaterials, crychic_pass_constants_viewproj vp, uint32_t W, uint32_t H,
                                                     SetupTri* __restrict__ tris, uint32_t slotBase, uint32_t* __restrict__ live,
                                                     uint32_t liveCapacity, RasterCounters* __restrict__ counters)
@@ -40,13 +48,17 @@ __global__ __launch_bounds__(128) void setup_kernel(crychic_draw_item item, cons
         if ((b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1) > kLargeBox) live[liveCapacity - 1u - atomicAdd(&counters->nlarge, 1u)] = slot;
         else live[atomicAdd(&counters->nlive, 1u)] = slot;
     };
+    const uint64_t bid = (uint64_t)blockIdx.x * 128u + threadIdx.x;     // triangle of the batch; draw order = item, instance, triangle
+    if (bid >= batch.first[batch.n]) return;
+    uint32_t k = 0;
+    while (k + 1u < batch.n && bid >= batch.first[k + 1u]) ++k;
+    const crychic_draw_item& item = batch.item[k];
     const uint32_t ntri = item.indexCount / 3u;
-    const uint64_t gid = (uint64_t)blockIdx.x * 128u + threadIdx.x;
-    if (gid >= (uint64_t)ntri * item.instanceCount) return;
+    const uint64_t gid = bid - batch.first[k];
     const uint32_t inst = (uint32_t)(gid / ntri), tri = (uint32_t)(gid - (uint64_t)inst * ntri);
     const crychic_instance_data I = item.instances_dev[inst];
     const crychic_material_data* M = (materials && I.MaterialIndex < nMaterials) ? &materials[I.MaterialIndex] : nullptr;
-    const uint32_t slot0 = slotBase + (uint32_t)gid * 3u;
+    const uint32_t slot0 = slotBase + (uint32_t)bid * 3u;
     tris[slot0].A2 = 0; tris[slot0 + 1].A2 = 0; tris[slot0 + 2].A2 = 0;
 
     VsOut v[3];
@@ -186,10 +198,20 @@ hipError_t launch_raster_pass(const RasterPass& p, hipStream_t stream)
     crychic_pass_constants_viewproj vp, view;
     for (int i = 0; i < 16; ++i) { vp.m[i] = p.viewProj[i]; view.m[i] = p.view[i]; }
     uint32_t slotBase = 0;
-    for (uint32_t i = 0; i < p.nItems; ++i) {
-        const uint64_t n = (uint64_t)(p.items[i].indexCount / 3u) * p.items[i].instanceCount;
-        if (n == 0) continue;
-        hipLaunchKernelGGL(setup_kernel, dim3((uint32_t)((n + 127u) / 128u)), dim3(128), 0, stream, p.items[i], p.materials, p.nMaterials,
+    for (uint32_t i0 = 0; i0 < p.nItems;) {
+        ItemBatch b;
+        b.n = 0;
+        b.first[0] = 0;
+        for (; i0 < p.nItems && b.n < kBatchItems; ++i0) {
+            const uint64_t n = (uint64_t)(p.items[i0].indexCount / 3u) * p.items[i0].instanceCount;
+            if (n == 0) continue;
+            b.item[b.n] = p.items[i0];
+            b.first[b.n + 1u] = b.first[b.n] + n;
+            ++b.n;
+        }
+        if (b.n == 0) continue;
+        const uint64_t n = b.first[b.n];
+        hipLaunchKernelGGL(setup_kernel, dim3((uint32_t)((n + 127u) / 128u)), dim3(128), 0, stream, b, p.materials, p.nMaterials,
                            vp, p.W, p.H, tris, slotBase, live, (uint32_t)slots, counters);
         slotBase += (uint32_t)(n * 3u);
     }
