@@ -150,9 +150,10 @@ def time_producers(ctx, planes, args, torch):
         cb.ViewProj[:] = list((consts.light_view[k].astype(np.float32) @ consts.light_proj[k].astype(np.float32)).T.reshape(-1))
         cbs.append(cb)
 
+    shadow_planes = [shadow[k] for k in range(4)]
+
     def run():
-        for k in range(4):
-            sgeo.DrawSceneToShadowMap(cbs[k], shadow[k])
+        sgeo.DrawSceneToShadowMaps(cbs, shadow_planes)
         geo.DrawNormalsDepthAndGBuffer(consts.pass_cb, normal, gb, depth)
 
     run()
@@ -162,8 +163,7 @@ def time_producers(ctx, planes, args, torch):
     t_sh = t_cam = 0.0
     for _ in range(n):
         e0.record()
-        for k in range(4):
-            sgeo.DrawSceneToShadowMap(cbs[k], shadow[k])
+        sgeo.DrawSceneToShadowMaps(cbs, shadow_planes)
         e1.record()
         geo.DrawNormalsDepthAndGBuffer(consts.pass_cb, normal, gb, depth)
         e2.record()

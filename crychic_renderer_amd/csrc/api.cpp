@@ -347,7 +347,7 @@ static int raster_common(crychic_ctx* ctx, cry::RasterPass& p, const crychic_pas
                          uint32_t nItems, void* stream)
 {
     if (int rc = bind(ctx)) return rc;
-    if (!passCB || (!items && nItems) || !p.depth || !p.workspace) return fail(CRYCHIC_E_INVALID_ARG, "null argument");
+    if (!passCB || (!items && nItems) || (!p.depth && p.nTargets < 2u) || !p.workspace) return fail(CRYCHIC_E_INVALID_ARG, "null argument");
     if (p.W == 0 || p.H == 0 || (uint64_t)p.W * p.H > 0x7FFFFFFFull) return fail(CRYCHIC_E_INVALID_ARG, "bad target size %ux%u", p.W, p.H);
     for (uint32_t i = 0; i < nItems; ++i) {
         const crychic_draw_item& d = items[i];
@@ -373,6 +373,26 @@ int crychic_draw_scene_to_shadow_map(crychic_ctx* ctx, const crychic_pass_consta
     p.mode = 0; p.W = shadowDim; p.H = shadowDim; p.depthBias = depthBias; p.slopeScaledDepthBias = slopeScaledDepthBias;
     p.depth = shadow_dev; p.workspace = workspace_dev; p.workspaceBytes = workspaceBytes;
     return raster_common(ctx, p, passCB, items, nItems, stream);
+}
+
+int crychic_draw_scene_to_shadow_maps(crychic_ctx* ctx, const crychic_pass_constants* passCBs, uint32_t nCascades, const crychic_draw_item* items,
+                                      uint32_t nItems, uint32_t* const* shadow_dev, uint32_t shadowDim, int depthBias, float slopeScaledDepthBias,
+                                      void* workspace_dev, size_t workspaceBytes, void* stream)
+{
+    if (!passCBs || !shadow_dev || nCascades < 1u || nCascades > 4u) return fail(CRYCHIC_E_INVALID_ARG, "1..4 cascades with their pass constants and targets");
+    if (nCascades == 1u)
+        return crychic_draw_scene_to_shadow_map(ctx, passCBs, items, nItems, shadow_dev[0], shadowDim, depthBias, slopeScaledDepthBias, workspace_dev,
+                                                workspaceBytes, stream);
+    cry::RasterPass p = {};
+    p.mode = 0; p.W = shadowDim; p.H = shadowDim; p.depthBias = depthBias; p.slopeScaledDepthBias = slopeScaledDepthBias;
+    p.workspace = workspace_dev; p.workspaceBytes = workspaceBytes;
+    p.nTargets = nCascades;
+    for (uint32_t c = 0; c < nCascades; ++c) {
+        if (!shadow_dev[c]) return fail(CRYCHIC_E_INVALID_ARG, "shadow target %u is null", c);
+        p.viewProjN[c] = passCBs[c].ViewProj;
+        p.depthN[c] = shadow_dev[c];
+    }
+    return raster_common(ctx, p, passCBs, items, nItems, stream);
 }
 
 int crychic_draw_normals_and_depth(crychic_ctx* ctx, const crychic_pass_constants* passCB, const crychic_draw_item* items,

@@ -41,6 +41,8 @@ struct RasterPass {
     int depthBias; float slopeScaledDepthBias;
     uint32_t* depth; void* normal; float* g0; float* g1; float* g2;
     void* workspace; size_t workspaceBytes;
+    // fused shadow pass (mode 0, nTargets 2..4): one ViewProj and one depth target per cascade, same items
+    uint32_t nTargets; const float* viewProjN[4]; uint32_t* depthN[4];
 };
 size_t raster_workspace_bytes(uint64_t triangles, uint32_t W, uint32_t H);
 hipError_t launch_raster_pass(const RasterPass& p, hipStream_t stream);

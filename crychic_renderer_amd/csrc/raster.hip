@@ -28,6 +28,9 @@ __global__ __launch_bounds__(256) void clear_vis_kernel(uint64_t* __restrict__ v
     if (i == 0) { c->nlive = 0; c->overflow = 0; c->nlarge = 0; }
 }
 
+struct ViewProjSet { crychic_pass_constants_viewproj m[4]; };     // one per target of a fused shadow pass
+struct DepthTargets { uint32_t* p[4]; };
+
 // Up to kBatchItems render items of a pass share one setup launch (a pass of the reference scene has two: boxes + grid).
 constexpr uint32_t kBatchItems = 8;
 struct ItemBatch {
@@ -37,10 +40,12 @@ struct ItemBatch {
 };
 
 __global__ __launch_bounds__(128) void setup_kernel(ItemBatch batch, const crychic_material_data* __restrict__ materials,
-                                                    uint32_t nMaterials, crychic_pass_constants_viewproj vp, uint32_t W, uint32_t H,
-                                                    SetupTri* __restrict__ tris, uint32_t slotBase, uint32_t* __restrict__ live,
-                                                    uint32_t liveCapacity, RasterCounters* __restrict__ counters)
+                                                    uint32_t nMaterials, ViewProjSet vps, uint32_t W, uint32_t H,
+                                                    SetupTri* __restrict__ tris, uint32_t slotBase, uint32_t slotsPerTarget,
+                                                    uint32_t* __restrict__ live, uint32_t liveCapacity, RasterCounters* __restrict__ counters)
 {
+    const uint32_t target = blockIdx.y;                                // shadow cascades of one fused pass; 0 otherwise
+    const crychic_pass_constants_viewproj& vp = vps.m[target];
     // small triangles are listed from the front of `live`, large ones (pixel box > kLargeBox) from its back
     auto append = [&](const SetupTri& s, uint32_t slot) {
         const PixelBox b = triangle_box(s, W, H);
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(128) void setup_kernel(ItemBatch batch, const crych
     const uint32_t inst = (uint32_t)(gid / ntri), tri = (uint32_t)(gid - (uint64_t)inst * ntri);
     const crychic_instance_data I = item.instances_dev[inst];
     const crychic_material_data* M = (materials && I.MaterialIndex < nMaterials) ? &materials[I.MaterialIndex] : nullptr;
-    const uint32_t slot0 = slotBase + (uint32_t)bid * 3u;
+    const uint32_t slot0 = target * slotsPerTarget + slotBase + (uint32_t)bid * 3u;
     tris[slot0].A2 = 0; tris[slot0 + 1].A2 = 0; tris[slot0 + 2].A2 = 0;
 
     VsOut v[3];
@@ -77,6 +82,7 @@ __global__ __launch_bounds__(128) void setup_kernel(ItemBatch batch, const crych
     if (inside) {
         SetupTri s;
         if (setup_triangle(v[0], v[1], v[2], I.MaterialIndex, W, H, s, &overflow)) {
+            s.pad = target;
             tris[slot0] = s;
             append(s, slot0);
         }
@@ -88,6 +94,7 @@ __global__ __launch_bounds__(128) void setup_kernel(ItemBatch batch, const crych
         for (int c = 1; c + 1 < n; ++c) {
             SetupTri s;
             if (setup_triangle(poly[0], poly[c], poly[c + 1], I.MaterialIndex, W, H, s, &overflow)) {
+                s.pad = target;
                 tris[slot0 + (uint32_t)(c - 1)] = s;
                 append(s, slot0 + (uint32_t)(c - 1));
             }
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(256) void clear_depth_kernel(uint32_t* __restrict__
 template <bool SHADOW, int FWL2>
 __global__ __launch_bounds__(256) void raster_kernel(const SetupTri* __restrict__ tris, const uint32_t* __restrict__ live, uint32_t liveCapacity,
                                                      const RasterCounters* __restrict__ counters, unsigned long long* __restrict__ vis,
-                                                     uint32_t* __restrict__ depth, uint32_t W, uint32_t H, int depthBias, float slopeBias)
+                                                     DepthTargets depthTargets, uint32_t W, uint32_t H, int depthBias, float slopeBias)
 {
     const uint32_t nsmall = counters->nlive, nlarge = counters->nlarge;   // written by the setup kernels that precede this launch
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
@@ -120,6 +127,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const SetupTri* __restrict_
     const int lx = lane & (FW - 1), ly = lane >> FWL2;
     auto sweep = [&](uint32_t slot, int yfirst, int ystep) {
         const SetupTri t = tris[slot];
+        uint32_t* __restrict__ depth = depthTargets.p[SHADOW ? (t.pad & 3u) : 0u];
         const PixelBox b = triangle_box(t, W, H);
         const EdgeFlags e = triangle_edge_flags(t);
         const double bias = SHADOW ? triangle_depth_bias(t, depthBias, slopeBias) : 0.0;
@@ -176,9 +184,12 @@ hipError_t launch_raster_pass(const RasterPass& p, hipStream_t stream)
     // carve the workspace: vis | tris | live | textures | counters (all 16-byte aligned)
     uint64_t total = 0;
     for (uint32_t i = 0; i < p.nItems; ++i) total += (uint64_t)(p.items[i].indexCount / 3u) * p.items[i].instanceCount;
-    const uint64_t slots = total * 3u;
+    const bool shadow = p.mode == 0;
+    const uint32_t nT = (shadow && p.nTargets > 1u) ? p.nTargets : 1u;     // cascades rasterised by one fused shadow pass
+    if (nT > 4u) return hipErrorInvalidValue;
+    const uint64_t slotsPerTarget = total * 3u, slots = slotsPerTarget * nT;
     if (slots >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
-    if (raster_workspace_bytes(total, p.W, p.H) > p.workspaceBytes || p.nTextures > 64u) return hipErrorInvalidValue;
+    if (raster_workspace_bytes(total * nT, p.W, p.H) > p.workspaceBytes || p.nTextures > 64u) return hipErrorInvalidValue;
     char* base = (char*)p.workspace;
     unsigned long long* vis = (unsigned long long*)base;
     size_t off = (size_t)p.W * p.H * 8u;
@@ -188,15 +199,22 @@ hipError_t launch_raster_pass(const RasterPass& p, hipStream_t stream)
     RasterCounters* counters = (RasterCounters*)(base + off);
 
     const uint32_t npx = p.W * p.H;
-    const bool shadow = p.mode == 0;
-    if (shadow) hipLaunchKernelGGL(clear_depth_kernel, dim3((npx + 255u) / 256u), dim3(256), 0, stream, p.depth, npx, counters);
+    ViewProjSet vps;
+    DepthTargets targets;
+    for (uint32_t t = 0; t < 4u; ++t) {
+        const float* m = (nT > 1u) ? p.viewProjN[t < nT ? t : 0u] : p.viewProj;
+        for (int i = 0; i < 16; ++i) vps.m[t].m[i] = m[i];
+        targets.p[t] = (nT > 1u) ? p.depthN[t < nT ? t : 0u] : p.depth;
+    }
+    if (shadow) for (uint32_t t = 0; t < nT; ++t)
+        hipLaunchKernelGGL(clear_depth_kernel, dim3((npx + 255u) / 256u), dim3(256), 0, stream, targets.p[t], npx, counters);
     else hipLaunchKernelGGL(clear_vis_kernel, dim3((npx + 255u) / 256u), dim3(256), 0, stream, (uint64_t*)vis, npx, counters);
     if (p.nTextures) {
         hipError_t e = hipMemcpyAsync(texDev, p.textures, p.nTextures * sizeof(Texture), hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) return e;
     }
-    crychic_pass_constants_viewproj vp, view;
-    for (int i = 0; i < 16; ++i) { vp.m[i] = p.viewProj[i]; view.m[i] = p.view[i]; }
+    crychic_pass_constants_viewproj view;
+    for (int i = 0; i < 16; ++i) view.m[i] = p.view[i];
     uint32_t slotBase = 0;
     for (uint32_t i0 = 0; i0 < p.nItems;) {
         ItemBatch b;
@@ -211,12 +229,12 @@ hipError_t launch_raster_pass(const RasterPass& p, hipStream_t stream)
         }
         if (b.n == 0) continue;
         const uint64_t n = b.first[b.n];
-        hipLaunchKernelGGL(setup_kernel, dim3((uint32_t)((n + 127u) / 128u)), dim3(128), 0, stream, b, p.materials, p.nMaterials,
-                           vp, p.W, p.H, tris, slotBase, live, (uint32_t)slots, counters);
+        hipLaunchKernelGGL(setup_kernel, dim3((uint32_t)((n + 127u) / 128u), nT), dim3(128), 0, stream, b, p.materials, p.nMaterials,
+                           vps, p.W, p.H, tris, slotBase, (uint32_t)slotsPerTarget, live, (uint32_t)slots, counters);
         slotBase += (uint32_t)(n * 3u);
     }
     if (slots) {
-#define CRY_RASTER(S, F) hipLaunchKernelGGL((raster_kernel<S, F>), dim3(256u * 8u), dim3(256), 0, stream, tris, live, (uint32_t)slots, counters, vis, p.depth, p.W, p.H, p.depthBias, p.slopeScaledDepthBias)
+#define CRY_RASTER(S, F) hipLaunchKernelGGL((raster_kernel<S, F>), dim3(256u * 8u), dim3(256), 0, stream, tris, live, (uint32_t)slots, counters, vis, targets, p.W, p.H, p.depthBias, p.slopeScaledDepthBias)
         if (shadow) CRY_RASTER(true, 4); else CRY_RASTER(false, 4);     // 16 x 4 footprint: measured best of 8x8 / 16x4 / 64x1
 #undef CRY_RASTER
     }

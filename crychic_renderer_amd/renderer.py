@@ -274,10 +274,10 @@ class SceneGeometry:
             self.n_textures = len(textures)
         self._ws = {}
 
-    def workspace(self, W, H):
-        key = (W, H)
+    def workspace(self, W, H, targets=1):
+        key = (W, H, targets)
         if key not in self._ws:
-            n = int(lib.crychic_raster_workspace_bytes(self.triangles, W, H))
+            n = int(lib.crychic_raster_workspace_bytes(self.triangles * targets, W, H))
             self._ws[key] = torch.zeros((n,), dtype=torch.uint8, device=self.ctx.device)
         return self._ws[key]
 
@@ -286,6 +286,16 @@ class SceneGeometry:
         ws = self.workspace(dim, dim)
         check(lib.crychic_draw_scene_to_shadow_map(self.ctx.handle, C.byref(pass_cb), self.items, len(self.items), _ptr(shadow_plane), dim,
                                                    int(depth_bias), float(slope_bias), _ptr(ws), ws.numel(), _stream(self.ctx.device)))
+
+    def DrawSceneToShadowMaps(self, pass_cbs, shadow_planes, depth_bias=10000, slope_bias=2.0):
+        """All cascades in one rasteriser pass (crychic_draw_scene_to_shadow_maps); bit-identical to one call per cascade."""
+        n = len(pass_cbs)
+        dim = int(shadow_planes[0].shape[0])
+        ws = self.workspace(dim, dim, n)
+        cbs = (type(pass_cbs[0]) * n)(*pass_cbs)
+        ptrs = (C.c_void_p * n)(*[p.data_ptr() for p in shadow_planes])
+        check(lib.crychic_draw_scene_to_shadow_maps(self.ctx.handle, C.cast(cbs, C.c_void_p), n, self.items, len(self.items), C.cast(ptrs, C.c_void_p), dim,
+                                                    int(depth_bias), float(slope_bias), _ptr(ws), ws.numel(), _stream(self.ctx.device)))
 
     def DrawNormalsAndDepth(self, pass_cb, normal_map, depth):  # CRYCHIC.cpp:2512-2543
         H, W = int(depth.shape[0]), int(depth.shape[1])

@@ -447,13 +447,16 @@ private:
     {
         auto items = DrawItems(mRitemLayer[(int)RenderLayer::OpaqueShadow]);
         size_t bytes;
-        void* ws = RasterWorkspace(mSceneTriangles, mShadowMap->Width(), mShadowMap->Height(), &bytes);
+        void* ws = RasterWorkspace(4 * mSceneTriangles, mShadowMap->Width(), mShadowMap->Height(), &bytes);
+        // the four cascades' pass constants sit in consecutive 256-byte-aligned slots of the upload buffer; gather them
+        crychic_pass_constants cbs[4];
+        uint32_t* targets[4];
         for (int i = 0; i < 4; ++i) {
-            const PassConstants& cb = mCurrFrameResource->PassCB->Element(1 + i);
-            CrychicThrowIfFailed(crychic_draw_scene_to_shadow_map(md3dDevice->Ctx(), reinterpret_cast<const crychic_pass_constants*>(&cb), items.data(),
-                                                                  (uint32_t)items.size(), static_cast<uint32_t*>(mShadowMap->Resource(i)->Data()),
-                                                                  mShadowMap->Width(), 10000, 2.0f, ws, bytes, mCommandList->Stream()));  // bias: :1601-1603
+            std::memcpy(&cbs[i], &mCurrFrameResource->PassCB->Element(1 + i), sizeof cbs[i]);
+            targets[i] = static_cast<uint32_t*>(mShadowMap->Resource(i)->Data());
         }
+        CrychicThrowIfFailed(crychic_draw_scene_to_shadow_maps(md3dDevice->Ctx(), cbs, 4, items.data(), (uint32_t)items.size(), targets,
+                                                               mShadowMap->Width(), 10000, 2.0f, ws, bytes, mCommandList->Stream()));  // bias: :1601-1603
     }
     void DrawNormalsAndDepth()  // CRYCHIC.cpp:2512-2543
     {

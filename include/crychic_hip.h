@@ -317,6 +317,13 @@ int crychic_draw_gbuffer(crychic_ctx* ctx, const crychic_pass_constants* passCB,
                          const crychic_texture* textures, uint32_t nTextures, float* g0_dev, float* g1_dev, float* g2_dev,
                          uint32_t* depth_dev, uint32_t W, uint32_t H, void* workspace_dev, size_t workspaceBytes, void* stream);
 
+/* All cascades of CRYCHIC::DrawSceneToShadowMap (CRYCHIC.cpp:2477-2510 loops over four) in one pass: passCBs[c].ViewProj and
+ * shadow_dev[c] per cascade, the same items for all.  Bit-identical to nCascades calls of crychic_draw_scene_to_shadow_map;
+ * the workspace must hold crychic_raster_workspace_bytes(nCascades * triangles, shadowDim, shadowDim). */
+int crychic_draw_scene_to_shadow_maps(crychic_ctx* ctx, const crychic_pass_constants* passCBs, uint32_t nCascades,
+                                      const crychic_draw_item* items, uint32_t nItems, uint32_t* const* shadow_dev, uint32_t shadowDim,
+                                      int depthBias, float slopeScaledDepthBias, void* workspace_dev, size_t workspaceBytes, void* stream);
+
 /* DrawNormalsAndDepth + DrawGBuffer in one rasterisation: the two passes draw the same items with the same ViewProj into
  * depth targets cleared to 1.0, so their visibility is identical; this entry rasterises once and runs both pixel shaders
  * on the winning primitive.  Every plane is bit-identical to calling the two passes one after the other. */

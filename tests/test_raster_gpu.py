@@ -32,9 +32,17 @@ def device_frame(ctx, built_lib, consts, items, shadow_items, materials, texture
     app = Crychic(ctx, W, H, torch.from_numpy(consts.randvec.copy()).to(dev), torch.from_numpy(cube).to(dev), shadow_dim=SD)
     app.mMainPassCB, app.mSsaoCB = consts.pass_cb, consts.ssao_cb
     shadow_cb = built_lib.PassConstants()
+    cbs = []
     for k in range(4):                                     # DrawSceneToShadowMap: one pass constant slot per cascade
         shadow_cb.ViewProj[:] = list(raster_util.light_viewproj_t(consts, k))
         sgeo.DrawSceneToShadowMap(shadow_cb, app.mShadowMap.mShadowMap[k])
+        cb = built_lib.PassConstants(); cb.ViewProj[:] = list(shadow_cb.ViewProj); cbs.append(cb)
+    # the fused four-cascade pass must reproduce the four separate passes bit for bit
+    fused = [torch.zeros_like(app.mShadowMap.mShadowMap[k]) for k in range(4)]
+    sgeo.DrawSceneToShadowMaps(cbs, fused)
+    torch.cuda.synchronize()
+    for k in range(4):
+        assert torch.equal(fused[k], app.mShadowMap.mShadowMap[k]), "cascade %d" % k
     geo.DrawNormalsAndDepth(app.mMainPassCB, app.mSsao.mNormalMap, app.mDepthStencilBuffer)
     geo.DrawGBuffer(app.mMainPassCB, app.mDeferred.mGBuffer, app.mDepthStencilBuffer)
     # the fused pass (one rasterisation, both pixel shaders) must reproduce the two passes bit for bit
