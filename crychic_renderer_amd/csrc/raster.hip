@@ -21,10 +21,14 @@ namespace cry {
 constexpr int kLargeBox = 2048;   // pixel-box area above which a triangle gets a whole workgroup
 struct RasterCounters { uint32_t nlive; uint32_t overflow; uint32_t nlarge; uint32_t pad; };
 
+// Clears: 16-byte stores (two visibility keys / four depth texels per lane); the planes come from hipMalloc / torch and are
+// 16-byte aligned, odd tails are finished with scalar stores by the last lanes.
 __global__ __launch_bounds__(256) void clear_vis_kernel(uint64_t* __restrict__ vis, uint32_t n, RasterCounters* c)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n) vis[i] = kVisClear;
+    const uint32_t pairs = n / 2u;
+    if (i < pairs) reinterpret_cast<ulonglong2*>(vis)[i] = ulonglong2{ kVisClear, kVisClear };
+    if (i == pairs && (n & 1u)) vis[n - 1u] = kVisClear;
     if (i == 0) { c->nlive = 0; c->overflow = 0; c->nlarge = 0; }
 }
 
@@ -106,7 +110,15 @@ __global__ __launch_bounds__(128) void setup_kernel(ItemBatch batch, const crych
 __global__ __launch_bounds__(256) void clear_depth_kernel(uint32_t* __restrict__ depth, uint32_t n, RasterCounters* c)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n) depth[i] = 0x00FFFFFFu;
+    const uint32_t head = (uint32_t)((16u - ((uintptr_t)depth & 15u)) & 15u) / 4u;   // texels before the first 16-byte boundary
+    if (head) {                                                                        // caller's plane is only 4-byte aligned
+        if (i < head && i < n) depth[i] = 0x00FFFFFFu;
+        depth += head < n ? head : n;
+        n -= head < n ? head : n;
+    }
+    const uint32_t quads = n / 4u;
+    if (i < quads) reinterpret_cast<uint4*>(depth)[i] = uint4{ 0x00FFFFFFu, 0x00FFFFFFu, 0x00FFFFFFu, 0x00FFFFFFu };
+    if (i == quads) for (uint32_t k = quads * 4u; k < n; ++k) depth[k] = 0x00FFFFFFu;
     if (i == 0) { c->nlive = 0; c->overflow = 0; c->nlarge = 0; }
 }
 
@@ -207,8 +219,8 @@ hipError_t launch_raster_pass(const RasterPass& p, hipStream_t stream)
         targets.p[t] = (nT > 1u) ? p.depthN[t < nT ? t : 0u] : p.depth;
     }
     if (shadow) for (uint32_t t = 0; t < nT; ++t)
-        hipLaunchKernelGGL(clear_depth_kernel, dim3((npx + 255u) / 256u), dim3(256), 0, stream, targets.p[t], npx, counters);
-    else hipLaunchKernelGGL(clear_vis_kernel, dim3((npx + 255u) / 256u), dim3(256), 0, stream, (uint64_t*)vis, npx, counters);
+        hipLaunchKernelGGL(clear_depth_kernel, dim3((npx / 4u + 256u) / 256u), dim3(256), 0, stream, targets.p[t], npx, counters);
+    else hipLaunchKernelGGL(clear_vis_kernel, dim3((npx / 2u + 256u) / 256u), dim3(256), 0, stream, (uint64_t*)vis, npx, counters);
     if (p.nTextures) {
         hipError_t e = hipMemcpyAsync(texDev, p.textures, p.nTextures * sizeof(Texture), hipMemcpyHostToDevice, stream);
         if (e != hipSuccess) return e;
