@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void blur_kernel(crychic_ssao_constants cb, Ed
 template <bool HORZ>
 __global__ __launch_bounds__(256) void blur_replay_kernel(crychic_ssao_constants cb, EdgePlane edge,
                                                           const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
-                                                          uint32_t W, uint32_t H, uint32_t row0, uint32_t row1)
+                                                          uint32_t W, uint32_t H, uint32_t row0, uint32_t row1, int onesShortcut)
 {
     constexpr int BW = 64, BH = 16, R = 5;
     constexpr int SW = HORZ ? BW + 2 * R : BW;
@@ -157,11 +157,30 @@ __global__ __launch_bounds__(256) void blur_replay_kernel(crychic_ssao_constants
     tile_origin<4>(bx, by);
     const int x0 = (int)bx * BW, y0 = (int)row0 + (int)by * BH;
     const int sx0 = HORZ ? x0 - R : x0, sy0 = HORZ ? y0 : y0 - R;
-    // this thread's four outputs: fetch their recorded decisions first so the loads fly during the staging
     const int tx = (int)(threadIdx.x & 63u), tyb = (int)(threadIdx.x >> 6);
     const int x = x0 + tx;
     const uint16_t* __restrict__ mask_in = HORZ ? edge.mask_h : edge.mask_v;
     const float* __restrict__ total_in = HORZ ? edge.total_h : edge.total_v;
+    bool allOne = onesShortcut != 0;
+    for (int k = (int)threadIdx.x; k < SW * SH; k += 256) {
+        const int ly = k / SW, lx = k - ly * SW;
+        const int cx = clampi(sx0 + lx, 0, w2 - 1), cy = clampi(sy0 + ly, 0, h2 - 1);   // ambient: point / CLAMP
+        const uint32_t raw = in[(uint32_t)cy * (uint32_t)w2 + (uint32_t)cx];
+        allOne = allOne && raw == 0xFFFFu;
+        s_a[k] = unorm16_to_float(raw);
+    }
+    // A window whose ambient values are all 1.0 blurs to exactly 1.0 whatever the recorded decisions are: the colour sum adds
+    // the very weights the recorded total was built from, in the same order, so colour == total bit for bit and x / x = 1
+    // for the finite positive totals that finite positive weights give (blur_weights_positive(), checked by the launcher).
+    // Most of the frame (sky, unoccluded surfaces) is like that; the whole tile then skips masks, taps and divisions.
+    if (__syncthreads_and(allOne)) {
+#pragma unroll
+        for (int j = 0; j < BH / 4; ++j) {
+            const int y = y0 + tyb + 4 * j;
+            if (x < w2 && y < (int)row1) out[(uint32_t)y * (uint32_t)w2 + (uint32_t)x] = (uint16_t)0xFFFFu;
+        }
+        return;
+    }
     uint32_t m[BH / 4];
     float tot[BH / 4];
 #pragma unroll
@@ -172,12 +191,6 @@ __global__ __launch_bounds__(256) void blur_replay_kernel(crychic_ssao_constants
         m[j] = mask_in[p];
         tot[j] = total_in[p];
     }
-    for (int k = (int)threadIdx.x; k < SW * SH; k += 256) {
-        const int ly = k / SW, lx = k - ly * SW;
-        const int cx = clampi(sx0 + lx, 0, w2 - 1), cy = clampi(sy0 + ly, 0, h2 - 1);   // ambient: point / CLAMP
-        s_a[k] = unorm16_to_float(in[(uint32_t)cy * (uint32_t)w2 + (uint32_t)cx]);
-    }
-    __syncthreads();
 
 #pragma unroll
     for (int j = 0; j < BH / 4; ++j) {
@@ -198,7 +211,7 @@ __global__ __launch_bounds__(256) void blur_replay_kernel(crychic_ssao_constants
 // blur_replay_kernel<true> followed by blur_replay_kernel<false>; `out` must not alias `in`.
 __global__ __launch_bounds__(256) void blur_replay_pair_kernel(crychic_ssao_constants cb, EdgePlane edge,
                                                                const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
-                                                               uint32_t W, uint32_t H, uint32_t row0, uint32_t row1)
+                                                               uint32_t W, uint32_t H, uint32_t row0, uint32_t row1, int onesShortcut)
 {
     constexpr int BW = 64, BH = 16, R = 5;
     constexpr int SW = BW + 2 * R, SH = BH + 2 * R;
@@ -211,7 +224,23 @@ __global__ __launch_bounds__(256) void blur_replay_pair_kernel(crychic_ssao_cons
     const int x0 = (int)bx * BW, y0 = (int)row0 + (int)by * BH;
     const int tx = (int)(threadIdx.x & 63u), tyb = (int)(threadIdx.x >> 6);
     const int x = x0 + tx;
-    // the vertical sweep's recorded decisions of this thread's four outputs: fetched first, they fly during the staging
+    bool allOne = onesShortcut != 0;
+    for (int k = (int)threadIdx.x; k < SW * SH; k += 256) {
+        const int ly = k / SW, lx = k - ly * SW;
+        const int cx = clampi(x0 - R + lx, 0, w2 - 1), cy = clampi(y0 - R + ly, 0, h2 - 1);   // ambient: point / CLAMP
+        const uint32_t raw = in[(uint32_t)cy * (uint32_t)w2 + (uint32_t)cx];
+        allOne = allOne && raw == 0xFFFFu;
+        s_in[k] = unorm16_to_float(raw);
+    }
+    if (__syncthreads_and(allOne)) {        // all-ones window: both sweeps return exactly 1.0 (see blur_replay_kernel)
+#pragma unroll
+        for (int j = 0; j < BH / 4; ++j) {
+            const int y = y0 + tyb + 4 * j;
+            if (x < w2 && y < (int)row1) out[(uint32_t)y * (uint32_t)w2 + (uint32_t)x] = (uint16_t)0xFFFFu;
+        }
+        return;
+    }
+    // the vertical sweep's recorded decisions of this thread's four outputs
     uint32_t m[BH / 4];
     float tot[BH / 4];
 #pragma unroll
@@ -222,12 +251,6 @@ __global__ __launch_bounds__(256) void blur_replay_pair_kernel(crychic_ssao_cons
         m[j] = edge.mask_v[p];
         tot[j] = edge.total_v[p];
     }
-    for (int k = (int)threadIdx.x; k < SW * SH; k += 256) {
-        const int ly = k / SW, lx = k - ly * SW;
-        const int cx = clampi(x0 - R + lx, 0, w2 - 1), cy = clampi(y0 - R + ly, 0, h2 - 1);   // ambient: point / CLAMP
-        s_in[k] = unorm16_to_float(in[(uint32_t)cy * (uint32_t)w2 + (uint32_t)cx]);
-    }
-    __syncthreads();
     // horizontal sweep of rows y0-5 .. y0+BH+4 (CLAMPed: a vertical tap above / below the map reads the edge row's result)
     for (int k = (int)threadIdx.x; k < BW * SH; k += 256) {
         const int ly = k >> 6, lx = k & 63;
@@ -370,6 +393,15 @@ __global__ __launch_bounds__(256) void light_points_kernel(LightParams P, const 
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------
+// All 11 blur weights finite and in (0, 1e30): every total the record sweep can produce is then finite and positive.
+static bool blur_weights_positive(const crychic_ssao_constants& cb)
+{
+    const float* w = &cb.BlurWeights[0][0];
+    for (int i = 0; i < 11; ++i)
+        if (!(w[i] > 0.0f && w[i] < 1.0e30f)) return false;
+    return true;
+}
+
 static inline dim3 grid_for(uint32_t width, uint32_t rows, uint32_t rows_per_block = 4u)
 {
     return dim3((width + 63u) / 64u, (rows + rows_per_block - 1u) / rows_per_block, 1);
@@ -410,7 +442,9 @@ hipError_t launch_blur(const crychic_ssao_constants& cb, const void* edge_base, 
     const dim3 grid = grid_for(W / 2, rows, 16u);
 #define CRY_LAUNCH_BLUR(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, cb, e, in, out, W, H, row0, row0 + rows)
     if (mode == BlurMode::Replay) {
-        if (horizontal) CRY_LAUNCH_BLUR(blur_replay_kernel<true>); else CRY_LAUNCH_BLUR(blur_replay_kernel<false>);
+        const int ones = blur_weights_positive(cb) ? 1 : 0;
+        if (horizontal) hipLaunchKernelGGL(blur_replay_kernel<true>, grid, dim3(256), 0, stream, cb, e, in, out, W, H, row0, row0 + rows, ones);
+        else hipLaunchKernelGGL(blur_replay_kernel<false>, grid, dim3(256), 0, stream, cb, e, in, out, W, H, row0, row0 + rows, ones);
     } else if (mode == BlurMode::Record) {
         if (horizontal) CRY_LAUNCH_BLUR((blur_kernel<true, true>)); else CRY_LAUNCH_BLUR((blur_kernel<false, true>));
     } else {
@@ -425,7 +459,8 @@ hipError_t launch_blur_replay_pair(const crychic_ssao_constants& cb, const void*
 {
     if (rows == 0) return hipSuccess;
     const EdgePlane e = edge_plane_carve(const_cast<void*>(edge_base), W, H);
-    hipLaunchKernelGGL(blur_replay_pair_kernel, grid_for(W / 2, rows, 16u), dim3(256), 0, stream, cb, e, in, out, W, H, row0, row0 + rows);
+    hipLaunchKernelGGL(blur_replay_pair_kernel, grid_for(W / 2, rows, 16u), dim3(256), 0, stream, cb, e, in, out, W, H, row0, row0 + rows,
+                       blur_weights_positive(cb) ? 1 : 0);
     return hipGetLastError();
 }
 
