@@ -36,3 +36,26 @@ def test_bench_gather_path_single_rank_rccl(built_lib, graph, inflight):
     assert out["n_gpus"] == 1 and out["value"] > 0
     assert out["config"]["launch"] == ("hipGraph replay" if graph == "on" else "eager")
     assert out["config"]["frames_in_flight"] == inflight
+
+
+def test_bench_json_contract(built_lib):
+    """The one JSON line of bench.py carries every key of the driver's contract, with sane types (small frame, bounded CPU leg)."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "2", "--width", "640", "--height", "360",
+           "--shadow-dim", "512", "--cube-dim", "64", "--cpu-band-rows", "32", "--no-producers"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    for k, t in (("metric", str), ("value", (int, float)), ("unit", str), ("n_gpus", int), ("steps", int), ("warmup", int),
+                 ("ms_per_step", (int, float)), ("higher_is_better", bool), ("scaling", str), ("dtype", str), ("data", str), ("config", dict),
+                 ("roofline", dict), ("cpu_baseline", dict)):
+        assert isinstance(out[k], t), (k, out[k])
+    assert out["vs_baseline"] is None and out["n_gpus"] == 1 and out["steps"] == 5 and out["warmup"] == 2
+    assert out["unit"] == "Mpixels/s" and out["scaling"] == "strong" and out["data"] == "synthetic" and "workload" in out["config"]
+    rf = out["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    assert "traffic" in rf and rf["achieved"] > 0
+    cb = out["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Mpixels/s" and isinstance(cb["sample"], str)
+    assert abs(out["value"] - 640 * 360 / (out["ms_per_step"] * 1e-3) / 1e6) / out["value"] < 0.01
