@@ -52,7 +52,8 @@ def parse():
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="independent frame pipelines (own stream + own ambient / edge workspace) alternating frames: the head and "
                          "tail of one frame's kernels overlap the other's (measured: -11 %% per whole 4K frame, -27 %% per 1/8 strip).  "
-                         "0 = auto: 1 at N = 1 (clean per-kernel durations for the roofline object), 2 for the strips of N > 1")
+                         "0 = auto: 1 at N = 1 (clean per-kernel durations for the roofline object), 4 for the strips of N > 1 "
+                         "(1/8 strip: 0.103 ms with 1, 0.089 with 2, 0.074 with 3, 0.069 with 4)")
     ap.add_argument("--also-two-in-flight", action="store_true",
                     help="N = 1: additionally time the K frames with two frames in flight and report it as an informational field "
                          "(off by default: its co-scheduled kernels would stretch the per-kernel averages of a rocprofv3 trace of the run)")
@@ -291,9 +292,9 @@ def main():
     # Frames in flight: consecutive frames are independent, so a second pipeline (own stream, own ambient / edge workspace,
     # same read-only input planes) lets the short kernels of one strip fill the dispatch gaps of the other.
     # auto: one frame at a time at N = 1 (the roofline object below needs kernel durations that are not stretched by a
-    # co-running frame, and has to agree with a rocprofv3 trace of this very command), two for the short strips of N > 1
-    nflight = args.frames_in_flight or (2 if rows < H else 1)
-    nflight = 1 if use_graph else max(1, min(nflight, 2))     # three or four measured the same as two
+    # co-running frame, and has to agree with a rocprofv3 trace of this very command), four for the short strips of N > 1
+    nflight = args.frames_in_flight or (4 if rows < H else 1)
+    nflight = 1 if use_graph else max(1, min(nflight, sharding.FrameGather.SLOTS if gather is not None else 4))
     apps, streams = [app], [torch.cuda.current_stream(dev)]
     for _ in range(nflight - 1):
         a = Crychic(ctx, W, H, planes["randvec"], planes["cube"], shadow_dim=args.shadow_dim)

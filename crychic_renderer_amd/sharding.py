@@ -84,13 +84,13 @@ def balanced_strips(depth, nranks, covered_row_weight=3.0):
 class FrameGather:
     """All-gather of the per-rank RGBA8 strips into a full frame on every rank.
 
-    Two frame slots alternate so the gather of frame i (issued asynchronously; RCCL runs it on its own stream
+    SLOTS frame slots rotate so the gather of frame i (issued asynchronously; RCCL runs it on its own stream
     behind an event on the render stream) overlaps the rendering of frame i+1.  Strips are equal-sized
     (H/2 divisible by nranks) so the collective is a plain all_gather_into_tensor; a ragged last strip falls
     back to all_gather with a padded send buffer.
     """
 
-    SLOTS = 2
+    SLOTS = 4
 
     def __init__(self, W, H, nranks, rank, device, group=None, bounds=None):
         """bounds = [(row0, rows)] per rank selects the point-to-point mode for strips of any size (balanced_strips): every
