@@ -84,24 +84,28 @@ int ssao_compute_impl(crychic_ctx* ctx, const crychic_ssao_constants* cb, const 
     CRY_HIP(cry::launch_ssao(*cb, normal, depth, randvec, ambient0, blurCount > 0 ? edge : nullptr, W, H, r0, rn, true, stream));
     if (afterSsao) CRY_HIP(hipEventRecord(afterSsao, stream));
     // Iteration 0 records each direction's tap decisions; iterations 1.. replay them (same geometry, same rows or fewer).
-    // Replay iterations run as one fused H+V launch each, ping-ponging ambient0 -> ambient1 -> ambient0; the result has to end
-    // in ambient0 (Ssao.cpp:75-78), so with an odd number of replay iterations the last one runs as two sweeps (0 -> 1 -> 0).
+    // Replay iterations run as one fused H+V launch each (in -> out, out != in).  The result has to end in ambient0
+    // (Ssao.cpp:75-78): an even number of them ping-pongs ambient0 <-> ambient1; an odd number >= 3 routes its last three
+    // steps through the spare plane of the edge workspace (0 -> 1 -> spare -> 0); a single one runs as two sweeps (0 -> 1 -> 0).
     const int replayIters = blurCount > 1 ? blurCount - 1 : 0;
-    const int fusedIters = replayIters & ~1;
+    uint16_t* spare = edge ? cry::edge_plane_carve(edge, W, H).spare : nullptr;
     uint16_t* cur = ambient0;
-    uint16_t* other = ambient1;
     for (int i = 0; i < blurCount; ++i) {
         uint32_t v0, vn;
         clamp_rows(h2, (int64_t)row0 - 5 * (blurCount - 1 - i), (int64_t)row0 + rows + 5 * (blurCount - 1 - i), &v0, &vn);
-        if (i >= 1 && i - 1 < fusedIters) {
-            CRY_HIP(cry::launch_blur_replay_pair(*cb, edge, cur, other, W, H, v0, vn, stream));
-            std::swap(cur, other);
+        if (i >= 1 && replayIters >= 2) {
+            const int left = blurCount - i;                      // fused steps still to run, this one included
+            uint16_t* dst;
+            if (replayIters % 2 == 0 || left > 3) dst = (cur == ambient0) ? ambient1 : ambient0;
+            else dst = left == 3 ? ambient1 : (left == 2 ? spare : ambient0);   // cur is ambient0, ambient1, spare in turn
+            CRY_HIP(cry::launch_blur_replay_pair(*cb, edge, cur, dst, W, H, v0, vn, stream));
+            cur = dst;
             continue;
         }
         clamp_rows(h2, (int64_t)row0 - 5 * (blurCount - i), (int64_t)row0 + rows + 5 * (blurCount - i), &r0, &rn);
         const cry::BlurMode mode = blurCount == 1 ? cry::BlurMode::Plain : (i == 0 ? cry::BlurMode::Record : cry::BlurMode::Replay);
-        CRY_HIP(cry::launch_blur(*cb, edge, cur, other, W, H, true, mode, r0, rn, stream));    // Ssao.cpp:240
-        CRY_HIP(cry::launch_blur(*cb, edge, other, cur, W, H, false, mode, v0, vn, stream));   // Ssao.cpp:241
+        CRY_HIP(cry::launch_blur(*cb, edge, ambient0, ambient1, W, H, true, mode, r0, rn, stream));    // Ssao.cpp:240
+        CRY_HIP(cry::launch_blur(*cb, edge, ambient1, ambient0, W, H, false, mode, v0, vn, stream));   // Ssao.cpp:241
     }
     return 0;
 }

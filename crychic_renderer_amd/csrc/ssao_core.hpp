@@ -27,11 +27,12 @@ struct EdgePlane {
     uint16_t* mask_v;
     float* total_h;
     float* total_v;
+    uint16_t* spare;   // a third ambient plane: lets an odd number of fused replay iterations end in ambient0 (api.cpp)
 };
 CRY_HD size_t edge_plane_bytes(uint32_t W, uint32_t H)
 {
     size_t w2 = W / 2, h2 = H / 2;
-    return w2 * h2 * 24 + (w2 + h2) * 8;
+    return w2 * h2 * 26 + (w2 + h2) * 8;
 }
 CRY_HD EdgePlane edge_plane_carve(void* base, uint32_t W, uint32_t H)
 {
@@ -46,6 +47,7 @@ CRY_HD EdgePlane edge_plane_carve(void* base, uint32_t W, uint32_t H)
     e.mask_v = (uint16_t*)(b + n * 22);   // n * 2
     e.gcol = (u2*)(b + n * 24);           // h2 * 8
     e.grow = e.gcol + h2;                 // w2 * 8
+    e.spare = (uint16_t*)(b + n * 24 + (w2 + h2) * 8);   // n * 2
     return e;
 }
 
