@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""One-off wide fuzz run on the GPU box: tests/test_fuzz.py::test_fuzz_device for seeds [start, start + n).
-usage: tools/fuzz_campaign.py [n=300] [start=5000]"""
+"""One-off wide fuzz run on the GPU box (test infrastructure: it drives the oracle): tests/test_fuzz.py::test_fuzz_device for
+seeds [start, start + n).  usage: python tests/fuzz_campaign.py [n=300] [start=5000]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
