@@ -244,7 +244,7 @@ def main():
     # let every rank time its own strip for a few frames, all-gather the times and re-cut (sharding.StripBalancer): equal
     # strips leave the ranks that own the ground 1.6x slower than the ones that own the sky.
     bounds = None
-    if args.partition == "balanced" and (world > 1 or args.strip):
+    if args.partition == "balanced" and (world > 1 or args.strip or args.force_gather):
         balancer = sharding.StripBalancer(planes["depth"], int(args.strip.split(":")[0]) if args.strip else world, args.covered_weight)
         bounds = balancer.bounds()
     if bounds and world > 1:
@@ -267,7 +267,7 @@ def main():
     if args.strip:
         sn, sr = (int(v) for v in args.strip.split(":"))
         row0, rows = bounds[sr] if bounds else sharding.strip_rows(H, sn, sr)
-    gather = sharding.FrameGather(W, H, world, rank, dev, bounds=bounds if world > 1 else None) if use_dist else None
+    gather = sharding.FrameGather(W, H, world, rank, dev, bounds=bounds if not args.strip else None) if use_dist else None
 
     # hipGraph: one graph per back-buffer slot replays the ~10 kernel launches of a frame with a single host call.
     use_graph = args.graph == "on"      # auto = eager: replaying a captured strip measured 5 % slower than launching it eagerly

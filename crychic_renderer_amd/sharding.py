@@ -93,10 +93,14 @@ class FrameGather:
     SLOTS = 4
 
     def __init__(self, W, H, nranks, rank, device, group=None, bounds=None):
-        """bounds = [(row0, rows)] per rank selects the point-to-point mode for strips of any size (balanced_strips): every
-        rank sends its strip to each peer and receives theirs straight into its own full-frame render buffer (one grouped
-        batch of sends / receives -- on the fully connected xGMI mesh each link carries exactly one strip), so the
-        gathered frame of a slot is render[slot] itself.  Without bounds: equal strips and one all_gather_into_tensor."""
+        """bounds = [(row0, rows)] per rank selects the ragged mode for strips of any height (StripBalancer): every rank
+        renders into a full-frame buffer and receives its peers' rows in place, so the gathered frame of a slot is
+        render[slot] itself.  On the nccl (= RCCL) backend that is ONE call per frame -- all_gather with a list of
+        different-sized row views, which the backend runs as a coalesced group of broadcasts (one per strip; on the fully
+        connected xGMI mesh every link carries each strip once) -- because per-call host cost matters once a strip renders
+        in 70 us: a batch of 2(N-1) isend/irecv ops costs roughly 15 us of Python/dispatcher time per op.  Backends
+        without uneven all_gather (gloo, used by the CPU tests) fall back to that batch of sends / receives.
+        Without bounds: equal strips and one all_gather_into_tensor."""
         self.W, self.H, self.nranks, self.rank, self.group = W, H, nranks, rank, group
         self.bounds = [tuple(int(v) for v in b) for b in bounds] if bounds is not None else None
         if self.bounds is not None:
@@ -104,6 +108,8 @@ class FrameGather:
             self.row0, self.rows = self.bounds[rank]
             self.render = [torch.zeros((H, W, 4), dtype=torch.uint8, device=device) for _ in range(self.SLOTS)]
             self.pending = [None] * self.SLOTS
+            self.p2p = dist.get_backend(group) != "nccl"
+            self.views = [[buf[r0:r0 + rn] for (r0, rn) in self.bounds] for buf in self.render]
             return
         self.row0, self.rows = strip_rows(H, nranks, rank)
         self.uniform = (H // 2) % nranks == 0
@@ -126,6 +132,9 @@ class FrameGather:
 
     def launch(self, i):
         s = i % self.SLOTS
+        if self.bounds is not None and not self.p2p:
+            self.pending[s] = dist.all_gather(self.views[s], self.views[s][self.rank], group=self.group, async_op=True)
+            return
         if self.bounds is not None:
             buf = self.render[s]
             ops = []

@@ -21,10 +21,10 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("graph,inflight", [("on", 1), ("off", 1), ("off", 2)])
-def test_bench_gather_path_single_rank_rccl(built_lib, graph, inflight):
+@pytest.mark.parametrize("graph,inflight,partition", [("on", 1, "equal"), ("off", 1, "equal"), ("off", 2, "equal"), ("off", 2, "balanced")])
+def test_bench_gather_path_single_rank_rccl(built_lib, graph, inflight, partition):
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-gather", "--graph", graph, "--frames-in-flight", str(inflight), "--steps", "7",
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-gather", "--graph", graph, "--frames-in-flight", str(inflight), "--partition", partition, "--steps", "7",
            "--warmup", "3", "--width", "640", "--height", "360", "--shadow-dim", "512", "--cube-dim", "64",
            "--no-cpu-baseline", "--no-producers"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
