@@ -77,7 +77,6 @@ def cpu_baseline(planes, args, pcf_radius):
     same frame; band size is calibrated so the leg takes roughly 10-30 s.  kind = "port": the reference has no CPU
     implementation (D3D12 + HLSL only), the oracle is this repo's literal restatement."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
-    import numpy as np
     import oracle_lib
     import scene_util
     orc = oracle_lib.load()
@@ -222,7 +221,7 @@ def main():
     if use_dist:
         dist.barrier()
     from crychic_renderer_amd import Context, Crychic, scene
-    from crychic_renderer_amd._lib import lib, check
+    from crychic_renderer_amd._lib import lib
     from crychic_renderer_amd import sharding
 
     W, H = args.width, args.height
