@@ -2,34 +2,42 @@
 """bench.py -- Mpixels/s of the CRYCHIC hot path (SSAO + 2*blurCount bilateral sweeps + deferred PBR lighting)
 on N MI355X GPUs of one node.
 
-    python bench.py --gpus 1 --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: this process starts the N rank processes itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W               (one rank per GPU from a launcher: same code path)
 
 A "step" is one frame: every input plane (G-buffer, view normals, depth, 4 shadow cascades, cubemap, noise) is
-already resident in HBM; the step runs crychic_draw_hot_path for this rank's row strip and, for N > 1, the RCCL
-exchange of the composed RGBA8 strips (strong scaling of ONE frame, the only collective).
-Consecutive frames are independent, so two frame pipelines (two HIP streams, each with its own ambient / edge
-workspace, --frames-in-flight) alternate: `value` is steady-state throughput; config.pass_ms is the latency view
-(one frame at a time on one stream).  N > 1: strips are cost-balanced from measured strip times (--partition).
-Workload = BASELINE.json configs[2]: 3840x2160, 3 directional lights, blurCount 4, cascade PCF.
-The PCF radius follows the reference shader as written (Common.hlsl:305 unsigned division => 16 coincident taps);
---pcf intended benches the 2.5-texel variant instead.
+already resident in HBM; the step runs crychic_draw_hot_path for this rank's row strip and, for N > 1, the exchange
+of the composed RGBA8 strips (strong scaling of ONE frame; the only collective).  The exchange is
+crychic_allgather_frame -- RCCL over xGMI behind the C ABI (csrc/comm.cpp), enqueued on the stream that rendered
+the strip; torch.distributed (gloo) carries only control traffic (rendezvous id, barriers, the max over ranks).
+Workload = BASELINE.json configs[2]: 3840x2160, 3 directional lights, blurCount 4, cascade PCF.  The PCF radius
+follows the reference shader as written (Common.hlsl:305 unsigned division => 16 coincident taps); --pcf intended
+benches the 2.5-texel variant instead.
 
-Rank 0 prints ONE JSON line: metric/value/... plus "roofline" (dominant kernel = deferred lighting, measured with
-HIP events on the launch stream) and "cpu_baseline" (the CPU oracle timed on a bounded band of the same frame).
+Rank 0 prints ONE JSON line: metric/value/... plus "roofline" (frame level per SURVEY.md 8d, with a per-kernel
+break-down measured by HIP events on the launch stream) and "cpu_baseline" (the CPU oracle on a band of the frame).
+
+No launch is ever retried inside a process that has touched the GPU and nothing is re-exec'ed: a failed or stuck
+rank ends the run with a non-zero exit code (--timeout).
 """
 import argparse
 import ctypes as C
+import datetime
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_counters.json")
 
 
 def parse():
@@ -44,34 +52,187 @@ def parse():
     ap.add_argument("--shadow-dim", type=int, default=4096)
     ap.add_argument("--cube-dim", type=int, default=256)
     ap.add_argument("--pcf", choices=["literal", "intended"], default="literal")
+    ap.add_argument("--camera", choices=["reference", "covered"], default="reference",
+                    help="covered: the camera pitched down until no pixel is sky (informational: every G-buffer texel is read)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-producers", action="store_true", help="skip the informational timing of the producer passes")
-    ap.add_argument("--graph", choices=["auto", "on", "off"], default="auto",
-                    help="replay the frame's launches from a captured hipGraph (auto = off: on a 1/8 strip the replay measured "
-                         "0.085 ms against 0.081 ms for eager launches, which the GPU already pipelines)")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="independent frame pipelines (own stream + own ambient / edge workspace) alternating frames: the head and "
-                         "tail of one frame's kernels overlap the other's (measured: -11 %% per whole 4K frame, -27 %% per 1/8 strip).  "
-                         "0 = auto: 1 at N = 1 (clean per-kernel durations for the roofline object), 4 for the strips of N > 1 "
-                         "(1/8 strip: 0.103 ms with 1, 0.089 with 2, 0.074 with 3, 0.069 with 4)")
+                         "tail of one frame's kernels overlap the other's.  0 = auto: 1 at N = 1 (clean per-kernel durations for "
+                         "the roofline object), 4 for the strips of N > 1")
     ap.add_argument("--also-two-in-flight", action="store_true",
-                    help="N = 1: additionally time the K frames with two frames in flight and report it as an informational field "
-                         "(off by default: its co-scheduled kernels would stretch the per-kernel averages of a rocprofv3 trace of the run)")
+                    help="N = 1: additionally time the K frames with two frames in flight (informational field)")
     ap.add_argument("--force-gather", action="store_true",
-                    help="run the strip all-gather (RCCL) even with one rank: exercises the N > 1 code path on a 1-GPU box")
-    ap.add_argument("--partition", choices=["balanced", "equal"], default="balanced",
-                    help="N > 1: balanced = cost-aware strip heights from the depth plane's coverage + point-to-point strip exchange; "
-                         "equal = H/N rows each + one all_gather_into_tensor")
+                    help="run the strip exchange even with one rank: exercises the N > 1 code path on a 1-GPU box")
+    ap.add_argument("--exchange", choices=["abi", "torch"], default="abi",
+                    help="abi: crychic_allgather_frame (RCCL behind the C ABI); torch: torch.distributed nccl all_gather (fallback)")
+    ap.add_argument("--partition", choices=["equal", "balanced"], default="equal",
+                    help="N > 1: equal = H/N rows each, one in-place ncclAllGather (default: the plan every test covers); "
+                         "balanced = cost-aware strip heights re-cut from measured strip times + one group of ncclBroadcasts")
     ap.add_argument("--balance-iters", type=int, default=4, help="measured re-balancing steps of the strip plan before the warm-up")
     ap.add_argument("--covered-weight", type=float, default=3.0, help="cost of a fully covered row pair relative to a sky row pair")
-    ap.add_argument("--strip", default="", help="N:R -- time only the row strip rank R of N would render (no gather): what one rank of an "
-                                                "N-GPU run computes per frame, measurable on a 1-GPU box")
+    ap.add_argument("--strip", default="", help="N:R -- time only the row strip rank R of N would render (no exchange): what one rank "
+                                                "of an N-GPU run computes per frame, measurable on a 1-GPU box")
     ap.add_argument("--point-lights", type=int, default=0, help="extension (BASELINE configs[4]): n x n point-light grid, e.g. 8")
     ap.add_argument("--dump-scene", default="", help="write the input planes + constants for tools/prof_driver and exit")
     ap.add_argument("--cpu-band-rows", type=int, default=0, help="full-res rows of the CPU baseline band (0 = auto)")
+    ap.add_argument("--timeout", type=float, default=900.0, help="seconds after which a rank (and the spawning parent) gives up and "
+                                                                 "exits non-zero instead of waiting on a stuck peer")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="plumbing rehearsal WITHOUT a GPU and without rendering: rank spawning, rendezvous, the strip plan and a gloo "
+                         "exchange of synthetic strips; prints a line marked data=dry-run (not a measurement)")
+    ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)   # tests: this rank exits 7 before the rendezvous
     return ap.parse_args()
 
 
+# ---- launching ----------------------------------------------------------------------------------------------------------
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher.  This parent never initialises HIP: it builds the library (hipcc, no
+    GPU needed), starts one child per rank with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, relays rank 0's JSON line,
+    and exits non-zero as soon as any child does (or after --timeout), ending the others by their exact PIDs."""
+    if not args.dry_run:
+        from crychic_renderer_amd import build
+        build.build(verbose=False)
+    port = free_port()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), CRYCHIC_BENCH_LAUNCHER="self-spawn")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr, text=(r == 0)))
+    lines = []
+    reader = threading.Thread(target=lambda: lines.extend(procs[0].stdout), daemon=True)
+    reader.start()
+    deadline = time.monotonic() + args.timeout + 30.0
+    code = 0
+    while True:
+        states = [p.poll() for p in procs]
+        bad = [(r, s) for r, s in enumerate(states) if s not in (None, 0)]
+        if bad:
+            code = bad[0][1] if bad[0][1] > 0 else 1
+            print("bench.py: rank %d exited with status %d; stopping the other ranks" % bad[0], file=sys.stderr, flush=True)
+            break
+        if all(s == 0 for s in states):
+            break
+        if time.monotonic() > deadline:
+            code = 124
+            print("bench.py: ranks still running after %.0f s; stopping them" % (args.timeout + 30.0), file=sys.stderr, flush=True)
+            break
+        time.sleep(0.1)
+    if code:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.monotonic() + 10.0
+        for p in procs:
+            try:
+                p.wait(timeout=max(0.1, t_end - time.monotonic()))
+            except subprocess.TimeoutExpired:
+                p.kill()
+    reader.join(timeout=5.0)
+    for ln in lines:
+        sys.stdout.write(ln)
+    sys.stdout.flush()
+    if not code and not any(ln.lstrip().startswith("{") for ln in lines):
+        print("bench.py: rank 0 printed no result line", file=sys.stderr, flush=True)
+        code = 1
+    raise SystemExit(code)
+
+
+def private_stdout():
+    """Native libraries (gloo, RCCL) print progress chatter on fd 1; the contract is ONE JSON line there.  Point fd 1 at
+    stderr for the life of the rank process and return a private handle on the real stdout for that line."""
+    sys.stdout.flush()
+    real = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    return real
+
+
+def arm_watchdog(seconds, rank):
+    """A stuck collective (a peer that never joined) cannot be recovered from inside the process: give up loudly."""
+    def fire():
+        print("bench.py rank %d: no result after %.0f s (stuck exchange or peer?) -- exiting 124" % (rank, seconds), file=sys.stderr, flush=True)
+        os._exit(124)
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+    return t
+
+
+def init_control_plane(args, world, rank):
+    """gloo process group for control traffic only.  Finite timeout: a missing peer raises instead of hanging."""
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")      # the container hostname may not resolve
+    dist.init_process_group(backend="gloo", timeout=datetime.timedelta(seconds=min(args.timeout, 300.0)))
+    return dist
+
+
+# ---- dry run (no GPU, no rendering) ----------------------------------------------------------------------------------------
+def dry_run(args, world, rank, result_out):
+    """Everything around the kernels, on CPU: rendezvous, strip plan, frames-in-flight slot rotation, the exchange (gloo
+    stands in for RCCL) and the verification that every rank ends up with every strip.  Strips carry a synthetic pattern."""
+    import torch
+    from crychic_renderer_amd import sharding
+    dist = init_control_plane(args, world, rank)
+    W, H = args.width, args.height
+    dev = torch.device("cpu")
+    bounds = None
+    if args.partition == "balanced":
+        depth = torch.full((H, W), 0xFFFFFF, dtype=torch.int32)
+        depth[H // 2:] = 0x7FFFFF            # lower half covered
+        bounds = sharding.StripBalancer(depth, world, args.covered_weight).bounds()
+    gather = sharding.FrameGather(W, H, world, rank, dev, bounds=bounds)
+    row0, rows = gather.row0, gather.rows
+
+    def pattern(frame, r):
+        r0, rn = bounds[r] if bounds else sharding.strip_rows(H, world, r)
+        return r0, rn, (17 * frame + 29 * r + 3) % 251
+
+    dist.barrier()
+    t0 = time.perf_counter()
+    n = args.warmup + args.steps
+    for i in range(n):
+        buf = gather.strip_buffer(i)
+        buf[row0:row0 + rows] = pattern(i, rank)[2]
+        gather.launch(i)
+    gather.wait_all()
+    dist.barrier()
+    dt = time.perf_counter() - t0
+    ok = True
+    for i in range(max(0, n - gather.SLOTS), n):
+        f = gather.frame(i)
+        for r in range(world):
+            r0, rn, v = pattern(i, r)
+            ok = ok and bool((f[r0:r0 + rn] == v).all())
+    flag = torch.tensor([0 if ok else 1], dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+    tmax = torch.tensor([dt], dtype=torch.float64)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        print(json.dumps({"metric": "DRY RUN (no rendering, not a measurement)", "value": None, "unit": "Mpixels/s", "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(float(tmax) / max(n, 1) * 1e3, 4),
+                          "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u8", "data": "dry-run",
+                          "config": {"workload": "synthetic strips %dx%d" % (W, H), "launcher": os.environ.get("CRYCHIC_BENCH_LAUNCHER", "external"),
+                                     "partition": args.partition, "strip_plan": [b[1] for b in bounds] if bounds else None,
+                                     "exchange": "gloo stand-in", "exchange_verified": bool(int(flag) == 0)}}), file=result_out, flush=True)
+    dist.destroy_process_group()
+    if int(flag):
+        raise SystemExit("bench.py --dry-run: a rank is missing a peer's strip")
+
+
+# ---- measurement helpers ----------------------------------------------------------------------------------------------------
 def cpu_baseline(planes, args, pcf_radius):
     """The CPU oracle (oracle/, OpenMP over rows, all host cores) on a horizontal band through the middle of the
     same frame; band size is calibrated so the leg takes roughly 10-30 s.  kind = "port": the reference has no CPU
@@ -116,17 +277,34 @@ def cpu_baseline(planes, args, pcf_radius):
                       "frame, %.1f s%s" % (2 * bc, rows, W, rows, dt, " (mean of %d runs)" % reps if reps > 1 else "")}
 
 
-def pmc_traffic(args, world):
-    """HBM bytes per light_kernel launch from the committed rocprofv3 PMC passes (profiles/r01_pmc_traffic.json:
-    (2*FETCH_SIZE + WRITE_SIZE) * 1024, the gfx950 correction of MI355X_MICROARCH.md).  PMC collection cannot run
-    inside this process, so the figure applies only to the exact workload it was measured on; otherwise null."""
-    if world != 1 or (args.width, args.height, args.blur_count, args.lights, args.pcf, args.shadow_dim) != (3840, 2160, 4, 3, "literal", 4096):
+def kernel_source_hash():
+    """Identifies the kernels a committed counter profile was taken on: sha256 over csrc/*.{hip,hpp,cpp} + the build flags."""
+    from crychic_renderer_amd import build
+    h = hashlib.sha256()
+    for name in sorted(build.SOURCES + build.HEADERS):
+        with open(os.path.join(build.CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read())
+    h.update(" ".join(build.FLAGS).encode())
+    return h.hexdigest()[:16]
+
+
+def pmc_profile(args, world):
+    """Hardware-counter figures per launch from the committed rocprofv3 PMC passes (tools/pmc_passes.sh ->
+    profiles/r02_pmc_counters.json).  PMC collection cannot run inside this process, so the figures apply only to the
+    exact workload AND the exact kernel sources they were measured on: any mismatch returns None (printed as null)."""
+    if world != 1 or args.strip or args.point_lights:
         return None
     try:
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
-            return int(json.load(f)["kernels"]["cry::light_kernel<true>"]["hbm_bytes_per_launch"])
-    except (OSError, KeyError, ValueError):
+        with open(PMC_PROFILE) as f:
+            prof = json.load(f)
+    except (OSError, ValueError):
         return None
+    wl = prof.get("workload", {})
+    mine = {"width": args.width, "height": args.height, "blur_count": args.blur_count, "lights": args.lights, "pcf": args.pcf,
+            "shadow_dim": args.shadow_dim, "camera": args.camera}
+    if any(wl.get(k) != v for k, v in mine.items()) or prof.get("kernel_source_hash") != kernel_source_hash():
+        return None
+    return prof.get("kernels")
 
 
 def time_producers(ctx, planes, args, torch):
@@ -192,28 +370,47 @@ def dump_scene(d, planes, args, pcf_radius):
     print("scene dumped to", d)
 
 
+def bench_camera(args):
+    from crychic_renderer_amd import scene
+    cam = scene.default_camera(args.width, args.height)
+    if args.camera == "covered":
+        # eye moved into the lane between two box columns and pitched down 25 degrees: the top edge of the view still meets
+        # the ground grid and nothing is nearer than the near plane, so every pixel is covered (checked: covered_pixel_fraction)
+        import math
+        a = math.radians(25.0)
+        cam.pos[:] = (2.5, 2.0, -15.0)
+        cam.look[:] = (0.0, -math.sin(a), math.cos(a))
+        cam.up[:] = (0.0, math.cos(a), math.sin(a))
+    return cam
+
+
+# ---- the benchmark proper -------------------------------------------------------------------------------------------------------
 def main():
     args = parse()
-    import torch
-    import torch.distributed as dist
-
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        spawn_ranks(args)                      # never returns
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE %d != --gpus %d" % (world, args.gpus))
+    watchdog = arm_watchdog(args.timeout, rank)
+    result_out = private_stdout()
+    if args.dry_run:
+        if rank == args.dry_run_fail_rank:
+            raise SystemExit(7)
+        dry_run(args, world, rank, result_out)
+        watchdog.cancel()
+        return
+
+    import torch
     if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (the product has no CPU path)")
+        raise SystemExit("bench.py needs a HIP device (the product has no CPU path); --dry-run rehearses the plumbing without one")
+    if local_rank >= torch.cuda.device_count():
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_gather
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29531")
-        os.environ.setdefault("RANK", "0")
-        os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    dist = init_control_plane(args, world, rank) if use_dist else None
 
     from crychic_renderer_amd import build
     if rank == 0:
@@ -227,125 +424,137 @@ def main():
     W, H = args.width, args.height
     ctx = Context(local_rank)
     dev = ctx.device
-    planes = scene.make_scene(W, H, shadow_dim=args.shadow_dim, cube_dim=args.cube_dim, device=str(dev))
-    app = Crychic(ctx, W, H, planes["randvec"], planes["cube"], shadow_dim=args.shadow_dim)
-    app.load_scene(planes)
-    app.blurCount, app.numDirLights = args.blur_count, args.lights
-    app.pcfSearchRadius = lib.crychic_pcf_search_radius(args.shadow_dim, 1 if args.pcf == "literal" else 0)
+    planes = scene.make_scene(W, H, shadow_dim=args.shadow_dim, cube_dim=args.cube_dim, device=str(dev),
+                              consts=scene.Constants(W, H, args.shadow_dim, cam=bench_camera(args)))
+    pcf_radius = lib.crychic_pcf_search_radius(args.shadow_dim, 1 if args.pcf == "literal" else 0)
+
+    def new_app():
+        a = Crychic(ctx, W, H, planes["randvec"], planes["cube"], shadow_dim=args.shadow_dim)
+        a.load_scene(planes)
+        a.blurCount, a.numDirLights, a.pcfSearchRadius = args.blur_count, args.lights, pcf_radius
+        if args.point_lights:
+            a.set_point_lights(scene.point_light_grid(args.point_lights))
+        return a
+
+    app = new_app()
     if args.dump_scene:
-        dump_scene(args.dump_scene, planes, args, app.pcfSearchRadius)
+        dump_scene(args.dump_scene, planes, args, pcf_radius)
         return
-    if args.point_lights:
-        app.set_point_lights(scene.point_light_grid(args.point_lights))
+
+    def all_ranks_ok(ok):
+        """True when `ok` holds on every rank (control plane; a no-op without peers)."""
+        if not use_dist:
+            return bool(ok)
+        flag = torch.tensor([0 if ok else 1], dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        return int(flag) == 0
 
     # ---- strip plan -------------------------------------------------------------------------------------------------
-    # equal: H/N rows per rank.  balanced: start from the depth plane's coverage (a covered row costs ~3x a sky row), then
-    # let every rank time its own strip for a few frames, all-gather the times and re-cut (sharding.StripBalancer): equal
-    # strips leave the ranks that own the ground 1.6x slower than the ones that own the sky.
+    # equal (default): H/N rows per rank -- the plan every parity and gloo test covers, one in-place ncclAllGather.
+    # balanced (opt-in): start from the depth plane's coverage (a covered row costs ~3x a sky row), then let every rank time
+    # its own strip for a few frames, share the times and re-cut (sharding.StripBalancer).
     bounds = None
     if args.partition == "balanced" and (world > 1 or args.strip or args.force_gather):
         balancer = sharding.StripBalancer(planes["depth"], int(args.strip.split(":")[0]) if args.strip else world, args.covered_weight)
         bounds = balancer.bounds()
-    if bounds and world > 1:
-        app.mBackBuffer = planes["out"]
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for _ in range(args.balance_iters):
-            r0_, rn_ = bounds[rank]
-            for _ in range(3):
-                app.Draw(r0_, rn_)
-            e0.record()
-            for _ in range(20):
-                app.Draw(r0_, rn_)
-            e1.record()
-            torch.cuda.synchronize()
-            mine = torch.tensor([e0.elapsed_time(e1) / 20.0], device=dev, dtype=torch.float32)
-            every = torch.zeros(world, device=dev, dtype=torch.float32)
-            dist.all_gather_into_tensor(every, mine)
-            bounds = balancer.update([float(v) for v in every.cpu()])      # same inputs, same plan on every rank
+        if world > 1:
+            app.mBackBuffer = planes["out"]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for _ in range(args.balance_iters):
+                r0_, rn_ = bounds[rank]
+                for _ in range(3):
+                    app.Draw(r0_, rn_)
+                e0.record()
+                for _ in range(20):
+                    app.Draw(r0_, rn_)
+                e1.record()
+                torch.cuda.synchronize()
+                mine = torch.tensor([e0.elapsed_time(e1) / 20.0], dtype=torch.float64)
+                every = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+                dist.all_gather(every, mine)
+                bounds = balancer.update([float(v) for v in every])      # same inputs, same plan on every rank
     row0, rows = bounds[rank] if bounds and not args.strip else sharding.strip_rows(H, world, rank)
     if args.strip:
         sn, sr = (int(v) for v in args.strip.split(":"))
         row0, rows = bounds[sr] if bounds else sharding.strip_rows(H, sn, sr)
-    gather = sharding.FrameGather(W, H, world, rank, dev, bounds=bounds if not args.strip else None) if use_dist else None
 
-    # hipGraph: one graph per back-buffer slot replays the ~10 kernel launches of a frame with a single host call.
-    use_graph = args.graph == "on"      # auto = eager: replaying a captured strip measured 5 % slower than launching it eagerly
-    graphs = {}
-    if use_graph:
-        # Captured up front, before any collective is in flight (thread-local capture mode: the RCCL watchdog thread
-        # may query events meanwhile).  A failed capture falls back to eager launches of the same kernels.
-        try:
-            for buf in (gather.render if gather is not None else [planes["out"]]):
-                app.mBackBuffer = buf
-                app.Draw(row0, rows)              # warm: no lazy allocation inside the capture
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    app.Draw(row0, rows)
-                graphs[buf.data_ptr()] = g
-        except Exception as e:  # noqa: BLE001 -- any capture problem: report and keep going eagerly
-            print("bench.py: hipGraph capture failed (%s); launching eagerly" % e, file=sys.stderr, flush=True)
-            graphs, use_graph = {}, False
-            torch.cuda.synchronize()
-
-    # Frames in flight: consecutive frames are independent, so a second pipeline (own stream, own ambient / edge workspace,
-    # same read-only input planes) lets the short kernels of one strip fill the dispatch gaps of the other.
+    # Frames in flight: consecutive frames are independent, so further pipelines (own stream, own ambient / edge workspace,
+    # same read-only input planes) let the short kernels of one strip fill the dispatch gaps of the others.
     # auto: one frame at a time at N = 1 (the roofline object below needs kernel durations that are not stretched by a
     # co-running frame, and has to agree with a rocprofv3 trace of this very command), four for the short strips of N > 1
-    nflight = args.frames_in_flight or (4 if rows < H else 1)
-    nflight = 1 if use_graph else max(1, min(nflight, sharding.FrameGather.SLOTS if gather is not None else 4))
+    nflight = max(1, min(args.frames_in_flight or (4 if rows < H else 1), 4))
     apps, streams = [app], [torch.cuda.current_stream(dev)]
     for _ in range(nflight - 1):
-        a = Crychic(ctx, W, H, planes["randvec"], planes["cube"], shadow_dim=args.shadow_dim)
-        a.load_scene(planes)
-        a.blurCount, a.numDirLights, a.pcfSearchRadius = app.blurCount, app.numDirLights, app.pcfSearchRadius
-        if args.point_lights:
-            a.set_point_lights(scene.point_light_grid(args.point_lights))
-        apps.append(a)
+        apps.append(new_app())
         streams.append(torch.cuda.Stream(device=dev))
-    outs = [planes["out"]] + [torch.zeros_like(planes["out"]) for _ in range(nflight - 1)]
 
-    def draw(k, slot_buffer):
-        if use_graph:
-            graphs[slot_buffer.data_ptr()].replay()
-        else:
-            apps[k].mBackBuffer = slot_buffer
-            apps[k].Draw(row0, rows)
+    # ---- the exchange ------------------------------------------------------------------------------------------------------
+    # abi: crychic_allgather_frame, enqueued on the pipeline's own stream (slot k belongs to stream k: stream order keeps a
+    # slot's gather ahead of its next lighting pass, no host wait anywhere).  If the communicator cannot be created on every
+    # rank, all ranks fall back together to torch.distributed's nccl all_gather (equal strips only).
+    exchange, exchange_kind = None, None
+    if use_dist and not args.strip:
+        if args.exchange == "abi":
+            idt = torch.zeros(128, dtype=torch.uint8)
+            try:
+                if rank == 0:
+                    idt = torch.frombuffer(bytearray(sharding.StripExchange.new_unique_id()), dtype=torch.uint8).clone()
+                ok = True
+            except Exception as e:  # noqa: BLE001
+                print("bench.py rank %d: no RCCL rendezvous id (%s)" % (rank, e), file=sys.stderr, flush=True)
+                ok = False
+            if all_ranks_ok(ok):
+                dist.broadcast(idt, src=0)
+                try:
+                    exchange = sharding.StripExchange(ctx, W, H, world, rank, bytes(idt.numpy().tobytes()), bounds=bounds, slots=nflight)
+                    for k in range(nflight):                 # first exchange of every slot, outside the timed region
+                        exchange.launch(k, streams[k])
+                    exchange.wait_all()
+                    ok = True
+                except Exception as e:  # noqa: BLE001
+                    print("bench.py rank %d: crychic_allgather_frame unavailable (%s)" % (rank, e), file=sys.stderr, flush=True)
+                    ok = False
+                if all_ranks_ok(ok):
+                    exchange_kind = "crychic_allgather_frame (C ABI, RCCL): " + ("one group of in-place ncclBroadcasts" if bounds else "in-place ncclAllGather")
+                else:
+                    if exchange is not None:
+                        exchange.abort()
+                    exchange = None
+        if exchange is None:
+            if bounds is not None:
+                bounds = None
+                row0, rows = sharding.strip_rows(H, world, rank)
+                args.partition = "equal (fallback)"
+            nccl = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=min(args.timeout, 300.0)))
+            exchange = sharding.FrameGather(W, H, world, rank, dev, group=nccl)
+            exchange_kind = "torch.distributed nccl all_gather_into_tensor (fallback)" if args.exchange == "abi" else "torch.distributed nccl all_gather_into_tensor"
+    abi = isinstance(exchange, sharding.StripExchange)
+    outs = [planes["out"]] + [torch.zeros_like(planes["out"]) for _ in range(nflight - 1)]
 
     def step(i):
         k = i % nflight
-        with torch.cuda.stream(streams[k]):            # launches, the exchange's pre-sync and its wait all bind to this stream
-            if gather is None:
-                draw(k, outs[k])
+        with torch.cuda.stream(streams[k]):            # launches and the exchange bind to this pipeline's stream
+            if exchange is None:
+                apps[k].mBackBuffer = outs[k]
+                apps[k].Draw(row0, rows)
+            elif abi:
+                apps[k].mBackBuffer = exchange.strip_buffer(k)
+                apps[k].Draw(row0, rows)
+                exchange.launch(k, streams[k])
             else:
-                draw(k, gather.strip_buffer(i))        # double-buffered so the exchange of frame i overlaps Draw(i+1)
-                gather.launch(i)
+                apps[k].mBackBuffer = exchange.strip_buffer(i)   # waits for the gather that last read this slot
+                apps[k].Draw(row0, rows)
+                exchange.launch(i)
 
     def fence():
-        if gather is not None:
-            gather.wait_all()
+        if exchange is not None:
+            exchange.wait_all()
         torch.cuda.synchronize()
         if use_dist:
-            dist.barrier()
-            torch.cuda.synchronize()
-
-    # First exchange under guard: if the point-to-point batch of the balanced plan fails on any rank (an exception, not a
-    # hang), every rank falls back to equal strips + one all_gather_into_tensor, which uses the collective path only.
-    if gather is not None and world > 1 and bounds is not None:
-        failed = torch.zeros(1, device=dev, dtype=torch.int32)
-        try:
-            step(0)
-            gather.wait_all()
-            torch.cuda.synchronize()
-        except Exception as e:  # noqa: BLE001
-            print("bench.py rank %d: strip exchange failed (%s); falling back to equal strips" % (rank, e), file=sys.stderr, flush=True)
-            failed.fill_(1)
-        dist.all_reduce(failed, op=dist.ReduceOp.MAX)
-        if int(failed.item()):
-            bounds = None
-            row0, rows = sharding.strip_rows(H, world, rank)
-            gather = sharding.FrameGather(W, H, world, rank, dev)
-            args.partition = "equal (fallback)"
+            dist.barrier()                              # coarse (TCP), then tight: a one-word all-reduce on the GPU
+            if abi:
+                exchange.barrier()
+                torch.cuda.synchronize()
 
     # Set-up, not part of W or K: code objects loaded and clocks ramped before the caller's warm-up count starts to matter
     # (with W = 1 the first timed frames would otherwise run at the idle clock).
@@ -358,35 +567,38 @@ def main():
         step(i)
     fence()
     exchange_ok = None
-    if gather is not None and world > 1 and args.warmup > 0:
-        # every rank must now hold the same complete frame: compare a checksum of the last gathered frame across ranks
-        f = gather.frame(args.warmup - 1)
-        chk = (f.reshape(-1).to(torch.int64) * (torch.arange(f.numel(), device=dev, dtype=torch.int64) % 251 + 1)).sum().reshape(1)
-        allchk = torch.zeros(world, device=dev, dtype=torch.int64)
-        dist.all_gather_into_tensor(allchk, chk)
-        exchange_ok = bool((allchk == allchk[0]).all().item()) and bool((f[..., 3] == 255).all().item())
-        if not exchange_ok:
-            raise SystemExit("bench.py: the ranks disagree on the gathered frame (checksums %s)" % allchk.tolist())
+    if exchange is not None and args.warmup > 0:
+        # Every rank must now hold the same complete frame, and it must be the frame one GPU renders alone: compare a checksum
+        # of the last gathered frame across ranks, and the gathered frame with a full local render bit for bit.
+        last = args.warmup - 1
+        f = exchange.frame(last % nflight if abi else last)
+        chk = int((f.reshape(-1).to(torch.int64) * (torch.arange(f.numel(), device=dev, dtype=torch.int64) % 251 + 1)).sum())
+        allchk = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(allchk, torch.tensor([chk], dtype=torch.int64))
+        app.mBackBuffer = planes["out"]
+        app.Draw(0, H)
+        torch.cuda.synchronize()
+        exchange_ok = all(int(c) == chk for c in allchk) and bool(torch.equal(f, planes["out"]))
+        if not all_ranks_ok(exchange_ok):
+            raise SystemExit("bench.py rank %d: the gathered frame differs between ranks or from the single-GPU frame (checksums %s)"
+                             % (rank, [int(c) for c in allchk]))
+        fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     fence()
     dt = time.perf_counter() - t0
-    if gather is None and nflight > 1 and not torch.equal(outs[0], outs[1]):
-        raise SystemExit("bench.py: the two frame pipelines disagree")      # same inputs, same kernels: must be the same bytes
+    if exchange is None and nflight > 1 and not torch.equal(outs[0], outs[1]):
+        raise SystemExit("bench.py: the frame pipelines disagree")      # same inputs, same kernels: must be the same bytes
     if use_dist:
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        tmax = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+        dt = float(tmax)
 
     # ---- informational at N = 1: the same K frames with two frames in flight (not `value`, see --frames-in-flight) ----
     overlapped = None
-    if args.also_two_in_flight and world == 1 and not args.strip and nflight == 1 and not use_graph:
-        app2 = Crychic(ctx, W, H, planes["randvec"], planes["cube"], shadow_dim=args.shadow_dim)
-        app2.load_scene(planes)
-        app2.blurCount, app2.numDirLights, app2.pcfSearchRadius = app.blurCount, app.numDirLights, app.pcfSearchRadius
-        if args.point_lights:
-            app2.set_point_lights(scene.point_light_grid(args.point_lights))
+    if args.also_two_in_flight and world == 1 and not args.strip and nflight == 1:
+        app2 = new_app()
         app2.mBackBuffer = torch.zeros_like(planes["out"])
         app.mBackBuffer = planes["out"]
         pair = [(app, torch.cuda.current_stream(dev)), (app2, torch.cuda.Stream(device=dev))]
@@ -422,11 +634,33 @@ def main():
     if rank == 0:
         npx = W * H
         strip_px = W * rows
-        # algorithmic bytes of the lighting pass: 48 B G0..G2 + 2 B/4 px ambient + 4 B RGBA8 out = 52.5 B per pixel
-        # (depth mask, shadow cascades and cubemap are not counted)
-        light_bytes = 52.5 * strip_px
-        achieved = light_bytes / (acc["light_ms"] * 1e-3) / 1e9
-        frame_bytes = (59 + 14 * args.blur_count) * npx
+        covered = float(((planes["depth"].to(torch.int64) & 0xFFFFFF) != 0xFFFFFF).float().mean())
+        bc = max(args.blur_count, 0)
+        # Algorithmic bytes: SSAO 6.5 B, each blur sweep 7 B, lighting 52.5 B per full-res pixel; shadow maps, cubemap
+        # and the depth mask are not counted.  Per-launch figures use the pixels this rank's launch covers.
+        frame_bytes = (59 + 14 * bc) * npx
+        frame_gbs = frame_bytes / (dt / args.steps) / 1e9
+        pmc = pmc_profile(args, world)
+
+        def kernel_row(name, ms, bytes_per_px, pmc_key):
+            alg = bytes_per_px * strip_px
+            row = {"kernel": name, "ms": round(ms, 4), "algorithmic_MB": round(alg / 1e6, 1),
+                   "achieved_GBs": round(alg / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
+                   "hbm_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None}
+            c = (pmc or {}).get(pmc_key)
+            if c:
+                row.update({"traffic_MB": round(c["hbm_bytes_per_launch"] / 1e6, 1),
+                            "traffic_over_algorithmic": round(c["hbm_bytes_per_launch"] / alg, 3),
+                            "valu_issue_frac": c.get("valu_issue_frac"), "l2_read_GBs": c.get("l2_read_GBs"),
+                            "bound": c.get("bound")})
+            return row
+
+        kernels = [kernel_row("ssao_kernel", acc["ssao_ms"], 6.5, "ssao"),
+                   kernel_row("blur sweeps x%d" % (2 * bc), acc["blur_ms"], 7.0 * 2 * bc, "blur"),
+                   kernel_row("light_kernel", acc["light_ms"], 52.5, "light")]
+        traffic = None
+        if pmc and all(k in pmc for k in ("ssao", "blur", "light")):
+            traffic = int(sum(pmc[k]["hbm_bytes_per_launch"] for k in ("ssao", "blur", "light")))
         out = {
             "metric": "Mpixels/s for G-buffer->SSAO+blur->deferred PBR lighting at 4K",
             "value": round(npx * args.steps / dt / 1e6, 2),
@@ -439,42 +673,39 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[2]: %dx%d, box+grid scene, %d dir lights, 14-tap SSAO + %d-pass bilateral "
-                                   "blur + cascade PCF (%s radius), 4x%d^2 D24 shadow maps" % (W, H, args.lights, args.blur_count,
-                                                                                             args.pcf, args.shadow_dim),
-                       "sharding": ("%s row strips x%d + RCCL %s of RGBA8 strips" % (args.partition, world, "point-to-point exchange"
-                                    if bounds else "all-gather")) if world > 1 else "single GPU",
-                       "exchange_verified": exchange_ok, "frames_in_flight": nflight,
+                                   "blur + cascade PCF (%s radius), 4x%d^2 D24 shadow maps%s" % (
+                                       W, H, args.lights, args.blur_count, args.pcf, args.shadow_dim,
+                                       "" if args.camera == "reference" else ", camera pitched down (no sky)"),
+                       "launcher": os.environ.get("CRYCHIC_BENCH_LAUNCHER", "external (torch.distributed.run)" if world > 1 else "direct"),
+                       "sharding": ("%s row strips x%d" % (args.partition, world)) if world > 1 else "single GPU",
+                       "exchange": exchange_kind, "exchange_verified": exchange_ok, "frames_in_flight": nflight,
                        "two_frames_in_flight_informational": overlapped,
                        "strip_rows": rows, "strip_plan": [b[1] for b in bounds] if bounds and world > 1 else None,
-                       "launch": "hipGraph replay" if use_graph else "eager",
                        "strip_only": args.strip or None,
                        "point_lights": args.point_lights * args.point_lights,
+                       "covered_pixel_fraction": round(covered, 4),
                        "frame_algorithmic_MB": round(frame_bytes / 1e6, 1),
-                       "frame_hbm_roofline_frac": round(frame_bytes / (dt / args.steps) / 1e9 / HBM_PEAK_GBS * world, 4)
-                       if world == 1 else None,
                        "pass_ms": {k: round(v, 4) for k, v in acc.items()},      # one frame at a time on one stream (latency view)
                        "producer_passes_ms": producer_ms,
                        "full_frame_ms_incl_producers": (round(dt / args.steps * 1e3 + producer_ms["shadow_4x%d" % args.shadow_dim]
                                                               + producer_ms["normals_depth+gbuffer"], 3)
                                                         if producer_ms and world == 1 else None)},
-            "roofline": {"kernel": "light_kernel", "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": pmc_traffic(args, world)},
+            # Frame level per SURVEY.md 8d: algorithmic bytes of the whole frame / measured frame time (N = 1: this GPU's HBM;
+            # N > 1: the aggregate over N GPUs against N x peak).  `traffic`: HBM bytes per frame from the committed PMC passes
+            # (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction), null unless they were taken on exactly these kernel sources.
+            "roofline": {"scope": "frame", "bound": "hbm", "achieved": round(frame_gbs, 1), "peak": HBM_PEAK_GBS * world,
+                         "unit": "GB/s", "frac": round(frame_gbs / (HBM_PEAK_GBS * world), 4), "traffic": traffic,
+                         "kernels": kernels},
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(planes, args, app.pcfSearchRadius)
-        print(json.dumps(out), flush=True)
+            out["cpu_baseline"] = cpu_baseline(planes, args, pcf_radius)
+        print(json.dumps(out), file=result_out, flush=True)
     if use_dist:
-        if args.force_gather and rank == 0:      # self-check of the gather path: the last gathered frame is the rendered one
-            app.mBackBuffer = planes["out"]
-            app.Draw(0, H) if world == 1 else None
-            torch.cuda.synchronize()
-            if world == 1:
-                same = bool(torch.equal(gather.frame(args.steps - 1), planes["out"]))
-                print("bench.py: gathered frame == directly rendered frame: %s" % same, file=sys.stderr, flush=True)
-                if not same:
-                    raise SystemExit(3)
         dist.barrier()
+        if abi:
+            exchange.close()
         dist.destroy_process_group()
+    watchdog.cancel()
 
 
 if __name__ == "__main__":

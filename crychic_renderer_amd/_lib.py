@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(HERE, "libcrychic_hip.so")
 
 MAX_LIGHTS = 16
 LIGHT_SKY = 1
+COMM_ID_BYTES = 128
 
 
 class Light(C.Structure):
@@ -101,6 +102,17 @@ PROTOTYPES = {
     "crychic_ctx_set_profiling": (_i, [_vp, _i]),
     "crychic_ctx_last_pass_times": (_i, [_vp, _P(PassTimes)]),
     "crychic_strip_rows": (_i, [_u32, _i, _i, _P(_u32), _P(_u32)]),
+    "crychic_comm_unique_id": (_i, [_vp]),
+    "crychic_comm_create": (_i, [_vp, _i, _i, _vp, _P(_vp)]),
+    "crychic_comm_create_all": (_i, [_P(_vp), _i, _P(_vp)]),
+    "crychic_comm_destroy": (None, [_vp]),
+    "crychic_comm_abort": (_i, [_vp]),
+    "crychic_comm_rank": (_i, [_vp]),
+    "crychic_comm_size": (_i, [_vp]),
+    "crychic_comm_async_error": (_i, [_vp]),
+    "crychic_allgather_frame": (_i, [_vp, _vp, _u32, _u32, _P(_u32), _vp]),
+    "crychic_allgather_frame_all": (_i, [_P(_vp), _i, _P(_vp), _u32, _u32, _P(_u32), _P(_vp)]),
+    "crychic_comm_barrier": (_i, [_vp, _vp]),
     "crychic_create_box": (_i, [_f, _f, _f, _u32, _vp, _u32, _vp, _u32, _P(_u32)]),
     "crychic_create_grid": (_i, [_f, _f, _u32, _u32, _vp, _u32, _vp, _u32, _P(_u32)]),
     "crychic_load_mesh_text": (_i, [C.c_char_p, _vp, _u32, _vp, _u32, _P(_u32), _P(_u32)]),

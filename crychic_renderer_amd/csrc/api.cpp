@@ -13,11 +13,14 @@
 #include "light_core.hpp"
 #include "ssao_core.hpp"
 #include "raster_core.hpp"
+#include "internal.hpp"
 
 namespace {
-
 thread_local char g_err[512] = "";
+}
 
+namespace cry {
+// shared with comm.cpp (internal.hpp): records the thread-local message behind crychic_last_error()
 int fail(int code, const char* fmt, ...)
 {
     va_list ap;
@@ -26,6 +29,10 @@ int fail(int code, const char* fmt, ...)
     va_end(ap);
     return code;
 }
+}  // namespace cry
+
+namespace {
+using cry::fail;
 
 #define CRY_HIP(expr)                                                                                  \
     do {                                                                                               \
@@ -44,13 +51,6 @@ int check_dims(uint32_t W, uint32_t H)
 
 }  // namespace
 
-struct crychic_ctx {
-    int device;
-    char name[256];
-    bool profiling;
-    bool times_valid;
-    hipEvent_t ev[4];  // start, after ssao, after blur, after light
-};
 
 namespace {
 

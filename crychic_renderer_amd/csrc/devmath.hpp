@@ -1,11 +1,13 @@
 // devmath.hpp -- arithmetic building blocks of the CRYCHIC hot-path kernels (gfx950).
 //
-// Every function is plain IEEE-754 binary32 with a fixed evaluation order; the translation units that
-// include this header are built with -ffp-contract=off so the compiler never fuses a*b+c.  The only fused
-// operations are the explicit fmaf() calls of the UNORM decoders below, which are proven (exhaustively, on
-// the host, tests/test_devmath_host.py) to equal the correctly rounded integer/constant divisions that D3D
-// format conversion specifies.  Transcendentals follow the fixed polynomial recurrences documented in
-// DESIGN.md ("deterministic transcendentals"), so results do not depend on a vendor math library.
+// Every function is IEEE-754 binary32 with a fixed evaluation order (DESIGN.md "Oracle definitions", version 2).  The
+// translation units that include this header are built with -ffp-contract=off: a*b+c is fused exactly where fma() is
+// written -- dot products, matrix rows, lerps and every Horner step -- and nowhere else.  Division is a * rcp(b) with rcp
+// the correctly rounded, flush-to-zero reciprocal; lengths use the correctly rounded square root of an argument clamped
+// to [2^-100, 2^100].  On the device those are v_rcp_f32 / v_sqrt_f32 / v_rsq_f32 plus one correction step each, proven
+// equal to the definitions for EVERY binary32 input by tools/exact_math_probe.hip (tests/test_gpu_exact_math.py runs it);
+// on the host (tests/hostsim) they are the definitions themselves.  Transcendentals follow fixed polynomial recurrences,
+// so results do not depend on a vendor math library.
 #pragma once
 #include <stdint.h>
 
@@ -32,23 +34,85 @@ CRY_HD float u2f(uint32_t u) { float f; __builtin_memcpy(&f, &u, 4); return f; }
 CRY_HD float saturate(float x) { return __builtin_fminf(__builtin_fmaxf(x, 0.0f), 1.0f); }
 CRY_HD float maxnn(float x, float c) { return (x > c) ? x : c; }            // HLSL max(): NaN loses
 CRY_HD float signf(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }
-CRY_HD float lerpf(float a, float b, float t) { return a + t * (b - a); }
-CRY_HD float dot3(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+CRY_HD float fma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+CRY_HD float lerpf(float a, float b, float t) { return fma(t, b - a, a); }
+
+// ---- exact reciprocal / square root ------------------------------------------------------------------------------
+// rcp(b): the correctly rounded 1/b; subnormal b -> +-inf, subnormal results -> +-0 (|b| > 2^126), NaN -> NaN.
+// Device: v_rcp_f32 (1 ulp) + one Newton step is correctly rounded for every normal b with a normal reciprocal; whenever
+// the seed is not a normal number (0, inf, NaN) it already is the defined result.  5 VALU instructions against 11 for the
+// IEEE quotient expansion (v_div_scale x2, v_rcp, 4 fma, mul, v_div_fmas, v_div_fixup).
+CRY_HD float rcp(float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    const float e = fma(-b, r0, 1.0f);
+    const float r1 = fma(e, r0, r0);
+    return __builtin_isnormal(r0) ? r1 : r0;
+#else
+    if (b != b) return b;
+    const float ab = __builtin_fabsf(b);
+    if (ab < 1.17549435e-38f) return __builtin_copysignf(__builtin_inff(), b);
+    if (ab > 8.50705917e37f) return __builtin_copysignf(0.0f, b);
+    return 1.0f / b;
+#endif
+}
+// The same for an argument known to be a normal number with a normal reciprocal (2^-126 <= |b| <= 2^126): no select.
+CRY_HD float rcp_normal(float b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float r0 = __builtin_amdgcn_rcpf(b);
+    return fma(fma(-b, r0, 1.0f), r0, r0);
+#else
+    return 1.0f / b;
+#endif
+}
+CRY_HD float divf(float a, float b) { return a * rcp(b); }     // HLSL a / b
+// Squared length clamped to [2^-100, 2^100] (NaN -> 2^-100: v_med3_f32 returns the minimum when an operand is NaN).
+CRY_HD float clamp_len2(float d)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_fmed3f(d, 7.8886090522101181e-31f, 1.2676506002282294e30f);
+#else
+    return (d != d) ? 7.8886090522101181e-31f : __builtin_fminf(__builtin_fmaxf(d, 7.8886090522101181e-31f), 1.2676506002282294e30f);
+#endif
+}
+// sqrt of an argument in [2^-100, 2^100], correctly rounded: v_sqrt_f32 (1 ulp) + one Markstein correction with
+// h = rsq/2 -- exhaustively equal to IEEE sqrtf on that range (the residual x - g*g would underflow below it).
+CRY_HD float sqrt_clamped(float x)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float g = __builtin_amdgcn_sqrtf(x);
+    const float h = 0.5f * __builtin_amdgcn_rsqf(x);
+    return fma(fma(-g, g, x), h, g);
+#else
+    return __builtin_sqrtf(x);
+#endif
+}
+CRY_HD float len_from_sq(float d2) { return sqrt_clamped(clamp_len2(d2)); }                  // length(v), d2 = dot(v, v)
+CRY_HD float inv_len_from_sq(float d2) { return rcp_normal(sqrt_clamped(clamp_len2(d2))); }  // 1 / length(v)
+
+CRY_HD float dot3(f3 a, f3 b) { return fma(a.z, b.z, fma(a.y, b.y, a.x * b.x)); }
 CRY_HD f3 normalize3(f3 v)
 {
-    float inv = 1.0f / __builtin_sqrtf(dot3(v, v));
+    const float inv = inv_len_from_sq(dot3(v, v));
     return f3{ v.x * inv, v.y * inv, v.z * inv };
 }
 CRY_HD f3 reflect3(f3 i, f3 n)
 {
-    float d2 = 2.0f * dot3(n, i);
-    return f3{ i.x - d2 * n.x, i.y - d2 * n.y, i.z - d2 * n.z };
+    const float d2 = 2.0f * dot3(n, i);
+    return f3{ fma(-d2, n.x, i.x), fma(-d2, n.y, i.y), fma(-d2, n.z, i.z) };
 }
 // HLSL mul(float4(v), M) for a matrix stored transposed (the reference's cbuffer layout): column j of the
 // row-vector matrix is mem[4j .. 4j+3].
 CRY_HD float mulcol(float x, float y, float z, float w, const float* col)
 {
-    return ((x * col[0] + y * col[1]) + z * col[2]) + w * col[3];
+    return fma(w, col[3], fma(z, col[2], fma(y, col[1], x * col[0])));
+}
+// w == 1: mad(1, c3, acc) == acc + c3
+CRY_HD float mulcol1(float x, float y, float z, const float* col)
+{
+    return fma(z, col[2], fma(y, col[1], x * col[0])) + col[3];
 }
 
 // ---- two-wide packed fp32 ---------------------------------------------------------------------------------------

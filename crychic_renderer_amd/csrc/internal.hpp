@@ -1,0 +1,17 @@
+// internal.hpp -- what the translation units behind the C ABI share: the context object and the error recorder.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include "crychic_hip.h"
+
+struct crychic_ctx {
+    int device;
+    char name[256];
+    bool profiling;
+    bool times_valid;
+    hipEvent_t ev[4];  // start, after ssao, after blur, after light
+};
+
+namespace cry {
+// Stores the message crychic_last_error() returns (thread-local) and returns `code`.
+int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+}  // namespace cry

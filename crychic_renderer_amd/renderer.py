@@ -205,9 +205,14 @@ class Crychic:
 
     def Draw(self, row0=0, rows=None):  # CRYCHIC.cpp:172-306 (hot part)
         # The descriptor only changes when a plane is re-allocated or a knob is turned: keep it across frames so the
-        # per-frame host cost is one FFI call (matters once a strip takes tens of microseconds on 8 GPUs).
-        key = (row0, rows, self.mBackBuffer.data_ptr(), self.mSsao.mAmbientMap0.data_ptr(), self.mDepthStencilBuffer.data_ptr(),
-               self.mDeferred.mGBuffer[0].data_ptr(), self.blurCount, self.numDirLights, self.pcfSearchRadius, self.flags,
+        # per-frame host cost is one FFI call (matters once a strip takes tens of microseconds on 8 GPUs).  The key holds
+        # every device pointer and size frame_desc() reads, so replacing any plane object invalidates the cached descriptor.
+        ssao, sm = self.mSsao, self.mShadowMap.mShadowMap
+        key = (row0, rows, self.mBackBuffer.data_ptr(), ssao.mAmbientMap0.data_ptr(), ssao.mAmbientMap1.data_ptr(), ssao.mEdge.data_ptr(),
+               ssao.mNormalMap.data_ptr(), ssao.mRandomVectorMap.data_ptr(), self.mDepthStencilBuffer.data_ptr(),
+               self.mDeferred.mGBuffer[0].data_ptr(), self.mDeferred.mGBuffer[1].data_ptr(), self.mDeferred.mGBuffer[2].data_ptr(),
+               sm.data_ptr(), int(sm.shape[-1]), self.mCubeMap.data_ptr(), int(self.mCubeMap.shape[1]),
+               self.blurCount, self.numDirLights, self.pcfSearchRadius, self.flags,
                0 if self.mPointLights is None else self.mPointLights.data_ptr())
         if self._desc is None:
             self._desc = {}

@@ -174,3 +174,72 @@ class FrameGather:
             rows = strip_rows(self.H, self.nranks, r)[1]
             parts.append(f[r * self.max_rows:r * self.max_rows + rows])
         return torch.cat(parts, dim=0)
+
+
+class StripExchange:
+    """The frame all-gather behind the C ABI (crychic_allgather_frame, csrc/comm.cpp): RCCL over xGMI, enqueued on the
+    stream that rendered the strip, no host wait and no Python collective per frame.
+
+    Every rank renders its strip IN PLACE into one of `slots` full-frame buffers and the exchange fills in the peers'
+    rows; a slot is reused only by work on the same stream, so stream order alone keeps frame i's gather ahead of
+    frame i + slots' lighting pass.  bounds = None: the crychic_strip_rows plan (equal strips, one in-place
+    ncclAllGather); bounds = [(row0, rows)] per rank: any heights (one group of in-place ncclBroadcasts)."""
+
+    def __init__(self, ctx, W, H, nranks, rank, unique_id, bounds=None, slots=4):
+        self.ctx, self.W, self.H, self.nranks, self.rank = ctx, int(W), int(H), int(nranks), int(rank)
+        assert len(unique_id) == _lib_comm_id_bytes()
+        self.bounds = [tuple(int(v) for v in b) for b in bounds] if bounds is not None else None
+        if self.bounds is not None:
+            assert len(self.bounds) == nranks and sum(b[1] for b in self.bounds) == H and self.bounds[0][0] == 0
+            flat = [v for b in self.bounds for v in b]
+            self._bounds_arr = (C.c_uint32 * len(flat))(*flat)
+            self.row0, self.rows = self.bounds[rank]
+        else:
+            self._bounds_arr = None
+            self.row0, self.rows = strip_rows(H, nranks, rank)
+        self.handle = C.c_void_p()
+        idbuf = (C.c_uint8 * len(unique_id)).from_buffer_copy(bytes(unique_id))
+        check(lib.crychic_comm_create(ctx.handle, self.nranks, self.rank, idbuf, C.byref(self.handle)))
+        self.render = [torch.zeros((H, W, 4), dtype=torch.uint8, device=ctx.device) for _ in range(int(slots))]
+
+    @staticmethod
+    def new_unique_id():
+        """Rank 0 calls this and hands the bytes to its peers out of band (ncclGetUniqueId)."""
+        buf = (C.c_uint8 * _lib_comm_id_bytes())()
+        check(lib.crychic_comm_unique_id(buf))
+        return bytes(buf)
+
+    def strip_buffer(self, i):
+        return self.render[i % len(self.render)]
+
+    def launch(self, i, stream=None):
+        """Enqueue the exchange of frame i's buffer on `stream` (default: torch's current stream)."""
+        s = torch.cuda.current_stream(self.ctx.device) if stream is None else stream
+        check(lib.crychic_allgather_frame(self.handle, C.c_void_p(self.render[i % len(self.render)].data_ptr()), self.W, self.H,
+                                          self._bounds_arr, C.c_void_p(s.cuda_stream)))
+
+    def barrier(self, stream=None):
+        """Stream-ordered rendezvous of all ranks (one-word all-reduce); the caller synchronises the stream."""
+        s = torch.cuda.current_stream(self.ctx.device) if stream is None else stream
+        check(lib.crychic_comm_barrier(self.handle, C.c_void_p(s.cuda_stream)))
+
+    def wait_all(self):
+        torch.cuda.synchronize(self.ctx.device)
+        check(lib.crychic_comm_async_error(self.handle))
+
+    def frame(self, i):
+        return self.render[i % len(self.render)]
+
+    def abort(self):
+        if self.handle:
+            lib.crychic_comm_abort(self.handle)
+
+    def close(self):
+        if self.handle:
+            lib.crychic_comm_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+def _lib_comm_id_bytes():
+    from ._lib import COMM_ID_BYTES
+    return COMM_ID_BYTES

@@ -137,6 +137,7 @@ public:
     ~CRYCHIC()
     {
         if (mCommandList) { try { mCommandList->Flush(); } catch (...) {} }
+        if (mComm) crychic_comm_destroy(mComm);
         for (auto& fr : mFrameResources) if (fr && fr->FenceEvent) (void)hipEventDestroy(fr->FenceEvent);
     }
 
@@ -201,7 +202,7 @@ public:
         f.numDirLights = mNumDirLights;
         f.pcfSearchRadius = crychic_pcf_search_radius(mShadowMap->Width(), mPcfLiteral ? 1 : 0);
         f.flags = mSkyEnabled ? CRYCHIC_LIGHT_SKY : 0u;                                             // :278-279
-        f.row0 = 0; f.rows = mClientHeight;
+        f.row0 = mStripRow0; f.rows = mStripRows ? mStripRows : mClientHeight - mStripRow0;           // whole frame unless SetStrip / JoinNode
         f.normal_dev = mSsao->NormalMap()->Data();
         f.depth_dev = static_cast<const uint32_t*>(mDepthStencilBuffer->Data());
         f.randvec_dev = static_cast<const uint8_t*>(mSsao->RandomVectorMap()->Data());
@@ -221,9 +222,36 @@ public:
         const PassConstants& pcb = mCurrFrameResource->PassCB->Element(0);
         CrychicThrowIfFailed(crychic_draw_hot_path(md3dDevice->Ctx(), reinterpret_cast<const crychic_ssao_constants*>(&scb),
                                                    reinterpret_cast<const crychic_pass_constants*>(&pcb), &f, mCommandList->Stream()));
+        // Several GPUs, one frame: the peers' strips arrive in place behind this strip's lighting pass (RCCL over xGMI), so the
+        // back buffer that Present sees is complete on every GPU.  The reference has one GPU (NodeMask 0, CRYCHIC.cpp:96,105).
+        if (mComm)
+            CrychicThrowIfFailed(crychic_allgather_frame(mComm, static_cast<uint8_t*>(mBackBuffer->Data()), mClientWidth, mClientHeight,
+                                                         mStripBounds.empty() ? nullptr : mStripBounds.data(), mCommandList->Stream()));
         // :300-305: advance the fence and signal it behind this frame's commands
         mCurrFrameResource->Fence = ++mCurrentFence;
         CrychicHipThrowIfFailed(hipEventRecord(mCurrFrameResource->FenceEvent, mCommandList->Stream()));
+    }
+
+    // ---- one frame on several GPUs (no counterpart in the single-GPU reference) ----------------------------------
+    // Rows [row0, row0 + rows) are this GPU's share of the hot path (row0 even); rows == 0 means "to the bottom".
+    void SetStrip(UINT row0, UINT rows) { mStripRow0 = row0; mStripRows = rows; }
+    // One process per GPU: `id` is the rendezvous id rank 0 obtained from crychic_comm_unique_id and handed to its peers.
+    // Takes the crychic_strip_rows plan unless `bounds` (nranks x {row0, rows}) gives another tiling.
+    void JoinNode(int nranks, int rank, const uint8_t id[CRYCHIC_COMM_ID_BYTES], const std::vector<uint32_t>& bounds = {})
+    {
+        LeaveNode();
+        CrychicThrowIfFailed(crychic_comm_create(md3dDevice->Ctx(), nranks, rank, id, &mComm));
+        mStripBounds = bounds;
+        uint32_t r0 = 0, rn = 0;
+        if (bounds.empty()) CrychicThrowIfFailed(crychic_strip_rows(mClientHeight, nranks, rank, &r0, &rn));
+        else { r0 = bounds.at(2 * (size_t)rank); rn = bounds.at(2 * (size_t)rank + 1); }
+        SetStrip(r0, rn);
+    }
+    void LeaveNode()
+    {
+        if (mComm) { mCommandList->Flush(); crychic_comm_destroy(mComm); mComm = nullptr; }
+        mStripBounds.clear();
+        SetStrip(0, 0);
     }
 
     // mSwapChain->Present (CRYCHIC.cpp:294-297) for a headless build: read the back buffer back and write it as PPM.
@@ -541,6 +569,9 @@ private:
     std::vector<std::unique_ptr<FrameResource>> mFrameResources;
     int mCurrFrameResourceIndex = 0;
     UINT64 mCurrentFence = 0;
+    crychic_comm* mComm = nullptr;            // set by JoinNode: this GPU renders a strip and gathers the others'
+    std::vector<uint32_t> mStripBounds;       // nranks x {row0, rows}; empty = crychic_strip_rows
+    UINT mStripRow0 = 0, mStripRows = 0;      // 0, 0 = the whole frame
     std::unique_ptr<ID3D12Resource> mDepthStencilBuffer, mBackBuffer, mCubeMap;
     UINT mCubeMapSize = 0;
     UINT mClientWidth, mClientHeight;

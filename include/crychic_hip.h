@@ -338,6 +338,42 @@ int crychic_draw_normals_depth_and_gbuffer(crychic_ctx* ctx, const crychic_pass_
  * of 2 rows (half-res alignment); the last rank takes the remainder. */
 int crychic_strip_rows(uint32_t H, int nranks, int rank, uint32_t* row0, uint32_t* rows);
 
+/* ---- multi-GPU exchange (SURVEY.md 8b `crychic_allgather_frame`, 8e): RCCL over xGMI ----------------------------- */
+/* The reference is single-GPU (NodeMask 0, CRYCHIC.cpp:96,105); these entry points complete the back buffer that
+ * CRYCHIC::Draw presents (CRYCHIC.cpp:282-297) when N GPUs each render a row strip of it.  One communicator per GPU.
+ * Every rank renders its strip IN PLACE into a full W x H RGBA8 frame buffer; the exchange fills in the peers' strips,
+ * stream-ordered behind the strip's lighting pass, with no host synchronisation.  Any RCCL failure returns
+ * CRYCHIC_E_COMM (crychic_last_error() carries RCCL's own message). */
+typedef struct crychic_comm crychic_comm;
+#define CRYCHIC_COMM_ID_BYTES 128
+
+/* One process per GPU: rank 0 obtains a rendezvous id (ncclGetUniqueId), hands it to its peers out of band (file, socket,
+ * key-value store), then every rank calls crychic_comm_create (ncclCommInitRank: blocks until all nranks have joined). */
+int crychic_comm_unique_id(uint8_t id[CRYCHIC_COMM_ID_BYTES]);
+int crychic_comm_create(crychic_ctx* ctx, int nranks, int rank, const uint8_t id[CRYCHIC_COMM_ID_BYTES], crychic_comm** out);
+/* One process driving all GPUs (the reference's own shape: one WinMain, one thread): communicators for ctxs[0..nranks),
+ * rank k on ctxs[k]'s device (ncclCommInitAll). */
+int crychic_comm_create_all(crychic_ctx* const* ctxs, int nranks, crychic_comm** out);
+void crychic_comm_destroy(crychic_comm* comm);
+/* Tears the communicator down without waiting for outstanding operations (ncclCommAbort): the way out of an exchange a
+ * peer never joined.  The handle stays valid only for crychic_comm_destroy. */
+int crychic_comm_abort(crychic_comm* comm);
+int crychic_comm_rank(const crychic_comm* comm);
+int crychic_comm_size(const crychic_comm* comm);
+/* 0 while no asynchronous RCCL error is pending on the communicator, else CRYCHIC_E_COMM. */
+int crychic_comm_async_error(crychic_comm* comm);
+
+/* All-gather of the composed strips.  bounds = NULL: the crychic_strip_rows plan; otherwise nranks x (row0, rows) pairs that
+ * tile the frame in rank order (any heights: cost-balanced strips).  Equal strips run as one in-place ncclAllGather, ragged
+ * ones as one group of in-place ncclBroadcasts (one per strip).  Must be called by every rank, in the same order. */
+int crychic_allgather_frame(crychic_comm* comm, uint8_t* frame_rgba8_dev, uint32_t W, uint32_t H, const uint32_t* bounds,
+                            void* stream);
+/* The same for a single host thread that owns every rank: frames_rgba8_dev[k] / streams[k] belong to comms[k]. */
+int crychic_allgather_frame_all(crychic_comm* const* comms, int nranks, uint8_t* const* frames_rgba8_dev, uint32_t W, uint32_t H,
+                                const uint32_t* bounds, void* const* streams);
+/* Stream-ordered rendezvous of all ranks (a one-word ncclAllReduce): brackets timed regions; no host wait inside. */
+int crychic_comm_barrier(crychic_comm* comm, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -12,7 +12,7 @@
 /* Common.hlsl:167-171.  `noise` is a scalar broadcast to float2, so abs(noise.x + noise.y) * 0.5 == noise. */
 static inline float nrand(float u, float v)
 {
-    float d = u * (12.9898f * 2.0f) + v * (78.233f * 2.0f);
+    float d = fmaf(v, 78.233f * 2.0f, u * (12.9898f * 2.0f));
     float noise = or_frac(or_det_sinf_(d) * 43758.5453f);
     return fabsf(noise + noise) * 0.5f;
 }
@@ -34,26 +34,26 @@ float or_pcf_search_radius(uint32_t width, int literal)
 {
     /* Common.hlsl:305 `float search_radius = 5 / width / 2.0f;` with `uint width`: 5 / width is an
      * unsigned integer division (quirk Q2). */
-    if (literal) return (float)(5u / width) / 2.0f;
-    return 5.0f / (float)width / 2.0f;
+    if (literal) return (float)(5u / width) * 0.5f;
+    return or_div(5.0f, (float)width) * 0.5f;
 }
 
 /* Common.hlsl:263-317 */
 static float pcf_poisson(const uint32_t* shadow, uint32_t dim, const float sp[4], float search_radius)
 {
-    float x = sp[0] / sp[3], y = sp[1] / sp[3], depth = sp[2] / sp[3];  /* :266-269 */
+    float rw = or_rcp(sp[3]);
+    float x = sp[0] * rw, y = sp[1] * rw, depth = sp[2] * rw;           /* :266-269 */
     float theta = nrand(x, y);                                          /* :301 */
     float cos_theta = or_det_cosf_(theta);
     float sin_theta = or_det_sinf_(theta);
     float percentLit = 0.0f;
     for (int i = 0; i < 16; ++i) {                                      /* N_SAMPLE :21, :308 */
         /* mul(poissonDisk[i], float2x2(c, s, -s, c))  :304,310 */
-        float px = poissonDisk[i][0] * cos_theta + poissonDisk[i][1] * (-sin_theta);
-        float py = poissonDisk[i][0] * sin_theta + poissonDisk[i][1] * cos_theta;
-        float ox = px * search_radius, oy = py * search_radius;        /* :311 */
-        percentLit += or_shadow_cmp_linear(shadow, dim, x + ox, y + oy, depth); /* :312-313 */
+        float px = fmaf(poissonDisk[i][1], -sin_theta, poissonDisk[i][0] * cos_theta);
+        float py = fmaf(poissonDisk[i][1], cos_theta, poissonDisk[i][0] * sin_theta);
+        percentLit += or_shadow_cmp_linear(shadow, dim, fmaf(px, search_radius, x), fmaf(py, search_radius, y), depth); /* :311-313 */
     }
-    return percentLit / 16.0f;                                          /* :315 */
+    return percentLit * 0.0625f;                                        /* :315 (/ 16 is exact) */
 }
 float or_pcf_poisson(const uint32_t* shadow, uint32_t dim, const float shadowPosH[4], float searchRadius)
 {
@@ -72,13 +72,13 @@ static inline float ndf_ggx(const float n[3], const float h[3], float a)
     float a2 = a * a;
     float nDoth = or_max0(or_dot3(n, h), 0.001f);
     float nDoth2 = nDoth * nDoth;
-    float t = nDoth2 * (a2 - 1.0f) + 1.0f;
+    float t = fmaf(nDoth2, a2 - 1.0f, 1.0f);
     float tmp = t * t;                      /* pow(x, 2) */
     float bottom = OR_PI * tmp;
-    return a2 * (1.0f / bottom);            /* top * rcp(bottom) */
+    return a2 * or_rcp(bottom);             /* top * rcp(bottom) */
 }
 /* PBR.hlsl:16-21 */
-static inline float geometry_schlick_ggx(float nDotvec, float k) { return nDotvec / (nDotvec * (1.0f - k) + k); }
+static inline float geometry_schlick_ggx(float nDotvec, float k) { return or_div(nDotvec, fmaf(nDotvec, 1.0f - k, k)); }
 
 /* One directional light: PBR.hlsl:72-88 (GetPBRDesc), :45-70 (GetBRDF), :99-106 (PBRShading loop body). */
 static void pbr_light(const float lightDir[3], const float strength[3], const float albedo[3], float roughness, float metalness,
@@ -96,17 +96,18 @@ static void pbr_light(const float lightDir[3], const float strength[3], const fl
     float k = 0.125f * (roughness + 1.0f) * (roughness + 1.0f);
     float G = geometry_schlick_ggx(nDotv, k) * geometry_schlick_ggx(nDotl, k); /* true nDotv :29-38 */
     float s5 = shadowTerm;
+    float rdenom = or_rcp(nDotl * nDotvQ);    /* PBR.hlsl:66 `/ (nDotl * nDotv)`, the same quotient for every channel */
     for (int c = 0; c < 3; ++c) {
         float f0 = or_lerp(0.04f, albedo[c], metalness);
-        float F = f0 + (1.0f - f0) * fr;
+        float F = fmaf(1.0f - f0, fr, f0);
         float fs = 0.25f * D * G * F;
-        fs = fs / (nDotl * nDotvQ);
+        fs = fs * rdenom;
         float fd = albedo[c] * (1.0f / OR_PI);
         float ks = F;                         /* quirk Q4: F applied twice */
         float kd = (1.0f - F) * (1.0f - metalness);
-        float brdf = kd * fd + ks * fs;
+        float brdf = fmaf(ks, fs, kd * fd);
         float irradiance = strength[c] * nDotl;
-        result[c] += s5 * brdf * irradiance;
+        result[c] = fmaf(s5 * brdf, irradiance, result[c]);
     }
 }
 
@@ -125,10 +126,11 @@ static void pbr_point_light(const or_light* L, const float pos[3], const float a
                             const float normal[3], const float view[3], float result[3])
 {
     float l[3] = { L->Position[0] - pos[0], L->Position[1] - pos[1], L->Position[2] - pos[2] };
-    float d = sqrtf(or_dot3(l, l));
+    float d = or_len(or_dot3(l, l));
     if (d > L->FalloffEnd) return;
-    float ln[3] = { l[0] / d, l[1] / d, l[2] / d };
-    float att = or_saturate((L->FalloffEnd - d) / (L->FalloffEnd - L->FalloffStart));   /* CalcAttenuation, LightingUtil.hlsl:44-48 */
+    float rd = or_rcp(d);
+    float ln[3] = { l[0] * rd, l[1] * rd, l[2] * rd };
+    float att = or_saturate(or_div(L->FalloffEnd - d, L->FalloffEnd - L->FalloffStart));   /* CalcAttenuation, LightingUtil.hlsl:44-48 */
     /* GetPBRDesc / GetBRDF exactly as for a directional light (PBR.hlsl:72-88, 45-70), with l as the light direction */
     float vl[3] = { view[0] + ln[0], view[1] + ln[1], view[2] + ln[2] }, halfVec[3];
     or_normalize3(vl, halfVec);
@@ -140,17 +142,18 @@ static void pbr_point_light(const or_light* L, const float pos[3], const float a
     float fr = pow5(or_saturate(1.0f - nDotvQ));
     float k = 0.125f * (roughness + 1.0f) * (roughness + 1.0f);
     float G = geometry_schlick_ggx(nDotv, k) * geometry_schlick_ggx(nDotl, k);
+    float rdenom = or_rcp(nDotl * nDotvQ);
     for (int c = 0; c < 3; ++c) {
         float f0 = or_lerp(0.04f, albedo[c], metalness);
-        float F = f0 + (1.0f - f0) * fr;
+        float F = fmaf(1.0f - f0, fr, f0);
         float fs = 0.25f * D * G * F;
-        fs = fs / (nDotl * nDotvQ);
+        fs = fs * rdenom;
         float fd = albedo[c] * (1.0f / OR_PI);
         float kd = (1.0f - F) * (1.0f - metalness);
-        float brdf = kd * fd + F * fs;
+        float brdf = fmaf(F, fs, kd * fd);
         float lightStrength = L->Strength[c] * nDotl;      /* PBR.hlsl:118 */
         lightStrength = lightStrength * att;               /* :120 */
-        result[c] += 1.0f * brdf * lightStrength;          /* :122 with shadowFactor[i] = 1 */
+        result[c] = fmaf(1.0f * brdf, lightStrength, result[c]);   /* :122 with shadowFactor[i] = 1 */
     }
 }
 
@@ -184,7 +187,8 @@ static void light_pixel(const or_pass_constants* cb, const float* g0, const floa
     if (ambient) {
         float sp[4];
         or_mul_v4_m(pos4, cb->ViewProjTex, sp);       /* :40 */
-        ambientAccess = or_ambient_linear_clamp(ambient, W / 2, H / 2, sp[0] / sp[3], sp[1] / sp[3]); /* :41-42 */
+        float rw = or_rcp(sp[3]);
+        ambientAccess = or_ambient_linear_clamp(ambient, W / 2, H / 2, sp[0] * rw, sp[1] * rw); /* :41-42 */
     }
     float amb[4];
     for (int c = 0; c < 3; ++c) amb[c] = ambientAccess * cb->AmbientLight[c] * albedo[c]; /* :44 */
@@ -194,7 +198,7 @@ static void light_pixel(const or_pass_constants* cb, const float* g0, const floa
     for (int i = 0; i < OR_MAX_LIGHTS; ++i) shadowFactors[i] = 1.0f;  /* :46-51 */
 
     static const float radius[4] = { 30.0f, 50.0f, 80.0f, 100.0f };  /* :53 */
-    float distance = sqrtf(or_dot3(toEye, toEye));                    /* :57 length(gEyePosW - posW) */
+    float distance = or_len(or_dot3(toEye, toEye));                   /* :57 length(gEyePosW - posW) */
     for (int j = 0; j < 4; ++j) {
         /* :60 `abs(distance - radius[j] < 5.0f)` is abs() of a bool (quirk Q1): it is 1 whenever
          * distance < radius[j], so the blend branch is taken for every j < 3. */
@@ -223,7 +227,7 @@ static void light_pixel(const or_pass_constants* cb, const float* g0, const floa
     for (uint32_t i = 0; i < numPointLights; ++i)                     /* extension: NUM_POINT_LIGHTS lights from a separate buffer */
         pbr_point_light(&pointLights[i], posW, albedo, roughness, metalness, normalW, view, direct);
     for (int c = 0; c < 3; ++c) {
-        float d = direct[c] / (direct[c] + 1.0f);                     /* :89 */
+        float d = or_div(direct[c], direct[c] + 1.0f);                /* :89 */
         d = or_det_powf_(d, 1.0f / 2.2f);                             /* :90 */
         lit[c] = d + amb[c];                                          /* :92 */
     }
@@ -237,8 +241,8 @@ static void light_pixel(const or_pass_constants* cb, const float* g0, const floa
     float f0 = 1.0f - cosI;
     float f5 = f0 * f0 * f0 * f0 * f0;                                /* :57 */
     for (int c = 0; c < 3; ++c) {
-        float fresnel = fresnelR0[c] + (1.0f - fresnelR0[c]) * f5;
-        lit[c] += shininess * fresnel * refl[c];                      /* DeferredShading.hlsl:97 */
+        float fresnel = fmaf(1.0f - fresnelR0[c], f5, fresnelR0[c]);
+        lit[c] = fmaf(shininess * fresnel, refl[c], lit[c]);          /* DeferredShading.hlsl:97 */
     }
     lit[3] = 1.0f;                                                    /* :99 */
 }
@@ -249,10 +253,11 @@ static void light_pixel(const or_pass_constants* cb, const float* g0, const floa
 static void sky_pixel(const or_pass_constants* cb, const uint8_t* cube, uint32_t cubeDim, uint32_t W, uint32_t H,
                       uint32_t x, uint32_t y, float out[4])
 {
-    float u = ((float)x + 0.5f) / (float)W, v = ((float)y + 0.5f) / (float)H;
-    float posh[4] = { 2.0f * u - 1.0f, 1.0f - 2.0f * v, 0.0f, 1.0f }, ph[4];
+    float u = or_div((float)x + 0.5f, (float)W), v = or_div((float)y + 0.5f, (float)H);
+    float posh[4] = { fmaf(2.0f, u, -1.0f), fmaf(-2.0f, v, 1.0f), 0.0f, 1.0f }, ph[4];
     or_mul_v4_m(posh, cb->InvProj, ph);
-    float pv[4] = { ph[0] / ph[3], ph[1] / ph[3], ph[2] / ph[3], 0.0f }, dw[4];
+    float rw = or_rcp(ph[3]);
+    float pv[4] = { ph[0] * rw, ph[1] * rw, ph[2] * rw, 0.0f }, dw[4];
     or_mul_v4_m(pv, cb->InvView, dw);
     cube4(cube, cubeDim, dw, out);
 }

@@ -1,9 +1,21 @@
 /*
- * or_math.h -- oracle arithmetic definitions (TEST INFRASTRUCTURE, see crychic_oracle.h).
+ * or_math.h -- oracle arithmetic definitions, version 2 (TEST INFRASTRUCTURE, see crychic_oracle.h).
  *
- * Everything here is IEEE-754 binary32 with one fixed evaluation order and no fused multiply-add
- * (build with -ffp-contract=off).  These are the oracle's DEFINITIONS of the HLSL intrinsics whose
- * precision D3D leaves open; DESIGN.md "Oracle definitions" lists them.
+ * Everything here is IEEE-754 binary32 with one fixed evaluation order.  HLSL leaves the precision of mul / dot / lerp /
+ * mad contraction, `/`, rcp, rsqrt, sqrt, pow, sin and cos open (D3D11.3 functional spec: 1 ULP class operations, fused or
+ * unfused mad at the compiler's choice; fxc emits mad and rcp-multiply freely), so the oracle DEFINES one evaluation:
+ *
+ *   - a*b+c chains are FUSED exactly where written: fmaf() below, nowhere else (build with -ffp-contract=off);
+ *   - a / b      := a * or_rcp(b); or_rcp is the correctly rounded reciprocal with flush-to-zero on subnormal
+ *                   inputs and results (what `v_rcp_f32` + one Newton step yields on gfx950 for EVERY binary32 input:
+ *                   tools/exact_math_probe.hip, tests/test_gpu_exact_math.py);
+ *   - length(v)  := sqrtf(clamp(dot(v,v), 2^-100, 2^100)), normalize(v) := v * (1 / length): IEEE sqrt and division on
+ *                   an argument clamped to a range where neither can meet a subnormal (NaN -> 2^-100);
+ *   - pow(x, y)  := the fixed exp2(y * log2(x)) kernels below; sin / cos: fixed Cody-Waite + polynomial kernels.
+ *
+ * Version 1 (round 1) used unfused chains and IEEE division everywhere; version 2 exists because those choices cost the
+ * GPU kernels ~40 % of their instruction issue without being any closer to what a D3D12 driver computes.  DESIGN.md
+ * "Oracle definitions" lists every definition.
  */
 #ifndef OR_MATH_H
 #define OR_MATH_H
@@ -23,28 +35,49 @@ static inline float or_max0(float x, float c) { return (x > c) ? x : c; }
 static inline float or_sign(float x) { return (float)((x > 0.0f) - (x < 0.0f)); }
 /* HLSL frac(x) = x - floor(x). */
 static inline float or_frac(float x) { return x - floorf(x); }
-/* HLSL lerp(a,b,t) = a + t*(b-a). */
-static inline float or_lerp(float a, float b, float t) { return a + t * (b - a); }
+/* HLSL lerp(a,b,t) = a + t*(b-a), as one mad. */
+static inline float or_lerp(float a, float b, float t) { return fmaf(t, b - a, a); }
 
-static inline float or_dot3(const float a[3], const float b[3]) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
-/* HLSL normalize(v) = v * rsqrt(dot(v,v)); defined here as v * (1 / sqrt(dot)). */
+/* Reciprocal: correctly rounded 1/b with subnormal inputs and results flushed (to +-inf / +-0).  |b| > 2^126 is exactly
+ * the set of normal b whose reciprocal is subnormal. */
+static inline float or_rcp(float b)
+{
+    if (b != b) return b;
+    float ab = fabsf(b);
+    if (ab < 1.17549435e-38f) return copysignf(INFINITY, b);
+    if (ab > 8.50705917e37f) return copysignf(0.0f, b);
+    return 1.0f / b;
+}
+/* HLSL a / b. */
+static inline float or_div(float a, float b) { return a * or_rcp(b); }
+/* Squared length -> length / inverse length on the clamped argument (NaN -> the lower bound). */
+static inline float or_clamp_len2(float d) { return (d != d) ? 7.8886090522101181e-31f : fminf(fmaxf(d, 7.8886090522101181e-31f), 1.2676506002282294e30f); }
+static inline float or_len(float d2) { return sqrtf(or_clamp_len2(d2)); }
+static inline float or_inv_len(float d2) { return 1.0f / sqrtf(or_clamp_len2(d2)); }
+
+/* HLSL dot(a, b): x first, then two mads. */
+static inline float or_dot3(const float a[3], const float b[3]) { return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])); }
+/* HLSL normalize(v) = v * rsqrt(dot(v,v)). */
 static inline void or_normalize3(const float v[3], float out[3])
 {
-    float inv = 1.0f / sqrtf(or_dot3(v, v));
+    float inv = or_inv_len(or_dot3(v, v));
     out[0] = v[0] * inv; out[1] = v[1] * inv; out[2] = v[2] * inv;
 }
 /* HLSL reflect(i, n) = i - 2*dot(n,i)*n  (n need not be unit: Ssao.hlsl:148 passes an un-normalised randVec). */
 static inline void or_reflect3(const float i[3], const float n[3], float out[3])
 {
     float d2 = 2.0f * or_dot3(n, i);
-    out[0] = i[0] - d2 * n[0]; out[1] = i[1] - d2 * n[1]; out[2] = i[2] - d2 * n[2];
+    out[0] = fmaf(-d2, n[0], i[0]); out[1] = fmaf(-d2, n[1], i[1]); out[2] = fmaf(-d2, n[2], i[2]);
 }
 /* HLSL mul(float4 v, float4x4 M) with M stored transposed in memory: out[j] = sum_i v[i]*mem[4j+i],
- * summed left to right. */
+ * x first, then three mads. */
+static inline float or_mul_v4_col(const float v[4], const float col[4])
+{
+    return fmaf(v[3], col[3], fmaf(v[2], col[2], fmaf(v[1], col[1], v[0] * col[0])));
+}
 static inline void or_mul_v4_m(const float v[4], const float mem[16], float out[4])
 {
-    for (int j = 0; j < 4; ++j)
-        out[j] = ((v[0] * mem[4 * j + 0] + v[1] * mem[4 * j + 1]) + v[2] * mem[4 * j + 2]) + v[3] * mem[4 * j + 3];
+    for (int j = 0; j < 4; ++j) out[j] = or_mul_v4_col(v, mem + 4 * j);
 }
 
 /* IEEE half -> float (exact). */
@@ -65,78 +98,69 @@ static inline float or_half_bits_to_float(uint16_t h)
 
 /* ---- deterministic transcendentals ("detmath") ------------------------------------------------
  * HLSL sin/cos/pow/exp2/log2 are hardware approximations with no pinned bits, so the oracle fixes
- * one polynomial evaluation (Cephes single-precision kernels, Horner form, no FMA).  The HIP
- * kernels implement the same recurrences and must agree bit for bit.                            */
+ * one polynomial evaluation (Horner form, every step one mad).  The HIP kernels implement the same
+ * recurrences and must agree bit for bit.                                                         */
 
 static inline float or_det_sincos_core(float x, int want_cos)
 {
     if (!(fabsf(x) < 8388608.0f)) return x - x; /* inf, NaN -> NaN; huge finite -> 0 */
     float k = nearbyintf(x * 0.636619772367581343f); /* round-half-even of x*2/pi */
-    float r = x - k * 1.5703125f;
-    r = r - k * 4.837512969970703125e-4f;
-    r = r - k * 7.54978995489188216e-8f;
+    float r = fmaf(-k, 1.5703125f, x);               /* three-term Cody-Waite reduction by pi/2 */
+    r = fmaf(-k, 4.837512969970703125e-4f, r);
+    r = fmaf(-k, 7.54978995489188216e-8f, r);
     int q = ((int)k + want_cos) & 3;
     float r2 = r * r;
-    float s = ((-1.9515295891e-4f * r2 + 8.3321608736e-3f) * r2 - 1.6666654611e-1f) * r2 * r + r;
-    float c = ((2.443315711809948e-5f * r2 - 1.388731625493765e-3f) * r2 + 4.166664568298827e-2f) * r2 * r2
-              - 0.5f * r2 + 1.0f;
+    float sp = fmaf(fmaf(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f);
+    float s = fmaf(sp * r2, r, r);
+    float cp = fmaf(fmaf(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f);
+    float c = fmaf(cp * r2, r2, fmaf(-0.5f, r2, 1.0f));
     float v = (q & 1) ? c : s;
     return (q & 2) ? -v : v;
 }
 static inline float or_det_sinf_(float x) { return or_det_sincos_core(x, 0); }
 static inline float or_det_cosf_(float x) { return or_det_sincos_core(x, 1); }
 
+/* log2 of a NORMAL positive x: x = m * 2^e with m in [sqrt(1/2), sqrt(2)); log2(m) = s * P(s^2), s = (m-1)/(m+1)
+ * (2/ln2 * atanh(s), minimax on |s| <= 0.1716: 7e-10 relative). */
+static inline float or_det_log2_normal(float x)
+{
+    uint32_t ue = or_float_to_bits(x) - 0x3F3504F3u;
+    float ef = (float)((int32_t)ue >> 23);
+    float m = or_bits_to_float((ue & 0x007FFFFFu) + 0x3F3504F3u);
+    float s = (m - 1.0f) * (1.0f / (m + 1.0f));     /* m + 1 in [1.7, 2.42]: IEEE reciprocal == or_rcp */
+    float s2 = s * s;
+    float p = fmaf(fmaf(fmaf(0.43174004554748535f, s2, 0.5767142176628113f), s2, 0.9617988467216492f), s2, 2.885390043258667f);
+    return fmaf(s, p, ef);
+}
+/* 2^z for z in [-125, 127]: z = n + f, f in [-1/2, 1/2], degree-6 minimax (2e-9 relative), exact scaling. */
+static inline float or_det_exp2_clamped(float z)
+{
+    float n = nearbyintf(z);
+    float f = z - n;
+    float p = fmaf(fmaf(fmaf(fmaf(fmaf(fmaf(0.00015406982856802642f, f, 0.0013400138122960925f), f, 0.009618260897696018f), f,
+                                  0.05550328269600868f), f, 0.24022649228572845f), f, 0.6931471824645996f), f, 1.0f);
+    return ldexpf(p, (int)n);
+}
 static inline float or_det_log2f_(float x)
 {
-    if (x != x) return x;
-    if (x < 0.0f) return or_bits_to_float(0x7FC00000u);
-    if (x == 0.0f) return -INFINITY;
-    if (x == INFINITY) return x;
-    uint32_t u = or_float_to_bits(x);
-    int e = (int)(u >> 23) - 126; /* x = m * 2^e, m in [0.5, 1) */
-    if ((u >> 23) == 0) {         /* subnormal: scale by 2^24 first */
-        x = x * 16777216.0f;
-        u = or_float_to_bits(x);
-        e = (int)(u >> 23) - 126 - 24;
-    }
-    float m = or_bits_to_float((u & 0x007FFFFFu) | 0x3F000000u);
-    if (m < 0.70710678118654752440f) { e -= 1; m = m + m - 1.0f; }
-    else { m = m - 1.0f; }
-    float z = m * m;
-    float y = ((((((((7.0376836292e-2f * m - 1.1514610310e-1f) * m + 1.1676998740e-1f) * m - 1.2420140846e-1f) * m
-                  + 1.4249322787e-1f) * m - 1.6668057665e-1f) * m + 2.0000714765e-1f) * m - 2.4999993993e-1f) * m
-               + 3.3333331174e-1f) * m * z;
-    y = y - 0.5f * z;
-    /* log2(1+m) = (m + y) * log2(e), split as Cephes does */
-    float r = y * 0.44269504088896340735992f;
-    r = r + m * 0.44269504088896340735992f;
-    r = r + y;
-    r = r + m;
-    r = r + (float)e;
-    return r;
+    if (!(x >= 1.17549435e-38f)) return (x >= 0.0f) ? -INFINITY : or_bits_to_float(0x7FC00000u);   /* zero / subnormal; negative, NaN */
+    return or_det_log2_normal(x);
 }
-
 static inline float or_det_exp2f_(float x)
 {
     if (x != x) return x;
-    if (x >= 128.0f) return INFINITY;
-    if (x < -126.0f) return 0.0f;
-    float n = floorf(x + 0.5f);
-    float f = x - n; /* [-0.5, 0.5] */
-    float p = (((((1.535336188319500e-4f * f + 1.339887440266574e-3f) * f + 9.618437357674640e-3f) * f
-                 + 5.550332471162809e-2f) * f + 2.402264791363012e-1f) * f + 6.931472028550421e-1f) * f + 1.0f;
-    int ni = (int)n; /* [-126, 128] */
-    if (ni > 127) { p = p * 2.0f; ni = 127; }
-    return p * or_bits_to_float((uint32_t)(ni + 127) << 23);
+    return or_det_exp2_clamped(fminf(fmaxf(x, -125.0f), 127.0f));
 }
 
-/* HLSL pow(x, y) = exp2(y * log2(x)) for x > 0; pow(0, y>0) = 0; negative or NaN base -> NaN. */
+/* HLSL pow(x, y) = exp2(y * log2(x)) for the exponents the path uses (0 < y <= 1): x below the smallest normal
+ * (zero, subnormal) -> 0; negative or NaN base -> NaN; y * log2(x) is clamped to [-125, 127] (unreachable for y <= 1
+ * except x = +inf, which therefore evaluates to 2^127). */
 static inline float or_det_powf_(float x, float y)
 {
-    if (x != x) return x;
-    if (x < 0.0f) return or_bits_to_float(0x7FC00000u);
-    if (x == 0.0f) return 0.0f;
-    return or_det_exp2f_(y * or_det_log2f_(x));
+    if (!(x >= 0.0f)) return or_bits_to_float(0x7FC00000u);
+    if (!(x >= 1.17549435e-38f)) return 0.0f;
+    float z = y * or_det_log2_normal(x);
+    return or_det_exp2_clamped(fminf(fmaxf(z, -125.0f), 127.0f));
 }
 
 #endif

@@ -2,8 +2,8 @@
  * or_samplers.h -- D3D fixed-function sampler emulation for the oracle (TEST INFRASTRUCTURE).
  *
  * Rules: texel i has its centre at (i + 0.5) / dim; bilinear at uv uses
- * t = uv*dim - 0.5, i0 = floor(t), f = t - i0, texels i0 and i0+1 with weights (1-f) and f, evaluated
- * as lerp(a, b, f) = a + f*(b - a), x first then y; the address mode is applied per texel.
+ * t = uv*dim - 0.5 (one mad), i0 = floor(t), f = t - i0, texels i0 and i0+1 with weights (1-f) and f, evaluated
+ * as lerp(a, b, f) = mad(f, b - a, a), x first then y; the address mode is applied per texel.
  * Non-finite or far-out-of-range coordinates are DEFINED to address only out-of-range texels.
  */
 #ifndef OR_SAMPLERS_H
@@ -15,9 +15,9 @@
 static inline float or_d24(uint32_t v) { return (float)(v & 0x00FFFFFFu) / 16777215.0f; }
 static inline float or_unorm16(uint16_t v) { return (float)v / 65535.0f; }
 static inline float or_unorm8(uint8_t v) { return (float)v / 255.0f; }
-/* UNORM write: floor(saturate(x) * (2^n - 1) + 0.5) */
-static inline uint16_t or_to_unorm16(float x) { return (uint16_t)(or_saturate(x) * 65535.0f + 0.5f); }
-static inline uint8_t or_to_unorm8(float x) { return (uint8_t)(or_saturate(x) * 255.0f + 0.5f); }
+/* UNORM write: floor(saturate(x) * (2^n - 1) + 0.5), the scale-and-bias as one mad */
+static inline uint16_t or_to_unorm16(float x) { return (uint16_t)fmaf(or_saturate(x), 65535.0f, 0.5f); }
+static inline uint8_t or_to_unorm8(float x) { return (uint8_t)fmaf(or_saturate(x), 255.0f, 0.5f); }
 
 typedef struct or_bilin {
     int i0, j0;   /* top-left texel (may be out of range) */
@@ -36,8 +36,8 @@ static inline int or_texel_index(float fl, uint32_t dim)
 static inline or_bilin or_bilinear_setup(float u, float v, uint32_t w, uint32_t h)
 {
     or_bilin b;
-    float tx = u * (float)w - 0.5f;
-    float ty = v * (float)h - 0.5f;
+    float tx = fmaf(u, (float)w, -0.5f);
+    float ty = fmaf(v, (float)h, -0.5f);
     float flx = floorf(tx), fly = floorf(ty);
     b.fx = tx - flx;
     b.fy = ty - fly;
@@ -131,8 +131,9 @@ static inline void or_cube_linear(const uint8_t* cube, uint32_t dim, const float
     if (ax >= ay && ax >= az) { ma = ax; if (r[0] >= 0.0f) { face = 0; sc = -r[2]; tc = -r[1]; } else { face = 1; sc = r[2]; tc = -r[1]; } }
     else if (ay >= az)        { ma = ay; if (r[1] >= 0.0f) { face = 2; sc = r[0]; tc = r[2]; } else { face = 3; sc = r[0]; tc = -r[2]; } }
     else                      { ma = az; if (r[2] >= 0.0f) { face = 4; sc = r[0]; tc = -r[1]; } else { face = 5; sc = -r[0]; tc = -r[1]; } }
-    float u = 0.5f * (sc / ma + 1.0f);
-    float v = 0.5f * (tc / ma + 1.0f);
+    float inv = or_rcp(ma);
+    float u = fmaf(0.5f, sc * inv, 0.5f);       /* 0.5 * (sc / ma + 1) */
+    float v = fmaf(0.5f, tc * inv, 0.5f);
     or_bilin b = or_bilinear_setup(u, v, dim, dim);
     int x0 = or_clampi(b.i0, 0, (int)dim - 1), x1 = or_clampi(b.i0 + 1, 0, (int)dim - 1);
     int y0 = or_clampi(b.j0, 0, (int)dim - 1), y1 = or_clampi(b.j0 + 1, 0, (int)dim - 1);

@@ -8,7 +8,7 @@
 /* Ssao.hlsl:110-115  viewZ = gProj[3][2] / (z_ndc - gProj[2][2]); HLSL M[r][c] = mem[4c + r]. */
 static inline float ndc_to_view(const or_ssao_constants* cb, float z_ndc)
 {
-    return cb->Proj[4 * 2 + 3] / (z_ndc - cb->Proj[4 * 2 + 2]);
+    return or_div(cb->Proj[4 * 2 + 3], z_ndc - cb->Proj[4 * 2 + 2]);
 }
 float or_ndc_depth_to_view_depth(const or_ssao_constants* cb, float z_ndc) { return ndc_to_view(cb, z_ndc); }
 
@@ -16,8 +16,8 @@ float or_ndc_depth_to_view_depth(const or_ssao_constants* cb, float z_ndc) { ret
  * (Ssao.hlsl:41-49,62) to the pixel centre. */
 static inline void pixel_uv(uint32_t x, uint32_t y, uint32_t w2, uint32_t h2, float* u, float* v)
 {
-    *u = ((float)x + 0.5f) / (float)w2;
-    *v = ((float)y + 0.5f) / (float)h2;
+    *u = or_div((float)x + 0.5f, (float)w2);
+    *v = or_div((float)y + 0.5f, (float)h2);
 }
 
 /* gsamPointClamp fetch of the full-res normal map at the centre of half-res pixel (xi, yi); (xi, yi) may
@@ -52,7 +52,7 @@ static inline float occlusion_function(const or_ssao_constants* cb, float distZ)
     float occlusion = 0.0f;
     if (distZ > cb->SurfaceEpsilon) {
         float fadeLength = cb->OcclusionFadeEnd - cb->OcclusionFadeStart;
-        occlusion = or_saturate((cb->OcclusionFadeEnd - distZ) / fadeLength);
+        occlusion = or_saturate(or_div(cb->OcclusionFadeEnd - distZ, fadeLength));
     }
     return occlusion;
 }
@@ -67,22 +67,23 @@ static uint16_t ssao_pixel(const or_ssao_constants* cb, const uint16_t* normal, 
 
     /* VS (Ssao.hlsl:58-72): PosH = (2u-1, 1-2v, 0, 1); PosV = mul(PosH, gInvProj).xyz / .w, evaluated at the
      * pixel centre (the interpolation of a projective-linear quantity over the quad). */
-    float posh[4] = { 2.0f * u - 1.0f, 1.0f - 2.0f * v, 0.0f, 1.0f };
+    float posh[4] = { fmaf(2.0f, u, -1.0f), fmaf(-2.0f, v, 1.0f), 0.0f, 1.0f };
     float ph[4];
     or_mul_v4_m(posh, cb->InvProj, ph);
-    float PosV[3] = { ph[0] / ph[3], ph[1] / ph[3], ph[2] / ph[3] };
+    float rw = or_rcp(ph[3]);
+    float PosV[3] = { ph[0] * rw, ph[1] * rw, ph[2] * rw };
 
     float nraw[3], n[3];
     normal_point(normal, W, H, (int)x, (int)y, nraw);
     or_normalize3(nraw, n);                                           /* :125 */
     float pz = ndc_to_view(cb, depth_at_half_pixel(depth, W, H, (int)x, (int)y)); /* :126-127 */
 
-    float t = pz / PosV[2];                                           /* :135 */
+    float t = or_div(pz, PosV[2]);                                    /* :135 */
     float p[3] = { t * PosV[0], t * PosV[1], t * PosV[2] };
 
     float rv[3];
     or_randvec_linear_wrap(randvec, 4.0f * u, 4.0f * v, rv);          /* :138 */
-    float randVec[3] = { 2.0f * rv[0] - 1.0f, 2.0f * rv[1] - 1.0f, 2.0f * rv[2] - 1.0f };
+    float randVec[3] = { fmaf(2.0f, rv[0], -1.0f), fmaf(2.0f, rv[1], -1.0f), fmaf(2.0f, rv[2], -1.0f) };
 
     float occlusionSum = 0.0f;
     for (int i = 0; i < 14; ++i) {                                    /* gSampleCount :39 */
@@ -90,20 +91,21 @@ static uint16_t ssao_pixel(const or_ssao_constants* cb, const uint16_t* normal, 
         or_reflect3(cb->OffsetVectors[i], randVec, offset);          /* :148 */
         float flip = or_sign(or_dot3(offset, n));                    /* :151 */
         float fr = flip * cb->OcclusionRadius;
-        float q[4] = { p[0] + fr * offset[0], p[1] + fr * offset[1], p[2] + fr * offset[2], 1.0f }; /* :154 */
+        float q[4] = { fmaf(fr, offset[0], p[0]), fmaf(fr, offset[1], p[1]), fmaf(fr, offset[2], p[2]), 1.0f }; /* :154 */
         float projQ[4];
         or_mul_v4_m(q, cb->ProjTex, projQ);                          /* :157 */
-        float qu = projQ[0] / projQ[3], qv = projQ[1] / projQ[3];   /* :158 */
+        float rq = or_rcp(projQ[3]);
+        float qu = projQ[0] * rq, qv = projQ[1] * rq;                /* :158 */
         float rz = ndc_to_view(cb, or_depth_linear_border(depth, W, H, qu, qv)); /* :164-165 */
-        float s = rz / q[2];                                         /* :171 */
+        float s = or_div(rz, q[2]);                                  /* :171 */
         float r[3] = { s * q[0], s * q[1], s * q[2] };
         float distZ = p[2] - r[2];                                   /* :185 */
         float d[3] = { r[0] - p[0], r[1] - p[1], r[2] - p[2] }, dn[3];
         or_normalize3(d, dn);
         float dp = or_max0(or_dot3(n, dn), 0.0f);                    /* :186 */
-        occlusionSum += dp * occlusion_function(cb, distZ);          /* :188-190 */
+        occlusionSum = fmaf(dp, occlusion_function(cb, distZ), occlusionSum); /* :188-190 */
     }
-    occlusionSum = occlusionSum / 14.0f;                              /* :193 */
+    occlusionSum = or_div(occlusionSum, 14.0f);                       /* :193 */
     float access = 1.0f - occlusionSum;                               /* :195 */
     /* :198 saturate(pow(access, 6)): the literal-6 power is DEFINED as three multiplies. */
     float a2 = access * access, a4 = a2 * a2, a6 = a4 * a2;
@@ -145,11 +147,11 @@ static uint16_t blur_pixel(const or_ssao_constants* cb, const uint16_t* normal, 
         if (or_dot3(neighborNormal, centerNormal) >= 0.8f && fabsf(neighborDepth - centerDepth) <= 0.2f) { /* :131-132 */
             float weight = blurWeights[i + gBlurRadius];
             int cx = or_clampi(tx, 0, w2 - 1), cy = or_clampi(ty, 0, h2 - 1);       /* point/clamp :137 */
-            color += weight * or_unorm16(in[(size_t)cy * w2 + cx]);
+            color = fmaf(weight, or_unorm16(in[(size_t)cy * w2 + cx]), color);
             totalWeight += weight;
         }
     }
-    return or_to_unorm16(color / totalWeight);                        /* :145 */
+    return or_to_unorm16(or_div(color, totalWeight));                 /* :145 */
 }
 
 void or_ssao_blur(const or_ssao_constants* cb, const uint16_t* normal, const uint32_t* depth,

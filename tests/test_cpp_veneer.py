@@ -14,14 +14,16 @@ SRC = os.path.join(ROOT, "tests", "cpp", "veneer_driver.cpp")
 EXE = os.path.join(ROOT, "tests", "cpp", "veneer_driver")
 
 
-def build_driver():
+def build_driver(name="veneer_driver"):
+    """tests/cpp/<name>.cpp -> tests/cpp/<name>, linked against the in-tree libcrychic_hip.so (rebuilt when a header changed)."""
+    src, exe = os.path.join(ROOT, "tests", "cpp", name + ".cpp"), os.path.join(ROOT, "tests", "cpp", name)
     hdrs = [os.path.join(ROOT, "include", "crychic", f) for f in os.listdir(os.path.join(ROOT, "include", "crychic"))]
-    deps = [SRC, os.path.join(ROOT, "include", "crychic_hip.h")] + hdrs
-    if not os.path.exists(EXE) or any(os.path.getmtime(d) > os.path.getmtime(EXE) for d in deps):
-        subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), SRC,
+    deps = [src, os.path.join(ROOT, "include", "crychic_hip.h")] + hdrs
+    if not os.path.exists(exe) or any(os.path.getmtime(d) > os.path.getmtime(exe) for d in deps):
+        subprocess.run(["/opt/rocm/bin/hipcc", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), src,
                         "-L", os.path.join(ROOT, "crychic_renderer_amd"), "-lcrychic_hip",
-                        "-Wl,-rpath," + os.path.join(ROOT, "crychic_renderer_amd"), "-o", EXE], check=True)
-    return EXE
+                        "-Wl,-rpath," + os.path.join(ROOT, "crychic_renderer_amd"), "-o", exe], check=True)
+    return exe
 
 
 def test_veneer_compiles(built_lib):

@@ -1,6 +1,7 @@
-"""The N > 1 code path of bench.py on a one-GPU box: process group on backend nccl (= RCCL) with a single rank, the
-two-slot FrameGather, and the per-slot hipGraph replay.  The gathered frame must equal the directly rendered one
-(bench.py checks it and exits 3 otherwise).  Real multi-rank behaviour is covered on CPU by test_sharding_gloo.py."""
+"""The N > 1 code path of bench.py on a one-GPU box: gloo control plane, the RCCL strip exchange behind the C ABI
+(crychic_allgather_frame) with a single rank, frames in flight.  The gathered frame must equal the directly rendered one
+(bench.py checks it and exits non-zero otherwise).  Rank spawning and multi-rank plumbing are covered on CPU by
+test_bench_launch.py and test_sharding_gloo.py."""
 import json
 import os
 import socket
@@ -21,21 +22,60 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("graph,inflight,partition", [("on", 1, "equal"), ("off", 1, "equal"), ("off", 2, "equal"), ("off", 2, "balanced")])
-def test_bench_gather_path_single_rank_rccl(built_lib, graph, inflight, partition):
+@pytest.mark.parametrize("exchange,inflight,partition", [("abi", 1, "equal"), ("abi", 2, "equal"), ("abi", 2, "balanced"), ("torch", 2, "equal")])
+def test_bench_gather_path_single_rank_rccl(built_lib, exchange, inflight, partition):
+    """bench.py's N > 1 path with one rank: gloo control plane, the RCCL exchange behind the C ABI (or the torch nccl
+    fallback), frames in flight; bench.py itself compares the gathered frame with a direct render and exits non-zero on a
+    difference (config.exchange_verified)."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
-    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-gather", "--graph", graph, "--frames-in-flight", str(inflight), "--partition", partition, "--steps", "7",
-           "--warmup", "3", "--width", "640", "--height", "360", "--shadow-dim", "512", "--cube-dim", "64",
-           "--no-cpu-baseline", "--no-producers"]
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-gather", "--exchange", exchange, "--frames-in-flight", str(inflight),
+           "--partition", partition, "--steps", "7", "--warmup", "3", "--width", "640", "--height", "360", "--shadow-dim", "512", "--cube-dim", "64",
+           "--no-cpu-baseline", "--no-producers", "--timeout", "400"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]
-    assert "gathered frame == directly rendered frame: True" in r.stderr, r.stderr[-3000:]
-    assert "capture failed" not in r.stderr, r.stderr[-3000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    out = json.loads(line)
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]      # native chatter must not reach stdout
+    out = json.loads(lines[0])
     assert out["n_gpus"] == 1 and out["value"] > 0
-    assert out["config"]["launch"] == ("hipGraph replay" if graph == "on" else "eager")
+    assert out["config"]["exchange_verified"] is True
     assert out["config"]["frames_in_flight"] == inflight
+    assert ("crychic_allgather_frame" in out["config"]["exchange"]) == (exchange == "abi"), out["config"]["exchange"]
+
+
+def test_allgather_frame_abi_single_rank(built_lib):
+    """crychic_comm_* / crychic_allgather_frame through ctypes with one rank: communicator from a rendezvous id, equal and
+    explicit bounds, the stream-ordered barrier, error paths (CRYCHIC_E_COMM / INVALID_ARG never crash)."""
+    import ctypes as C
+    import torch
+    from crychic_renderer_amd import Context, sharding
+    lib = built_lib.lib
+    ctx = Context(0)
+    W, H = 64, 48
+    ex = sharding.StripExchange(ctx, W, H, 1, 0, sharding.StripExchange.new_unique_id(), slots=2)
+    assert (ex.row0, ex.rows) == (0, H) and lib.crychic_comm_size(ex.handle) == 1 and lib.crychic_comm_rank(ex.handle) == 0
+    frame = torch.randint(0, 255, (H, W, 4), dtype=torch.uint8, device=ctx.device)
+    ex.strip_buffer(0).copy_(frame)
+    ex.launch(0)
+    ex.barrier()
+    ex.wait_all()
+    assert torch.equal(ex.frame(0), frame)
+    # explicit bounds that do not tile the frame are refused before anything is enqueued
+    bad = (C.c_uint32 * 2)(0, H - 2)
+    assert lib.crychic_allgather_frame(ex.handle, C.c_void_p(frame.data_ptr()), W, H, bad, None) == -1
+    assert b"strips cover" in lib.crychic_last_error()
+    assert lib.crychic_allgather_frame(None, C.c_void_p(frame.data_ptr()), W, H, None, None) == -1
+    # a rank outside the communicator size is refused without touching RCCL
+    h = C.c_void_p()
+    assert lib.crychic_comm_create(ctx.handle, 2, 2, (C.c_uint8 * 128)(), C.byref(h)) == -1 and not h.value
+    ex.close()
+    # single-process form (ncclCommInitAll) with the one visible GPU
+    comms = (C.c_void_p * 1)()
+    ctxs = (C.c_void_p * 1)(ctx.handle)
+    built_lib.check(lib.crychic_comm_create_all(ctxs, 1, comms))
+    frames = (C.c_void_p * 1)(frame.data_ptr())
+    built_lib.check(lib.crychic_allgather_frame_all(comms, 1, frames, W, H, None, None))
+    torch.cuda.synchronize()
+    lib.crychic_comm_destroy(comms[0])
 
 
 def test_bench_json_contract(built_lib):
@@ -55,7 +95,10 @@ def test_bench_json_contract(built_lib):
     assert out["unit"] == "Mpixels/s" and out["scaling"] == "strong" and out["data"] == "synthetic" and "workload" in out["config"]
     rf = out["roofline"]
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
-    assert "traffic" in rf and rf["achieved"] > 0
+    assert "traffic" in rf and rf["achieved"] > 0 and rf["scope"] == "frame"
+    assert rf["traffic"] is None                      # not the workload the committed PMC passes were taken on
+    assert [k["kernel"].split()[0] for k in rf["kernels"]] == ["ssao_kernel", "blur", "light_kernel"]
+    assert all(k["ms"] > 0 and k["achieved_GBs"] > 0 for k in rf["kernels"])
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Mpixels/s" and isinstance(cb["sample"], str)
     assert abs(out["value"] - 640 * 360 / (out["ms_per_step"] * 1e-3) / 1e6) / out["value"] < 0.01

@@ -5,6 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
 out=$1; shift
+bash tools/build_tools.sh      # never profile a stale driver
 mkdir -p "$out"
 [ -d /tmp/scene4k ] || python bench.py --dump-scene /tmp/scene4k --no-cpu-baseline --no-producers > "$out/dump.log" 2>&1
 i=0
