@@ -116,10 +116,9 @@ CRY_HD float mulcol1(float x, float y, float z, const float* col)
 }
 
 // ---- two-wide packed fp32 ---------------------------------------------------------------------------------------
-// On gfx950 a wave64 VALU instruction occupies its SIMD for 4 cycles whether it is v_mul_f32 or v_pk_mul_f32 (measured:
-// 4.1 cycles per VALU instruction in the VALU-bound SSAO loop), and the packed forms do two lanes' worth of IEEE-754
-// work per instruction.  The tap loops therefore process independent work items in pairs: `v2f` arithmetic compiles to
-// v_pk_mul_f32 / v_pk_add_f32 (never fused: -ffp-contract=off), each lane bit-identical to the scalar expression.
+// On gfx950 v_pk_fma_f32 issues in 4.6 cycles against 4.2 for v_fma_f32 (tools/valu_rate.hip): two mads for the price of
+// one.  The SSAO tap loop therefore processes two taps at a time: `v2f` arithmetic compiles to v_pk_fma_f32 /
+// v_pk_mul_f32 / v_pk_add_f32, each lane bit-identical to the scalar expression (fused only where fma2 is written).
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef int v2i __attribute__((ext_vector_type(2)));
 
@@ -132,35 +131,39 @@ CRY_HD float sign1(float x) { return ((x < 0.0f) | (x > 0.0f)) ? __builtin_copys
 CRY_HD v2f sign2(v2f x) { return v2f{ sign1(x.x), sign1(x.y) }; }
 CRY_HD v2f floor2(v2f x) { return v2f{ __builtin_floorf(x.x), __builtin_floorf(x.y) }; }
 CRY_HD v2f sqrt2(v2f x) { return v2f{ __builtin_sqrtf(x.x), __builtin_sqrtf(x.y) }; }
-CRY_HD v2f lerp2(v2f a, v2f b, v2f t) { return a + t * (b - a); }
-// Two correctly rounded divisions at once.  The device path is LLVM's own f32 fdiv expansion (v_div_scale x2, v_rcp,
-// Newton step, quotient refinement, v_div_fmas, v_div_fixup) written out so that the six FMA/MUL steps of the two
-// quotients issue as packed instructions: 16 instead of 22 VALU instructions per pair, bit-identical to n / d
-// (same operations, same special-case fix-up).  The host build simply divides.
-CRY_HD v2f div2(v2f n, v2f d)
+CRY_HD v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }      // v_pk_fma_f32: two mads per instruction
+CRY_HD v2f fma2(v2f a, float b, v2f c) { return fma2(a, splat(b), c); }
+CRY_HD v2f fma2(float a, v2f b, v2f c) { return fma2(splat(a), b, c); }
+CRY_HD v2f fma2(v2f a, v2f b, float c) { return fma2(a, b, splat(c)); }
+CRY_HD v2f fma2(v2f a, float b, float c) { return fma2(a, splat(b), splat(c)); }
+CRY_HD v2f lerp2(v2f a, v2f b, v2f t) { return fma2(t, b - a, a); }
+// rcp() of two values: the transcendental seeds are scalar instructions, the Newton step is packed.
+CRY_HD v2f rcp2(v2f b)
 {
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(CRYCHIC_RELAXED_MATH_PROBE)   // probe build: tools/relaxed_math_probe.py
-    bool na, nb, da, db;
-    const v2f ds{ __builtin_amdgcn_div_scalef(n.x, d.x, false, &da), __builtin_amdgcn_div_scalef(n.y, d.y, false, &db) };
-    const v2f ns{ __builtin_amdgcn_div_scalef(n.x, d.x, true, &na), __builtin_amdgcn_div_scalef(n.y, d.y, true, &nb) };
-    const v2f r{ __builtin_amdgcn_rcpf(ds.x), __builtin_amdgcn_rcpf(ds.y) };
-    const v2f nd = -ds;
-    const v2f f0 = __builtin_elementwise_fma(nd, r, v2f{ 1.0f, 1.0f });
-    const v2f f1 = __builtin_elementwise_fma(f0, r, r);
-    const v2f m = ns * f1;
-    const v2f f2 = __builtin_elementwise_fma(nd, m, ns);
-    const v2f f3 = __builtin_elementwise_fma(f2, f1, m);
-    const v2f f4 = __builtin_elementwise_fma(nd, f3, ns);
-    return v2f{ __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(f4.x, f1.x, f3.x, na), d.x, n.x),
-                __builtin_amdgcn_div_fixupf(__builtin_amdgcn_div_fmasf(f4.y, f1.y, f3.y, nb), d.y, n.y) };
+#if defined(__HIP_DEVICE_COMPILE__)
+    const v2f r0{ __builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y) };
+    const v2f e = fma2(-b, r0, 1.0f);
+    const v2f r1 = fma2(e, r0, r0);
+    return v2f{ __builtin_isnormal(r0.x) ? r1.x : r0.x, __builtin_isnormal(r0.y) ? r1.y : r0.y };
 #else
-    return n / d;
+    return v2f{ rcp(b.x), rcp(b.y) };
 #endif
 }
-CRY_HD v2f div2(float n, v2f d) { return div2(v2f{ n, n }, d); }
-CRY_HD v2f div2(v2f n, float d) { return div2(n, v2f{ d, d }); }
+CRY_HD v2f inv_len_from_sq2(v2f d2)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const v2f x{ clamp_len2(d2.x), clamp_len2(d2.y) };
+    const v2f g{ __builtin_amdgcn_sqrtf(x.x), __builtin_amdgcn_sqrtf(x.y) };
+    const v2f h = 0.5f * v2f{ __builtin_amdgcn_rsqf(x.x), __builtin_amdgcn_rsqf(x.y) };
+    const v2f sq = fma2(fma2(-g, g, x), h, g);
+    const v2f r0{ __builtin_amdgcn_rcpf(sq.x), __builtin_amdgcn_rcpf(sq.y) };
+    return fma2(fma2(-sq, r0, 1.0f), r0, r0);
+#else
+    return v2f{ inv_len_from_sq(d2.x), inv_len_from_sq(d2.y) };
+#endif
+}
 struct f3x2 { v2f x, y, z; };                                          // two 3-vectors, component-packed
-CRY_HD v2f dot3x2(f3x2 a, f3x2 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+CRY_HD v2f dot3x2(f3x2 a, f3x2 b) { return fma2(a.z, b.z, fma2(a.y, b.y, a.x * b.x)); }
 CRY_HD f3x2 splat3(f3 a) { return f3x2{ splat(a.x), splat(a.y), splat(a.z) }; }
 
 // ---- format decoders -------------------------------------------------------------------------------
@@ -190,8 +193,8 @@ CRY_HD float unorm8_to_float(uint32_t u)
     float r = __builtin_fmaf(-t, 255.0f, a);
     return __builtin_fmaf(r, c, t);
 }
-CRY_HD uint32_t float_to_unorm16(float x) { return (uint32_t)(saturate(x) * 65535.0f + 0.5f); }
-CRY_HD uint32_t float_to_unorm8(float x) { return (uint32_t)(saturate(x) * 255.0f + 0.5f); }
+CRY_HD uint32_t float_to_unorm16(float x) { return (uint32_t)fma(saturate(x), 65535.0f, 0.5f); }
+CRY_HD uint32_t float_to_unorm8(float x) { return (uint32_t)fma(saturate(x), 255.0f, 0.5f); }
 
 CRY_HD float half_to_float(uint16_t h)
 {
@@ -201,75 +204,66 @@ CRY_HD float half_to_float(uint16_t h)
 }
 
 // ---- deterministic transcendentals -------------------------------------------------------------------
-// sin/cos: 3-term Cody-Waite reduction by pi/2, degree-7 / degree-8 kernels on [-pi/4, pi/4].
+// sin/cos: 3-term Cody-Waite reduction by pi/2, degree-7 / degree-8 kernels on [-pi/4, pi/4], every step one mad.
 CRY_HD float det_sincos(float x, int want_cos)
 {
     float ax = __builtin_fabsf(x);
     if (!(ax < 8388608.0f)) return x - x;
     float k = __builtin_rintf(x * 0.636619772367581343f);
-    float r = x - k * 1.5703125f;
-    r = r - k * 4.837512969970703125e-4f;
-    r = r - k * 7.54978995489188216e-8f;
+    float r = fma(-k, 1.5703125f, x);
+    r = fma(-k, 4.837512969970703125e-4f, r);
+    r = fma(-k, 7.54978995489188216e-8f, r);
     int q = ((int)k + want_cos) & 3;
     float r2 = r * r;
-    float s = ((-1.9515295891e-4f * r2 + 8.3321608736e-3f) * r2 - 1.6666654611e-1f) * r2 * r + r;
-    float c = ((2.443315711809948e-5f * r2 - 1.388731625493765e-3f) * r2 + 4.166664568298827e-2f) * r2 * r2
-              - 0.5f * r2 + 1.0f;
+    float sp = fma(fma(-1.9515295891e-4f, r2, 8.3321608736e-3f), r2, -1.6666654611e-1f);
+    float s = fma(sp * r2, r, r);
+    float cp = fma(fma(2.443315711809948e-5f, r2, -1.388731625493765e-3f), r2, 4.166664568298827e-2f);
+    float c = fma(cp * r2, r2, fma(-0.5f, r2, 1.0f));
     float v = (q & 1) ? c : s;
     return (q & 2) ? -v : v;
 }
 CRY_HD float det_sin(float x) { return det_sincos(x, 0); }
 CRY_HD float det_cos(float x) { return det_sincos(x, 1); }
 
+// log2 of a normal positive x: x = m 2^e, m in [sqrt(1/2), sqrt(2)); log2(m) = s P(s^2), s = (m - 1) / (m + 1)
+CRY_HD float det_log2_normal(float x)
+{
+    const uint32_t ue = f2u(x) - 0x3F3504F3u;
+    const float ef = (float)((int32_t)ue >> 23);
+    const float m = u2f((ue & 0x007FFFFFu) + 0x3F3504F3u);
+    const float s = (m - 1.0f) * rcp_normal(m + 1.0f);
+    const float s2 = s * s;
+    const float p = fma(fma(fma(0.43174004554748535f, s2, 0.5767142176628113f), s2, 0.9617988467216492f), s2, 2.885390043258667f);
+    return fma(s, p, ef);
+}
+// 2^z for z in [-125, 127]
+CRY_HD float det_exp2_clamped(float z)
+{
+    const float n = __builtin_rintf(z);
+    const float f = z - n;
+    const float p = fma(fma(fma(fma(fma(fma(0.00015406982856802642f, f, 0.0013400138122960925f), f, 0.009618260897696018f), f,
+                                    0.05550328269600868f), f, 0.24022649228572845f), f, 0.6931471824645996f), f, 1.0f);
+    return __builtin_ldexpf(p, (int)n);
+}
+CRY_HD float clampf(float x, float lo, float hi) { return __builtin_fminf(__builtin_fmaxf(x, lo), hi); }
 CRY_HD float det_log2(float x)
 {
-    if (x != x) return x;
-    if (x < 0.0f) return u2f(0x7FC00000u);
-    if (x == 0.0f) return u2f(0xFF800000u);
-    if (x == u2f(0x7F800000u)) return x;
-    uint32_t u = f2u(x);
-    int e = (int)(u >> 23) - 126;
-    if ((u >> 23) == 0) {
-        x = x * 16777216.0f;
-        u = f2u(x);
-        e = (int)(u >> 23) - 126 - 24;
-    }
-    float m = u2f((u & 0x007FFFFFu) | 0x3F000000u);
-    if (m < 0.70710678118654752440f) { e -= 1; m = m + m - 1.0f; }
-    else { m = m - 1.0f; }
-    float z = m * m;
-    float y = ((((((((7.0376836292e-2f * m - 1.1514610310e-1f) * m + 1.1676998740e-1f) * m - 1.2420140846e-1f) * m
-                  + 1.4249322787e-1f) * m - 1.6668057665e-1f) * m + 2.0000714765e-1f) * m - 2.4999993993e-1f) * m
-               + 3.3333331174e-1f) * m * z;
-    y = y - 0.5f * z;
-    float r = y * 0.44269504088896340735992f;
-    r = r + m * 0.44269504088896340735992f;
-    r = r + y;
-    r = r + m;
-    r = r + (float)e;
-    return r;
+    if (!(x >= 1.17549435e-38f)) return (x >= 0.0f) ? u2f(0xFF800000u) : u2f(0x7FC00000u);
+    return det_log2_normal(x);
 }
-
 CRY_HD float det_exp2(float x)
 {
     if (x != x) return x;
-    if (x >= 128.0f) return u2f(0x7F800000u);
-    if (x < -126.0f) return 0.0f;
-    float n = __builtin_floorf(x + 0.5f);
-    float f = x - n;
-    float p = (((((1.535336188319500e-4f * f + 1.339887440266574e-3f) * f + 9.618437357674640e-3f) * f
-                 + 5.550332471162809e-2f) * f + 2.402264791363012e-1f) * f + 6.931472028550421e-1f) * f + 1.0f;
-    int ni = (int)n;
-    if (ni > 127) { p = p * 2.0f; ni = 127; }
-    return p * u2f((uint32_t)(ni + 127) << 23);
+    return det_exp2_clamped(clampf(x, -125.0f, 127.0f));
 }
-
+// HLSL pow(x, y) for 0 < y <= 1: below the smallest normal -> 0; negative or NaN -> NaN.  Branch-free:
+// the kernel runs on a safe stand-in and the specials are selected afterwards.
 CRY_HD float det_pow(float x, float y)
 {
-    if (x != x) return x;
-    if (x < 0.0f) return u2f(0x7FC00000u);
-    if (x == 0.0f) return 0.0f;
-    return det_exp2(y * det_log2(x));
+    const bool normal = x >= 1.17549435e-38f;
+    const float z = y * det_log2_normal(normal ? x : 1.0f);
+    const float r = det_exp2_clamped(clampf(z, -125.0f, 127.0f));
+    return normal ? r : ((x >= 0.0f) ? 0.0f : u2f(0x7FC00000u));
 }
 
 // ---- bilinear addressing --------------------------------------------------------------
@@ -284,8 +278,8 @@ CRY_HD int texel_index(float fl, uint32_t dim)
 CRY_HD Bilin bilinear_setup(float u, float v, uint32_t w, uint32_t h)
 {
     Bilin b;
-    const float tx = u * (float)w - 0.5f;
-    const float ty = v * (float)h - 0.5f;
+    const float tx = fma(u, (float)w, -0.5f);
+    const float ty = fma(v, (float)h, -0.5f);
     const float flx = __builtin_floorf(tx), fly = __builtin_floorf(ty);
     const float fx = tx - flx, fy = ty - fly;
     const bool bad = !(fx == fx) | !(fy == fy);   // non-finite coordinates address only out-of-range texels

@@ -33,7 +33,7 @@ constexpr uint32_t kMaxPointLights = 1024;   // tile masks live in LDS: 32 words
 // Common.hlsl:167-171 (noise is a scalar broadcast, so abs(noise.x + noise.y) * 0.5 == noise)
 CRY_HD float nrand(float u, float v)
 {
-    float d = u * (12.9898f * 2.0f) + v * (78.233f * 2.0f);
+    float d = fma(v, 78.233f * 2.0f, u * (12.9898f * 2.0f));
     float s = det_sin(d) * 43758.5453f;
     float noise = s - __builtin_floorf(s);
     return __builtin_fabsf(noise + noise) * 0.5f;
@@ -74,7 +74,8 @@ template <bool ZERO_RADIUS, bool W_ONE = false>
 CRY_HD float pcf_poisson(const uint32_t* __restrict__ s, uint32_t dim, float spx, float spy, float spz, float spw,
                          float radius)
 {
-    const float x = W_ONE ? spx : spx / spw, y = W_ONE ? spy : spy / spw, depth = W_ONE ? spz : spz / spw;  // :266-269
+    const float rw = W_ONE ? 1.0f : rcp(spw);      // x / 1 == x * rcp(1): the W_ONE form drops an exact identity
+    const float x = W_ONE ? spx : spx * rw, y = W_ONE ? spy : spy * rw, depth = W_ONE ? spz : spz * rw;  // :266-269
     float percentLit = 0.0f;
     if (ZERO_RADIUS || radius == 0.0f) {
         // Common.hlsl:305 as written (uint division) gives radius 0: every one of the 16 taps is
@@ -88,12 +89,12 @@ CRY_HD float pcf_poisson(const uint32_t* __restrict__ s, uint32_t dim, float spx
         const float P[32] = CRY_POISSON_TABLE;
 #pragma unroll
         for (int i = 0; i < 16; ++i) {                            // :308
-            const float px = P[2 * i] * c + P[2 * i + 1] * (-sn); // mul(poissonDisk[i], float2x2(c, s, -s, c))
-            const float py = P[2 * i] * sn + P[2 * i + 1] * c;
-            percentLit += shadow_cmp_linear(s, dim, x + px * radius, y + py * radius, depth);  // :311-313
+            const float px = fma(P[2 * i + 1], -sn, P[2 * i] * c); // mul(poissonDisk[i], float2x2(c, s, -s, c))
+            const float py = fma(P[2 * i + 1], c, P[2 * i] * sn);
+            percentLit += shadow_cmp_linear(s, dim, fma(px, radius, x), fma(py, radius, y), depth);  // :311-313
         }
     }
-    return percentLit / 16.0f;                                    // :315
+    return percentLit * 0.0625f;                                  // :315
 }
 
 // The cascades' light projections are orthographic (CRYCHIC.cpp:804), so ShadowTransform = lightView * ortho * T has the
@@ -127,14 +128,14 @@ CRY_HD void pbr_light(f3 lightDir, const float* strength, float att, f3 albedo, 
     // NDF_GGX :4-14
     const float a2 = roughness * roughness;
     const float nDoth = maxnn(dot3(normal, halfVec), 0.001f);
-    const float tt = (nDoth * nDoth) * (a2 - 1.0f) + 1.0f;
-    const float D = a2 * (1.0f / (CRY_PBR_PI * (tt * tt)));
+    const float tt = fma(nDoth * nDoth, a2 - 1.0f, 1.0f);
+    const float D = a2 * rcp(CRY_PBR_PI * (tt * tt));
     // FresnelSchlick :40-43
     const float fr = pow5(saturate(1.0f - nDotvQ));
     // GeometrySmith :29-38 (true nDotv)
     const float k = 0.125f * (roughness + 1.0f) * (roughness + 1.0f);
-    const float G = (nDotv / (nDotv * (1.0f - k) + k)) * (nDotl / (nDotl * (1.0f - k) + k));
-    const float denom = nDotl * nDotvQ;
+    const float G = divf(nDotv, fma(nDotv, 1.0f - k, k)) * divf(nDotl, fma(nDotl, 1.0f - k, k));
+    const float rdenom = rcp(nDotl * nDotvQ);
     const float invPi = 1.0f / CRY_PBR_PI;
     const float oneMinusMetal = 1.0f - metalness;
 
@@ -143,15 +144,15 @@ CRY_HD void pbr_light(f3 lightDir, const float* strength, float att, f3 albedo, 
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch) {
         const float f0 = lerpf(0.04f, alb[ch], metalness);
-        const float F = f0 + (1.0f - f0) * fr;
+        const float F = fma(1.0f - f0, fr, f0);
         float fs = 0.25f * D * G * F;
-        fs = fs / denom;
+        fs = fs * rdenom;
         const float fd = alb[ch] * invPi;
         const float kd = (1.0f - F) * oneMinusMetal;
-        const float brdf = kd * fd + F * fs;  // ks = F (Q4)
+        const float brdf = fma(F, fs, kd * fd);  // ks = F (Q4)
         float lightStrength = strength[ch] * nDotl;           // :104 / :118
         if (POINT) lightStrength = lightStrength * att;       // :120
-        res[ch] += scale * brdf * lightStrength;              // :105 / :122
+        res[ch] = fma(scale * brdf, lightStrength, res[ch]);  // :105 / :122
     }
     result = f3{ res[0], res[1], res[2] };
 }
@@ -170,10 +171,11 @@ CRY_HD void pbr_point_light(const crychic_light& L, f3 pos, f3 albedo, float rou
                             f3& result)
 {
     const f3 l{ L.Position[0] - pos.x, L.Position[1] - pos.y, L.Position[2] - pos.z };
-    const float d = __builtin_sqrtf(dot3(l, l));
+    const float d = len_from_sq(dot3(l, l));
     if (d > L.FalloffEnd) return;
-    const f3 ln{ l.x / d, l.y / d, l.z / d };
-    const float att = saturate((L.FalloffEnd - d) / (L.FalloffEnd - L.FalloffStart));
+    const float rd = rcp(d);
+    const f3 ln{ l.x * rd, l.y * rd, l.z * rd };
+    const float att = saturate(divf(L.FalloffEnd - d, L.FalloffEnd - L.FalloffStart));
     pbr_light<true>(ln, L.Strength, att, albedo, roughness, metalness, normal, view, 1.0f, result);
 }
 
@@ -186,8 +188,9 @@ CRY_HD f4 cube_linear(const uint32_t* __restrict__ cube, uint32_t dim, f3 r)
     if (ax >= ay && ax >= az) { ma = ax; if (r.x >= 0.0f) { face = 0; sc = -r.z; tc = -r.y; } else { face = 1; sc = r.z; tc = -r.y; } }
     else if (ay >= az)        { ma = ay; if (r.y >= 0.0f) { face = 2; sc = r.x; tc = r.z; } else { face = 3; sc = r.x; tc = -r.z; } }
     else                      { ma = az; if (r.z >= 0.0f) { face = 4; sc = r.x; tc = -r.y; } else { face = 5; sc = -r.x; tc = -r.y; } }
-    const float u = 0.5f * (sc / ma + 1.0f);
-    const float v = 0.5f * (tc / ma + 1.0f);
+    const float rma = rcp(ma);
+    const float u = fma(0.5f, sc * rma, 0.5f);      // 0.5 * (sc / ma + 1)
+    const float v = fma(0.5f, tc * rma, 0.5f);
     const Bilin b = bilinear_setup(u, v, dim, dim);
     const uint32_t y0 = (uint32_t)clampi(b.j0, 0, (int)dim - 1), y1 = (uint32_t)clampi(b.j0 + 1, 0, (int)dim - 1);
     const uint32_t faceRow = mul24(face, dim);   // faces are stacked: row index face*dim + y
@@ -247,10 +250,10 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
 
     float ambientAccess = 1.0f;
     if (ambient) {                                              // :40-42
-        const float sx = mulcol(posW.x, posW.y, posW.z, 1.0f, P.ViewProjTex + 0);
-        const float sy = mulcol(posW.x, posW.y, posW.z, 1.0f, P.ViewProjTex + 4);
-        const float sw = mulcol(posW.x, posW.y, posW.z, 1.0f, P.ViewProjTex + 12);
-        ambientAccess = ambient_linear_clamp(ambient, P.W / 2, P.H / 2, sx / sw, sy / sw);
+        const float sx = mulcol1(posW.x, posW.y, posW.z, P.ViewProjTex + 0);
+        const float sy = mulcol1(posW.x, posW.y, posW.z, P.ViewProjTex + 4);
+        const float rsw = rcp(mulcol1(posW.x, posW.y, posW.z, P.ViewProjTex + 12));
+        ambientAccess = ambient_linear_clamp(ambient, P.W / 2, P.H / 2, sx * rsw, sy * rsw);
     }
     const f3 amb{ ambientAccess * P.AmbientLight[0] * albedo.x, ambientAccess * P.AmbientLight[1] * albedo.y,
                   ambientAccess * P.AmbientLight[2] * albedo.z };  // :44
@@ -258,7 +261,8 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
     // :53-76  cascade selection.  `abs(distance - radius[j] < 5.0f)` is abs(bool) (Q1), true whenever
     // distance < radius[j]: every pixel nearer than 80 blends cascades j and j+1.
     float shadow0 = 1.0f;
-    const float distance = __builtin_sqrtf(dot3(toEye, toEye));
+    const float d2Eye = dot3(toEye, toEye);
+    const float distance = len_from_sq(d2Eye);
     int j = 4;
     if (distance < 30.0f) j = 0;
     else if (distance < 50.0f) j = 1;
@@ -273,10 +277,10 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
 #endif
         auto cascade = [&](int k) {
             const float* T = P.ShadowTransforms[k];
-            const float spx = mulcol(posW.x, posW.y, posW.z, 1.0f, T + 0), spy = mulcol(posW.x, posW.y, posW.z, 1.0f, T + 4);
-            const float spz = mulcol(posW.x, posW.y, posW.z, 1.0f, T + 8);
+            const float spx = mulcol1(posW.x, posW.y, posW.z, T + 0), spy = mulcol1(posW.x, posW.y, posW.z, T + 4);
+            const float spz = mulcol1(posW.x, posW.y, posW.z, T + 8);
             if (wOne) return pcf_poisson<ZERO_RADIUS, true>(P.shadow[k], P.shadowDim, spx, spy, spz, 1.0f, P.pcfSearchRadius);
-            float spw = mulcol(posW.x, posW.y, posW.z, 1.0f, T + 12);
+            float spw = mulcol1(posW.x, posW.y, posW.z, T + 12);
 #if defined(__HIP_DEVICE_COMPILE__)
             asm volatile("" : "+v"(spw));   // keeps the three divisions inside this (rare) branch: the optimiser would otherwise
                                             // speculate them above the wave-uniform test and select afterwards
@@ -297,17 +301,17 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
 
     const float invGamma = 1.0f / 2.2f;
     f4 lit;
-    lit.x = det_pow(direct.x / (direct.x + 1.0f), invGamma) + amb.x;  // :89-92
-    lit.y = det_pow(direct.y / (direct.y + 1.0f), invGamma) + amb.y;
-    lit.z = det_pow(direct.z / (direct.z + 1.0f), invGamma) + amb.z;
+    lit.x = det_pow(divf(direct.x, direct.x + 1.0f), invGamma) + amb.x;  // :89-92
+    lit.y = det_pow(divf(direct.y, direct.y + 1.0f), invGamma) + amb.y;
+    lit.z = det_pow(divf(direct.z, direct.z + 1.0f), invGamma) + amb.z;
 
     const f3 r = reflect3(f3{ -view.x, -view.y, -view.z }, normalW);  // :94
     const f4 refl = cube_linear(cube, P.cubeDim, r);            // :95
     const float f0 = 1.0f - saturate(dot3(normalW, r));         // LightingUtil.hlsl:54-57
     const float f5 = f0 * f0 * f0 * f0 * f0;
-    lit.x += shininess * (R0.x + (1.0f - R0.x) * f5) * refl.x;  // :97
-    lit.y += shininess * (R0.y + (1.0f - R0.y) * f5) * refl.y;
-    lit.z += shininess * (R0.z + (1.0f - R0.z) * f5) * refl.z;
+    lit.x = fma(shininess * fma(1.0f - R0.x, f5, R0.x), refl.x, lit.x);  // :97
+    lit.y = fma(shininess * fma(1.0f - R0.y, f5, R0.y), refl.y, lit.y);
+    lit.z = fma(shininess * fma(1.0f - R0.z, f5, R0.z), refl.z, lit.z);
     lit.w = 1.0f;                                               // :99
     return lit;
 }
@@ -315,13 +319,14 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
 // sky.hlsl:21-47 for an uncovered pixel: cubemap lookup along the pixel's view ray.
 CRY_HD f4 sky_pixel(const LightParams& P, const uint32_t* __restrict__ cube, uint32_t x, uint32_t y)
 {
-    const float u = ((float)x + 0.5f) / (float)P.W, v = ((float)y + 0.5f) / (float)P.H;
-    const float hx = 2.0f * u - 1.0f, hy = 1.0f - 2.0f * v;
+    const float u = divf((float)x + 0.5f, (float)P.W), v = divf((float)y + 0.5f, (float)P.H);
+    const float hx = fma(2.0f, u, -1.0f), hy = fma(-2.0f, v, 1.0f);
     const float phx = mulcol(hx, hy, 0.0f, 1.0f, P.InvProj + 0);
     const float phy = mulcol(hx, hy, 0.0f, 1.0f, P.InvProj + 4);
     const float phz = mulcol(hx, hy, 0.0f, 1.0f, P.InvProj + 8);
     const float phw = mulcol(hx, hy, 0.0f, 1.0f, P.InvProj + 12);
-    const float vx = phx / phw, vy = phy / phw, vz = phz / phw;
+    const float rphw = rcp(phw);
+    const float vx = phx * rphw, vy = phy * rphw, vz = phz * rphw;
     const f3 d{ mulcol(vx, vy, vz, 0.0f, P.InvView + 0), mulcol(vx, vy, vz, 0.0f, P.InvView + 4),
                 mulcol(vx, vy, vz, 0.0f, P.InvView + 8) };
     return cube_linear(cube, P.cubeDim, d);

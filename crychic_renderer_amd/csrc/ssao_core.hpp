@@ -60,7 +60,7 @@ CRY_HD f3 unpack_normal(u2 t)
 // Ssao.hlsl:110-115; HLSL gProj[r][c] is mem[4c + r] in the transposed cbuffer layout.
 CRY_HD float ndc_to_view(const crychic_ssao_constants& cb, float z_ndc)
 {
-    return cb.Proj[4 * 2 + 3] / (z_ndc - cb.Proj[4 * 2 + 2]);
+    return divf(cb.Proj[4 * 2 + 3], z_ndc - cb.Proj[4 * 2 + 2]);
 }
 
 // gsamDepthMap: linear filter, BORDER (1.0) addressing  (CRYCHIC.cpp:1057-1066)
@@ -171,27 +171,28 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
                            uint32_t H, uint32_t x, uint32_t y, bool sparseProjTex)
 {
     const uint32_t w2 = W / 2, h2 = H / 2;
-    const float u = ((float)x + 0.5f) / (float)w2;
-    const float v = ((float)y + 0.5f) / (float)h2;
+    const float u = divf((float)x + 0.5f, (float)w2);
+    const float v = divf((float)y + 0.5f, (float)h2);
 
     // VS :58-72 evaluated at the pixel centre
-    const float hx = 2.0f * u - 1.0f, hy = 1.0f - 2.0f * v;
+    const float hx = fma(2.0f, u, -1.0f), hy = fma(-2.0f, v, 1.0f);
     const float phx = mulcol(hx, hy, 0.0f, 1.0f, cb.InvProj + 0);
     const float phy = mulcol(hx, hy, 0.0f, 1.0f, cb.InvProj + 4);
     const float phz = mulcol(hx, hy, 0.0f, 1.0f, cb.InvProj + 8);
     const float phw = mulcol(hx, hy, 0.0f, 1.0f, cb.InvProj + 12);
-    const f3 PosV{ phx / phw, phy / phw, phz / phw };
+    const float rphw = rcp(phw);
+    const f3 PosV{ phx * rphw, phy * rphw, phz * rphw };
 
     const f3 n = normalize3(unpack_normal(c.nrm_bits));   // :125
     const float pz = c.vz;                                // :126-127
-    const float t = pz / PosV.z;                          // :135
+    const float t = divf(pz, PosV.z);                     // :135
     const f3 p{ t * PosV.x, t * PosV.y, t * PosV.z };
 
     const f3 rv = randvec_linear_wrap(randvec, 4.0f * u, 4.0f * v);  // :138
-    const f3 randVec{ 2.0f * rv.x - 1.0f, 2.0f * rv.y - 1.0f, 2.0f * rv.z - 1.0f };
+    const f3 randVec{ fma(2.0f, rv.x, -1.0f), fma(2.0f, rv.y, -1.0f), fma(2.0f, rv.z, -1.0f) };
 
     const float eps = cb.SurfaceEpsilon, fadeEnd = cb.OcclusionFadeEnd;
-    const float fadeLength = cb.OcclusionFadeEnd - cb.OcclusionFadeStart;  // :100
+    const float rFadeLength = rcp(cb.OcclusionFadeEnd - cb.OcclusionFadeStart);  // :100,104: one reciprocal for all taps
 
     // Taps are evaluated two at a time in packed fp32 (devmath.hpp "two-wide packed fp32"); lane .x is tap i, lane .y tap
     // i+1, and the occlusion terms are added to the sum in tap order, so every bit equals the one-tap-at-a-time loop.
@@ -212,23 +213,26 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
         const f3x2 o{ v2f{ cb.OffsetVectors[i][0], cb.OffsetVectors[i + 1][0] }, v2f{ cb.OffsetVectors[i][1], cb.OffsetVectors[i + 1][1] },
                       v2f{ cb.OffsetVectors[i][2], cb.OffsetVectors[i + 1][2] } };
         const v2f d2 = 2.0f * dot3x2(rv2, o);                                     // reflect(o, randVec)  :148
-        const f3x2 offset{ o.x - d2 * rv2.x, o.y - d2 * rv2.y, o.z - d2 * rv2.z };
+        const v2f nd2 = -d2;
+        const f3x2 offset{ fma2(nd2, rv2.x, o.x), fma2(nd2, rv2.y, o.y), fma2(nd2, rv2.z, o.z) };
         const v2f fr = sign2(dot3x2(offset, n2)) * cb.OcclusionRadius;            // :151,154
-        const f3x2 q{ p2.x + fr * offset.x, p2.y + fr * offset.y, p2.z + fr * offset.z };
+        const f3x2 q{ fma2(fr, offset.x, p2.x), fma2(fr, offset.y, p2.y), fma2(fr, offset.z, p2.z) };
         v2f pqx, pqy, pqw;                                                        // mul(float4(q,1), gProjTex)  :157
         if (SPARSE) {
-            pqx = q.x * PT[0] + q.z * PT[2];
-            pqy = q.y * PT[5] + q.z * PT[6];
+            pqx = fma2(q.z, PT[2], q.x * PT[0]);
+            pqy = fma2(q.z, PT[6], q.y * PT[5]);
             pqw = q.z;
         } else {
-            pqx = ((q.x * PT[0] + q.y * PT[1]) + q.z * PT[2]) + PT[3];
-            pqy = ((q.x * PT[4] + q.y * PT[5]) + q.z * PT[6]) + PT[7];
-            pqw = ((q.x * PT[12] + q.y * PT[13]) + q.z * PT[14]) + PT[15];
+            pqx = fma2(q.z, PT[2], fma2(q.y, PT[1], q.x * PT[0])) + PT[3];
+            pqy = fma2(q.z, PT[6], fma2(q.y, PT[5], q.x * PT[4])) + PT[7];
+            pqw = fma2(q.z, PT[14], fma2(q.y, PT[13], q.x * PT[12])) + PT[15];
         }
-        const v2f tu = div2(pqx, pqw), tv = div2(pqy, pqw);                       // :158
+        const v2f rqz = rcp2(q.z);                                                // 1 / q.z: used at :171, and at :158 when w' = q.z
+        const v2f rpw = SPARSE ? rqz : rcp2(pqw);
+        const v2f tu = pqx * rpw, tv = pqy * rpw;                                 // :158
 
         // gsamDepthMap, both taps: bilinear setup in packed form, the 2 x 2 footprints through the paired loads
-        const v2f tx = tu * (float)W - 0.5f, ty = tv * (float)H - 0.5f;
+        const v2f tx = fma2(tu, (float)W, -0.5f), ty = fma2(tv, (float)H, -0.5f);
         const v2f flx = floor2(tx), fly = floor2(ty);
         // Fractions: in [0, 1) or NaN (non-finite coordinate); fmax(NaN, 0) = 0.  Texel indices: clamp(floor, -2, dim + 1)
         // sends +-inf out of range and NaN to -2, so a non-finite coordinate addresses only BORDER texels on its own axis --
@@ -254,23 +258,22 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
             t01.y = d24_to_float((xa && y1) ? a1.a : 0x00FFFFFFu); t11.y = d24_to_float((xb && y1) ? a1.b : 0x00FFFFFFu);
         }
         const v2f zndc = lerp2(lerp2(t00, t10, fx), lerp2(t01, t11, fx), fy);
-        const v2f rz = div2(B, zndc - A);                                         // :164-165
-        const v2f sc = div2(rz, q.z);                                             // :171
+        const v2f rz = B * rcp2(zndc - A);                                        // :164-165
+        const v2f sc = rz * rqz;                                                  // :171
         const f3x2 r{ sc * q.x, sc * q.y, sc * q.z };
         const v2f distZ = p2.z - r.z;                                             // :185
         const f3x2 dv{ r.x - p2.x, r.y - p2.y, r.z - p2.z };
-        const v2f inv = div2(1.0f, sqrt2(dot3x2(dv, dv)));                        // normalize(r - p)
+        const v2f inv = inv_len_from_sq2(dot3x2(dv, dv));                         // normalize(r - p)
         const f3x2 dn{ dv.x * inv, dv.y * inv, dv.z * inv };
         const v2f dp = max0_2(dot3x2(n2, dn));                                    // :186
-        const v2f fade = saturate2(div2(fadeEnd - distZ, fadeLength));            // :76-108
+        const v2f fade = saturate2((fadeEnd - distZ) * rFadeLength);              // :76-108
         const v2f occ = select2(distZ > eps, fade, splat(0.0f));
-        const v2f term = dp * occ;
-        occlusionSum += term.x;                                                   // :188-190, tap i then tap i+1
-        occlusionSum += term.y;
+        occlusionSum = fma(dp.x, occ.x, occlusionSum);                            // :188-190, tap i then tap i+1
+        occlusionSum = fma(dp.y, occ.y, occlusionSum);
     }
     };
     if (sparse) taps(SparseTag<true>{}); else taps(SparseTag<false>{});
-    occlusionSum = occlusionSum / 14.0f;                                         // :193
+    occlusionSum = occlusionSum * (1.0f / 14.0f);                                // :193: a / 14 = a * rcp(14)
     const float access = 1.0f - occlusionSum;                                    // :195
     const float a2 = access * access, a4 = a2 * a2;                              // :198 pow(access, 6)
     return float_to_unorm16(a4 * a2);
@@ -325,11 +328,11 @@ CRY_HD BlurOut blur_pixel_full(const float* __restrict__ w, Fetch fetch)
         // A rejected tap adds weight 0: color + 0 * a and total + 0 leave both sums bit-unchanged (a is a decoded UNORM,
         // finite and >= 0, so neither sum is ever -0) -- one select instead of two, and the wave never diverges here.
         const float ws = ok ? w[i] : 0.0f;
-        color = color + ws * t.a;
+        color = fma(ws, t.a, color);
         total = total + ws;
         mask |= ok ? (1u << i) : 0u;
     }
-    return BlurOut{ float_to_unorm16(color / total), mask, total };  // :145
+    return BlurOut{ float_to_unorm16(divf(color, total)), mask, total };  // :145
 }
 template <class Fetch>
 CRY_HD uint32_t blur_pixel(const float* __restrict__ w, Fetch fetch) { return blur_pixel_full(w, fetch).value; }
@@ -346,9 +349,9 @@ CRY_HD uint32_t blur_pixel_replay(const float* __restrict__ w, uint32_t mask, fl
         // weight or +0.0 by AND-ing the weight's bits with the sign-extended mask bit (v_bfe_i32 + v_and_b32); adding 0 * a
         // leaves the sum bit-unchanged, see blur_pixel_full
         const uint32_t keep = (uint32_t)(((int32_t)(mask << (31 - i))) >> 31);
-        color = color + u2f(f2u(w[i]) & keep) * amb(i);
+        color = fma(u2f(f2u(w[i]) & keep), amb(i), color);
     }
-    return float_to_unorm16(color / total);
+    return float_to_unorm16(divf(color, total));
 }
 
 }  // namespace cry

@@ -126,7 +126,7 @@ static void cross3(const float a[3], const float b[3], float o[3])
 }
 static void norm3(const float v[3], float o[3])
 {
-    float l = sqrtf(or_dot3(v, v));
+    float l = sqrtf(or_dot3_host(v, v));
     o[0] = v[0] / l; o[1] = v[1] / l; o[2] = v[2] / l;
 }
 /* XMMatrixLookAtLH = XMMatrixLookToLH(eye, at - eye, up) */
@@ -137,7 +137,7 @@ void or_mat_look_at_lh(const float eye[3], const float at[3], const float up[3],
     cross3(up, r2, t); norm3(t, r0);
     cross3(r2, r0, r1);
     float neg[3] = { -eye[0], -eye[1], -eye[2] };
-    float d0 = or_dot3(r0, neg), d1 = or_dot3(r1, neg), d2 = or_dot3(r2, neg);
+    float d0 = or_dot3_host(r0, neg), d1 = or_dot3_host(r1, neg), d2 = or_dot3_host(r2, neg);
     float m[16] = { r0[0], r1[0], r2[0], 0, r0[1], r1[1], r2[1], 0, r0[2], r1[2], r2[2], 0, d0, d1, d2, 1 };
     memcpy(out, m, sizeof m);
 }
@@ -160,7 +160,7 @@ static void camera_view(const or_camera* cam, float view[16])
     float t[3];
     cross3(L, R, t); norm3(t, U);             /* U = normalize(L x R) */
     cross3(U, L, R);                          /* R = U x L */
-    float x = -or_dot3(cam->pos, R), y = -or_dot3(cam->pos, U), z = -or_dot3(cam->pos, L);
+    float x = -or_dot3_host(cam->pos, R), y = -or_dot3_host(cam->pos, U), z = -or_dot3_host(cam->pos, L);
     float m[16] = { R[0], U[0], L[0], 0, R[1], U[1], L[1], 0, R[2], U[2], L[2], 0, x, y, z, 1 };
     memcpy(view, m, sizeof m);
 }

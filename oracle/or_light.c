@@ -34,8 +34,8 @@ float or_pcf_search_radius(uint32_t width, int literal)
 {
     /* Common.hlsl:305 `float search_radius = 5 / width / 2.0f;` with `uint width`: 5 / width is an
      * unsigned integer division (quirk Q2). */
-    if (literal) return (float)(5u / width) * 0.5f;
-    return or_div(5.0f, (float)width) * 0.5f;
+    if (literal) return (float)(5u / width) / 2.0f;
+    return 5.0f / (float)width / 2.0f;        /* evaluated on the host and handed to the pass as a constant */
 }
 
 /* Common.hlsl:263-317 */

@@ -55,6 +55,8 @@ static inline float or_clamp_len2(float d) { return (d != d) ? 7.888609052210118
 static inline float or_len(float d2) { return sqrtf(or_clamp_len2(d2)); }
 static inline float or_inv_len(float d2) { return 1.0f / sqrtf(or_clamp_len2(d2)); }
 
+/* HOST code of the reference (DirectXMath on x86: XMVector3Dot and friends, SSE multiplies and adds) is plain unfused IEEE. */
+static inline float or_dot3_host(const float a[3], const float b[3]) { return (a[0] * b[0] + a[1] * b[1]) + a[2] * b[2]; }
 /* HLSL dot(a, b): x first, then two mads. */
 static inline float or_dot3(const float a[3], const float b[3]) { return fmaf(a[2], b[2], fmaf(a[1], b[1], a[0] * b[0])); }
 /* HLSL normalize(v) = v * rsqrt(dot(v,v)). */

@@ -319,7 +319,7 @@ static or_vertex mkv(float px, float py, float pz, float nx, float ny, float nz,
 }
 static void norm3_(const float a[3], float o[3])
 {
-    float l = sqrtf(or_dot3(a, a));
+    float l = sqrtf(or_dot3_host(a, a));
     o[0] = a[0] / l; o[1] = a[1] / l; o[2] = a[2] / l;
 }
 /* GeometryGenerator.cpp:277-305 */
@@ -419,7 +419,7 @@ int or_load_mesh_text(const char* path, or_vertex* v, uint32_t vcap, uint32_t* i
         p->TexC[0] = p->TexC[1] = 0.0f;
         const float* N = p->Normal;
         float up[3] = { 0.0f, 1.0f, 0.0f }, c[3];
-        if (fabsf(or_dot3(N, up)) < 1.0f - 0.001f) {                    /* :1489-1493: T = normalize(up x N) */
+        if (fabsf(or_dot3_host(N, up)) < 1.0f - 0.001f) {                    /* :1489-1493: T = normalize(up x N) */
             c[0] = up[1] * N[2] - up[2] * N[1]; c[1] = up[2] * N[0] - up[0] * N[2]; c[2] = up[0] * N[1] - up[1] * N[0];
         } else {                                                        /* :1494-1499: up = +z, T = normalize(N x up) */
             float u2[3] = { 0.0f, 0.0f, 1.0f };

@@ -7,6 +7,7 @@
 // -fhip-fp32-correctly-rounded-divide-sqrt, the default; fp64 for rsqrt).  Prints, per candidate, the number of inputs
 // whose bits differ and the first few of them.  Build: hipcc -O2 --offload-arch=gfx950 -ffp-contract=off
 #include <hip/hip_runtime.h>
+#include "../crychic_renderer_amd/csrc/devmath.hpp"
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
@@ -125,6 +126,11 @@ __device__ __forceinline__ float def_invsqrt(float x)
     return def_rcp(__builtin_sqrtf(x));
 }
 
+// the oracle's definitions of the two length primitives (or_math.h), IEEE operations only
+__device__ __forceinline__ float def_clamp_len2(float d) { return (d != d) ? 7.8886090522101181e-31f : __builtin_fminf(__builtin_fmaxf(d, 7.8886090522101181e-31f), 1.2676506002282294e30f); }
+__device__ __forceinline__ float def_len(float d) { return __builtin_sqrtf(def_clamp_len2(d)); }
+__device__ __forceinline__ float def_inv_len(float d) { return 1.0f / __builtin_sqrtf(def_clamp_len2(d)); }
+
 // ---- references -------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float ref_rcp(float x) { return 1.0f / x; }
 __device__ __forceinline__ float ref_sqrt(float x) { return __builtin_sqrtf(x); }
@@ -133,7 +139,7 @@ __device__ __forceinline__ float ref_rsqrt(float x) { return (float)(1.0 / __bui
 struct Tally { unsigned long long bad; unsigned long long maxulp; uint32_t first[8]; };
 
 template <int WHICH>
-__global__ __launch_bounds__(256) void sweep(Tally* t, uint32_t lo, uint32_t hi)
+__global__ __launch_bounds__(256) void sweep(Tally* t, uint64_t lo, uint64_t hi)
 {
     unsigned long long bad = 0, maxulp = 0;
     for (uint64_t u = lo + (uint64_t)blockIdx.x * 256u + threadIdx.x; u < hi; u += (uint64_t)gridDim.x * 256u) {
@@ -151,7 +157,10 @@ __global__ __launch_bounds__(256) void sweep(Tally* t, uint32_t lo, uint32_t hi)
         else if (WHICH == 9) { got = sqrt_short(x); ref = ref_sqrt(x); }
         else if (WHICH == 10) { got = rcp_total(x); ref = def_rcp(x); }
         else if (WHICH == 11) { got = sqrt_total(x); ref = def_sqrt(x); }
-        else { got = invsqrt_total(x); ref = def_invsqrt(x); }
+        else if (WHICH == 12) { got = invsqrt_total(x); ref = def_invsqrt(x); }
+        else if (WHICH == 13) { got = cry::rcp(x); ref = def_rcp(x); }                    // the shipped text (csrc/devmath.hpp)
+        else if (WHICH == 14) { got = cry::len_from_sq(x); ref = def_len(x); }
+        else { got = cry::inv_len_from_sq(x); ref = def_inv_len(x); }
         uint32_t a = f2u(got), b = f2u(ref);
         if (got != got) a = 0x7FC00000u;       // any NaN == any NaN
         if (ref != ref) b = 0x7FC00000u;
@@ -166,7 +175,7 @@ __global__ __launch_bounds__(256) void sweep(Tally* t, uint32_t lo, uint32_t hi)
 }
 
 template <int WHICH>
-static int run(const char* name, uint32_t lo, uint32_t hi, Tally* d)
+static int run(const char* name, uint64_t lo, uint64_t hi, Tally* d)
 {
     Tally z;
     memset(&z, 0, sizeof z);
@@ -174,16 +183,29 @@ static int run(const char* name, uint32_t lo, uint32_t hi, Tally* d)
     hipLaunchKernelGGL(sweep<WHICH>, dim3(4096), dim3(256), 0, 0, d, lo, hi);
     CHK(hipDeviceSynchronize());
     CHK(hipMemcpy(&z, d, sizeof z, hipMemcpyDeviceToHost));
-    printf("%-34s inputs [%08x, %08x): %llu differ, max distance %llu ulp", name, lo, hi, z.bad, z.maxulp);
+    printf("%-34s inputs [%08llx, %08llx): %llu differ, max distance %llu ulp", name, (unsigned long long)lo, (unsigned long long)hi, z.bad, z.maxulp);
     if (z.bad) { printf("; e.g."); for (int i = 0; i < 8 && z.first[i]; ++i) printf(" %08x", z.first[i]); }
     printf("\n");
     return 0;
 }
 
-int main()
+int main(int argc, char** argv)
 {
     Tally* d;
     CHK(hipMalloc(&d, sizeof(Tally)));
+    const uint32_t cls8[][2] = { { 0x00000000u, 0x00800000u }, { 0x00800000u, 0x7F000000u }, { 0x7F000000u, 0x7F800000u }, { 0x7F800000u, 0x80000000u },
+                                 { 0x80000000u, 0x80800000u }, { 0x80800000u, 0xFF000000u }, { 0xFF000000u, 0xFF800000u }, { 0xFF800000u, 0xFFFFFFFFu } };
+    if (argc > 1 && strcmp(argv[1], "shipped") == 0) {     // what tests/test_gpu_exact_math.py asserts on
+        for (auto& c : cls8) {
+            if (run<13>("rcp (devmath.hpp) vs or_rcp", c[0], c[1], d)) return 1;
+            if (run<14>("len_from_sq vs or_len", c[0], c[1], d)) return 1;
+            if (run<15>("inv_len_from_sq vs or_inv_len", c[0], c[1], d)) return 1;
+        }
+        // 0xFFFFFFFF itself (a NaN): the half-open ranges above stop just short of it
+        if (run<13>("rcp (devmath.hpp) vs or_rcp", 0xFFFFFFFFull, 0x100000000ull, d)) return 1;
+        CHK(hipFree(d));
+        return 0;
+    }
     // full positive normal range, and the range the kernels promise (2^-100 .. 2^100: neither the input nor the result is subnormal)
     const uint32_t ranges[2][2] = { { 0x00800000u, 0x7F800000u }, { 0x0D800000u, 0x71800000u } };
     for (int r = 0; r < 2; ++r) {
