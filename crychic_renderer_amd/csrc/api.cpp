@@ -81,7 +81,10 @@ int ssao_compute_impl(crychic_ctx* ctx, const crychic_ssao_constants* cb, const 
     // Vertical sweeps reach 5 rows (gBlurRadius, SsaoBlur.hlsl:48): recompute a halo instead of exchanging it.
     uint32_t r0, rn;
     clamp_rows(h2, (int64_t)row0 - 5 * blurCount, (int64_t)row0 + rows + 5 * blurCount, &r0, &rn);
-    CRY_HIP(cry::launch_ssao(*cb, normal, depth, randvec, ambient0, blurCount > 0 ? edge : nullptr, W, H, r0, rn, true, stream));
+    // With a workspace at hand the depth plane is re-laid once per frame as decoded pairs (whole plane: the taps of any row
+    // reach far up and down the frame) and the taps gather from that; its cost is part of the SSAO pass.
+    if (edge) CRY_HIP(cry::launch_depth_pairs(depth, edge, W, H, stream));
+    CRY_HIP(cry::launch_ssao(*cb, normal, depth, randvec, ambient0, edge, W, H, r0, rn, true, edge != nullptr, stream));
     if (afterSsao) CRY_HIP(hipEventRecord(afterSsao, stream));
     // Iteration 0 records each direction's tap decisions; iterations 1.. replay them (same geometry, same rows or fewer).
     // Replay iterations run as one fused H+V launch each (in -> out, out != in).  The result has to end in ambient0
@@ -198,7 +201,8 @@ int crychic_ssao(crychic_ctx* ctx, const crychic_ssao_constants* cb, const void*
     if (int rc = check_dims(W, H)) return rc;
     if (!cb || !normal_dev || !depth_dev || !randvec_dev || !ambient_out_dev) return fail(CRYCHIC_E_INVALID_ARG, "null argument");
     if (row0 > H / 2 || rows > H / 2 - row0) return fail(CRYCHIC_E_INVALID_ARG, "rows [%u,+%u) outside the %u-row ambient map", row0, rows, H / 2);
-    CRY_HIP(cry::launch_ssao(*cb, normal_dev, depth_dev, randvec_dev, ambient_out_dev, edge_dev, W, H, row0, rows, true,
+    if (edge_dev) CRY_HIP(cry::launch_depth_pairs(depth_dev, edge_dev, W, H, (hipStream_t)stream));
+    CRY_HIP(cry::launch_ssao(*cb, normal_dev, depth_dev, randvec_dev, ambient_out_dev, edge_dev, W, H, row0, rows, true, edge_dev != nullptr,
                              (hipStream_t)stream));
     return 0;
 }
@@ -211,7 +215,7 @@ int crychic_ssao_edges(crychic_ctx* ctx, const crychic_ssao_constants* cb, const
     if (int rc = check_dims(W, H)) return rc;
     if (!cb || !normal_dev || !depth_dev || !edge_dev) return fail(CRYCHIC_E_INVALID_ARG, "null argument");
     if (row0 > H / 2 || rows > H / 2 - row0) return fail(CRYCHIC_E_INVALID_ARG, "rows [%u,+%u) outside the %u-row ambient map", row0, rows, H / 2);
-    CRY_HIP(cry::launch_ssao(*cb, normal_dev, depth_dev, nullptr, nullptr, edge_dev, W, H, row0, rows, false, (hipStream_t)stream));
+    CRY_HIP(cry::launch_ssao(*cb, normal_dev, depth_dev, nullptr, nullptr, edge_dev, W, H, row0, rows, false, false, (hipStream_t)stream));
     return 0;
 }
 

@@ -68,7 +68,8 @@ CRY_HD float rcp_normal(float b)
 #endif
 }
 CRY_HD float divf(float a, float b) { return a * rcp(b); }     // HLSL a / b
-// Squared length clamped to [2^-100, 2^100] (NaN -> 2^-100: v_med3_f32 returns the minimum when an operand is NaN).
+// Squared length clamped to [2^-100, 2^100] (NaN -> 2^-100: v_med3_f32 returns the minimum when an operand is a quiet NaN;
+// the argument is always an arithmetic result -- a dot product -- so it is never a signaling one).
 CRY_HD float clamp_len2(float d)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -167,32 +168,18 @@ CRY_HD v2f dot3x2(f3x2 a, f3x2 b) { return fma2(a.z, b.z, fma2(a.y, b.y, a.x * b
 CRY_HD f3x2 splat3(f3 a) { return f3x2{ splat(a.x), splat(a.y), splat(a.z) }; }
 
 // ---- format decoders -------------------------------------------------------------------------------
-// D24 -> float == (float)u / 16777215.0f for every u in [0, 2^24): q = u * 2^-24 is exact and the quotient
-// is q * (1 + 2^-24 + ...), i.e. q plus a correction strictly between 0.5 and 1 ulp(q), so the correctly
-// rounded result is the next float above q.
-CRY_HD float d24_to_float(uint32_t texel)
+// u / (2^n - 1), correctly rounded, for every u the format can hold: with c = 1 / (2^n - 1) split into c_hi = RN(c) and
+// c_lo = RN(c - c_hi), fma(u, c_hi, u * c_lo) equals the IEEE quotient (float)u / (2^n - 1) -- checked exhaustively on the
+// host for n = 8, 16 and 24 (tests/test_devmath_host.py).  Three instructions with the conversion (v_cvt_f32_u32, v_mul_f32,
+// v_fma_f32) against eleven for the division.
+CRY_HD float unorm_decode(uint32_t u, float c_hi, float c_lo)
 {
-    uint32_t u = texel & 0x00FFFFFFu;
-    float q = (float)u * 5.9604644775390625e-8f;
-    return u2f(f2u(q) + (u != 0u ? 1u : 0u));   // u == 0: q is +0.0 and stays +0.0
+    const float a = (float)u;
+    return fma(a, c_hi, a * c_lo);
 }
-// u / 65535.0f and u / 255.0f, correctly rounded, via one reciprocal multiply and one residual correction.
-CRY_HD float unorm16_to_float(uint32_t u)
-{
-    const float c = 1.0f / 65535.0f;
-    float a = (float)u;
-    float t = a * c;
-    float r = __builtin_fmaf(-t, 65535.0f, a);
-    return __builtin_fmaf(r, c, t);
-}
-CRY_HD float unorm8_to_float(uint32_t u)
-{
-    const float c = 1.0f / 255.0f;
-    float a = (float)u;
-    float t = a * c;
-    float r = __builtin_fmaf(-t, 255.0f, a);
-    return __builtin_fmaf(r, c, t);
-}
+CRY_HD float d24_to_float(uint32_t texel) { return unorm_decode(texel & 0x00FFFFFFu, u2f(0x33800001u), u2f(0xA77FFFFFu)); }
+CRY_HD float unorm16_to_float(uint32_t u) { return unorm_decode(u, u2f(0x37800080u), u2f(0x27800080u)); }
+CRY_HD float unorm8_to_float(uint32_t u) { return unorm_decode(u, u2f(0x3B808081u), u2f(0xAF7EFEFFu)); }
 CRY_HD uint32_t float_to_unorm16(float x) { return (uint32_t)fma(saturate(x), 65535.0f, 0.5f); }
 CRY_HD uint32_t float_to_unorm8(float x) { return (uint32_t)fma(saturate(x), 255.0f, 0.5f); }
 
@@ -271,8 +258,9 @@ struct Bilin { int i0, j0; float fx, fy; };
 
 CRY_HD int texel_index(float fl, uint32_t dim)
 {
-    // clamp(fl, -2, dim + 1) with NaN -> -2 (fmax returns the non-NaN operand); fl is already integral
-    const float c = __builtin_fminf(__builtin_fmaxf(fl, -2.0f), (float)dim + 1.0f);
+    // clamp(fl, -2, dim) with NaN -> -2 (fmax returns the non-NaN operand); fl is already integral.  A footprint whose
+    // top-left texel lies further out than that consists of out-of-range texels only, and so does its clamped stand-in.
+    const float c = __builtin_fminf(__builtin_fmaxf(fl, -2.0f), (float)dim);
     return (int)c;
 }
 CRY_HD Bilin bilinear_setup(float u, float v, uint32_t w, uint32_t h)

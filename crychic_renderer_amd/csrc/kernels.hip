@@ -60,8 +60,20 @@ __device__ __forceinline__ void tile_origin_2d(uint32_t& bx, uint32_t& by, uint3
 }
 
 // ---- SSAO ------------------------------------------------------------------------------------------------
+// Re-lays the D24 depth plane as decoded {d(x, y), d(x, y+1)} entries with a BORDER guard band (ssao_core.hpp "depth pairs"):
+// one lane per two horizontally adjacent entries (a 16-byte store), rows y = -2 .. H, entries x = -2 .. W+1.
+__global__ __launch_bounds__(256) void depth_pairs_kernel(const uint32_t* __restrict__ depth, f4a* __restrict__ pairs, uint32_t W, uint32_t H)
+{
+    const uint32_t halfPitch = depth_pairs_pitch(W) / 2u;
+    const uint32_t px2 = blockIdx.x * 64u + (threadIdx.x & 63u);
+    const uint32_t py = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (px2 >= halfPitch || py >= H + 3u) return;
+    pairs[py * halfPitch + px2] = depth_pairs_entry2(depth, W, H, 2 * (int)px2 - 2, (int)py - 2);
+}
+
 // Shaders/Ssao.hlsl:117-199 over half-res rows [row0, row1).  EMIT_AO = false builds only the edge workspace.
-template <bool EMIT_AO>
+// PAIRS: the depth taps read the pairs plane of the edge workspace (built by depth_pairs_kernel earlier on the stream).
+template <bool EMIT_AO, bool PAIRS>
 __global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, const u2* __restrict__ normal,
                                                    const uint32_t* __restrict__ depth,
                                                    const uint32_t* __restrict__ randvec,
@@ -75,7 +87,9 @@ __global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, co
     const uint32_t y = row0 + by * 4u + (threadIdx.x >> 6);
     if (x >= w2 || y >= row1) return;
 
-    const SsaoCentre c = ssao_centre(cb, normal, depth, W, H, (int)x, (int)y);
+    const DepthPairs dp{ edge.pairs, depth_pairs_pitch(W) };
+    const DepthD24 dd{ depth, W, H };
+    const SsaoCentre c = PAIRS ? ssao_centre(cb, normal, dp, W, H, (int)x, (int)y) : ssao_centre(cb, normal, depth, W, H, (int)x, (int)y);
     if (edge.nrm) {
         const uint32_t idx = y * w2 + x;
         edge.nrm[idx] = c.nrm_bits;
@@ -83,7 +97,10 @@ __global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, co
         if (x == 0) edge.gcol[y] = normal[(2u * y + 1u) * W];   // texel (0, 2y+1)
         if (y == row0) edge.grow[x] = normal[2u * x + 1u];      // texel (2x+1, 0)
     }
-    if (EMIT_AO) ambient[y * w2 + x] = (uint16_t)ssao_pixel(cb, c, depth, randvec, W, H, x, y, sparseProjTex != 0);
+    if (EMIT_AO) {
+        const uint32_t v = PAIRS ? ssao_pixel(cb, c, dp, randvec, W, H, x, y, sparseProjTex != 0) : ssao_pixel(cb, c, dd, randvec, W, H, x, y, sparseProjTex != 0);
+        ambient[y * w2 + x] = (uint16_t)v;
+    }
 }
 
 // ---- bilateral blur ------------------------------------------------------------------------------------------
@@ -407,13 +424,22 @@ static inline dim3 grid_for(uint32_t width, uint32_t rows, uint32_t rows_per_blo
     return dim3((width + 63u) / 64u, (rows + rows_per_block - 1u) / rows_per_block, 1);
 }
 
+hipError_t launch_depth_pairs(const uint32_t* depth, void* edge_base, uint32_t W, uint32_t H, hipStream_t stream)
+{
+    const EdgePlane e = edge_plane_carve(edge_base, W, H);
+    const dim3 grid((depth_pairs_pitch(W) / 2u + 63u) / 64u, (H + 3u + 3u) / 4u, 1);
+    hipLaunchKernelGGL(depth_pairs_kernel, grid, dim3(256), 0, stream, depth, (f4a*)const_cast<void*>(e.pairs), W, H);
+    return hipGetLastError();
+}
+
 hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, const uint32_t* depth,
                        const uint8_t* randvec, uint16_t* ambient, void* edge_base, uint32_t W, uint32_t H,
-                       uint32_t row0, uint32_t rows, bool emit_ao, hipStream_t stream)
+                       uint32_t row0, uint32_t rows, bool emit_ao, bool use_pairs, hipStream_t stream)
 {
     if (rows == 0) return hipSuccess;
     EdgePlane e{};
     if (edge_base) e = edge_plane_carve(edge_base, W, H);
+    if (use_pairs && !edge_base) return hipErrorInvalidValue;
     dim3 grid = grid_for(W / 2, rows);
     // super-tiles of SX x SY workgroup tiles (64 x 4 half-res pixels each) per XCD; the grid is padded to whole super-tiles
     // 6 x 32 tiles = 384 x 128 half-res pixels (768 x 256 depth texels, 0.8 MB): measured best of 20 shapes at 4K and 8K
@@ -424,12 +450,11 @@ hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, con
     grid.x = (grid.x + SX - 1u) / SX * SX;
     grid.y = (grid.y + SY - 1u) / SY * SY;
     const int sparse = ssao_projtex_is_sparse(cb) ? 1 : 0;
-    if (emit_ao)
-        hipLaunchKernelGGL(ssao_kernel<true>, grid, dim3(256), 0, stream, cb, (const u2*)normal, depth,
-                           (const uint32_t*)randvec, ambient, e, W, H, row0, row0 + rows, SX, SY, sparse);
-    else
-        hipLaunchKernelGGL(ssao_kernel<false>, grid, dim3(256), 0, stream, cb, (const u2*)normal, depth,
-                           (const uint32_t*)randvec, ambient, e, W, H, row0, row0 + rows, SX, SY, sparse);
+#define CRY_LAUNCH_SSAO(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, cb, (const u2*)normal, depth, (const uint32_t*)randvec, ambient, e, W, H, row0, row0 + rows, SX, SY, sparse)
+    if (emit_ao && use_pairs) CRY_LAUNCH_SSAO((ssao_kernel<true, true>));
+    else if (emit_ao) CRY_LAUNCH_SSAO((ssao_kernel<true, false>));
+    else CRY_LAUNCH_SSAO((ssao_kernel<false, false>));
+#undef CRY_LAUNCH_SSAO
     return hipGetLastError();
 }
 

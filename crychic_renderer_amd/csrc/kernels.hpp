@@ -8,9 +8,12 @@ namespace cry {
 
 struct LightParams;
 
+// D24 depth plane -> the decoded, BORDER-padded pairs plane inside the edge workspace (ssao_core.hpp "depth pairs"); whole plane.
+hipError_t launch_depth_pairs(const uint32_t* depth, void* edge_base, uint32_t W, uint32_t H, hipStream_t stream);
+// use_pairs: the taps read the pairs plane (launch_depth_pairs earlier on the same stream) instead of the raw D24 plane.
 hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, const uint32_t* depth,
                        const uint8_t* randvec, uint16_t* ambient, void* edge_base, uint32_t W, uint32_t H,
-                       uint32_t row0, uint32_t rows, bool emit_ao, hipStream_t stream);
+                       uint32_t row0, uint32_t rows, bool emit_ao, bool use_pairs, hipStream_t stream);
 
 // Plain: a self-contained sweep.  Record: same, and stores the per-pixel tap decisions + totalWeight of this
 // direction in the edge workspace.  Replay: uses what a Record sweep of the same direction stored (same geometry).

@@ -28,11 +28,34 @@ struct EdgePlane {
     float* total_h;
     float* total_v;
     uint16_t* spare;   // a third ambient plane: lets an odd number of fused replay iterations end in ambient0 (api.cpp)
+    const void* pairs; // DepthPairs plane (below), depth_pairs_bytes(W, H)
 };
-CRY_HD size_t edge_plane_bytes(uint32_t W, uint32_t H)
+
+// ---- depth pairs -----------------------------------------------------------------------------------------------------
+// The 14 + 1 bilinear depth fetches of a pixel (gsamDepthMap: linear, BORDER 1.0) are the SSAO pass's gather.  On the raw
+// D24 plane a footprint costs two 8-byte loads in two rows, four integer -> float decodes and four BORDER selects: 40 of the
+// ~100 VALU instructions of a tap.  depth_pairs_kernel therefore re-lays the plane once per frame as decoded floats in
+// entries {d(x, y), d(x, y+1)} with a guard band that holds the BORDER value: entry (x, y) for x in [-2, W+1], y in [-2, H].
+// A footprint with top-left texel (i0, j0), indices clamped to [-2, W] x [-2, H] (anything further out addresses only BORDER
+// texels either way), is then ONE 16-byte load of entries (i0, j0) and (i0+1, j0) = {t00, t01, t10, t11}, ready to filter.
+// Decoding is the same exact d24_to_float, so every output bit is unchanged.
+CRY_HD uint32_t depth_pairs_pitch(uint32_t W) { return W + 4u; }                       // entries per row
+CRY_HD size_t depth_pairs_bytes(uint32_t W, uint32_t H) { return (size_t)(W + 4u) * (H + 3u) * 8u; }
+CRY_HD size_t edge_plane_pairs_offset(uint32_t W, uint32_t H)
 {
     size_t w2 = W / 2, h2 = H / 2;
-    return w2 * h2 * 26 + (w2 + h2) * 8;
+    return (w2 * h2 * 26 + (w2 + h2) * 8 + 15) & ~(size_t)15;
+}
+CRY_HD size_t edge_plane_bytes(uint32_t W, uint32_t H) { return edge_plane_pairs_offset(W, H) + depth_pairs_bytes(W, H); }
+// Entries (x, y) and (x + 1, y) of the pairs plane from the D24 plane; x even (so the two texels of a row are one 8-byte load).
+CRY_HD f4a depth_pairs_entry2(const uint32_t* __restrict__ depth, uint32_t W, uint32_t H, int x, int y)
+{
+    const bool inx = (uint32_t)x < W, r0 = (uint32_t)y < H, r1 = (uint32_t)(y + 1) < H;     // W even, x even: x + 1 < W as well
+    const uint32_t cx = inx ? (uint32_t)x : 0u;
+    const RawPair border{ 0x00FFFFFFu, 0x00FFFFFFu };
+    const RawPair a = (inx && r0) ? load_at<RawPair>(depth, (mul24((uint32_t)y, W) + cx) * 4u) : border;
+    const RawPair b = (inx && r1) ? load_at<RawPair>(depth, (mul24((uint32_t)(y + 1), W) + cx) * 4u) : border;
+    return f4a{ d24_to_float(a.lo), d24_to_float(b.lo), d24_to_float(a.hi), d24_to_float(b.hi) };
 }
 CRY_HD EdgePlane edge_plane_carve(void* base, uint32_t W, uint32_t H)
 {
@@ -48,6 +71,7 @@ CRY_HD EdgePlane edge_plane_carve(void* base, uint32_t W, uint32_t H)
     e.gcol = (u2*)(b + n * 24);           // h2 * 8
     e.grow = e.gcol + h2;                 // w2 * 8
     e.spare = (uint16_t*)(b + n * 24 + (w2 + h2) * 8);   // n * 2
+    e.pairs = b + edge_plane_pairs_offset(W, H);
     return e;
 }
 
@@ -89,6 +113,30 @@ CRY_HD float depth_linear_border(const uint32_t* __restrict__ depth, uint32_t W,
     const float t11 = d24_to_float((xb && y1) ? p1.b : 0x00FFFFFFu);
     return bilerp(t00, t10, t01, t11, b.fx, b.fy);
 }
+// The two depth sources of the SSAO pass.  footprint(): the four decoded texels of the bilinear footprint whose top-left
+// texel is (i0, j0), both already clamped to [-2, dim], BORDER texels as 1.0.
+struct DepthD24 {
+    const uint32_t* __restrict__ plane; uint32_t W, H;
+    CRY_HD void footprint(int i0, int j0, float& t00, float& t10, float& t01, float& t11) const
+    {
+        // rows j0, j0+1: one 8-byte load each (texels i0, i0+1), fetched from clamped addresses, border selected after;
+        // the BORDER colour 1.0 is exactly D24 0xFFFFFF: select on the integer texel, then decode unconditionally
+        const uint32_t r0 = (uint32_t)clampi(j0, 0, (int)H - 1), r1 = (uint32_t)clampi(j0 + 1, 0, (int)H - 1);
+        const TexelPair a0 = pair_at(plane, r0, W, i0), a1 = pair_at(plane, r1, W, i0);
+        const bool xa = (uint32_t)i0 < W, xb = (uint32_t)(i0 + 1) < W, y0 = (uint32_t)j0 < H, y1 = (uint32_t)(j0 + 1) < H;
+        t00 = d24_to_float((xa && y0) ? a0.a : 0x00FFFFFFu); t10 = d24_to_float((xb && y0) ? a0.b : 0x00FFFFFFu);
+        t01 = d24_to_float((xa && y1) ? a1.a : 0x00FFFFFFu); t11 = d24_to_float((xb && y1) ? a1.b : 0x00FFFFFFu);
+    }
+};
+struct DepthPairs {
+    const void* __restrict__ base; uint32_t pitch;      // depth_pairs_pitch(W)
+    CRY_HD void footprint(int i0, int j0, float& t00, float& t10, float& t01, float& t11) const
+    {
+        const f4a v = load_at<f4a>(base, (mul24((uint32_t)(j0 + 2), pitch) + (uint32_t)(i0 + 2)) * 8u);
+        t00 = v.x; t01 = v.y; t10 = v.z; t11 = v.w;
+    }
+};
+
 // The same sampler at the centre of half-res pixel (xi, yi) (even W, H): texels 2xi..2xi+1 x 2yi..2yi+1 with
 // weights 1/2; a pixel outside the half-res map only ever addresses border texels.
 CRY_HD float depth_at_half_pixel(const uint32_t* __restrict__ depth, uint32_t W, uint32_t H, int xi, int yi)
@@ -144,6 +192,17 @@ CRY_HD SsaoCentre ssao_centre(const crychic_ssao_constants& cb, const u2* __rest
     c.vz = ndc_to_view(cb, depth_at_half_pixel(depth, W, H, x, y));
     return c;
 }
+// The same from the pairs plane (pixel inside the half-res map): the footprint at (2x, 2y) with weights 1/2.
+CRY_HD SsaoCentre ssao_centre(const crychic_ssao_constants& cb, const u2* __restrict__ normal, const DepthPairs depth,
+                              uint32_t W, uint32_t H, int x, int y)
+{
+    SsaoCentre c;
+    c.nrm_bits = normal_texel_bits(normal, W, H, x, y);
+    float t00, t10, t01, t11;
+    depth.footprint(2 * x, 2 * y, t00, t10, t01, t11);
+    c.vz = ndc_to_view(cb, bilerp(t00, t10, t01, t11, 0.5f, 0.5f));
+    return c;
+}
 
 // gProjTex = Proj * T (CRYCHIC.cpp:828-834,918) has seven structural zeros and a one for every perspective projection:
 //   x' = q.x PT[0] + q.z PT[2],  y' = q.y PT[5] + q.z PT[6],  w' = q.z.
@@ -166,8 +225,9 @@ CRY_HD bool ssao_projtex_is_sparse(const crychic_ssao_constants& cb)
 }
 
 // Ssao.hlsl:117-199 for half-res pixel (x, y); returns the R16_UNORM ambient value.  `sparseProjTex` = ssao_projtex_is_sparse(cb).
+template <class Depth>
 CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c,
-                           const uint32_t* __restrict__ depth, const uint32_t* __restrict__ randvec, uint32_t W,
+                           const Depth depth, const uint32_t* __restrict__ randvec, uint32_t W,
                            uint32_t H, uint32_t x, uint32_t y, bool sparseProjTex)
 {
     const uint32_t w2 = W / 2, h2 = H / 2;
@@ -234,7 +294,7 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
         // gsamDepthMap, both taps: bilinear setup in packed form, the 2 x 2 footprints through the paired loads
         const v2f tx = fma2(tu, (float)W, -0.5f), ty = fma2(tv, (float)H, -0.5f);
         const v2f flx = floor2(tx), fly = floor2(ty);
-        // Fractions: in [0, 1) or NaN (non-finite coordinate); fmax(NaN, 0) = 0.  Texel indices: clamp(floor, -2, dim + 1)
+        // Fractions: in [0, 1) or NaN (non-finite coordinate); fmax(NaN, 0) = 0.  Texel indices: clamp(floor, -2, dim)
         // sends +-inf out of range and NaN to -2, so a non-finite coordinate addresses only BORDER texels on its own axis --
         // which makes all four texels of the footprint the border value, the same result as the scalar sampler's joint
         // "bad => (-2, -2)" rule (the CLAMP samplers, where the two rules differ, keep the scalar bilinear_setup).
@@ -242,21 +302,10 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
         const v2f fy = v2f{ __builtin_fmaxf(ty.x - fly.x, 0.0f), __builtin_fmaxf(ty.y - fly.y, 0.0f) };
         const int i0a = texel_index(flx.x, W), j0a = texel_index(fly.x, H);
         const int i0b = texel_index(flx.y, W), j0b = texel_index(fly.y, H);
-        v2f t00, t10, t01, t11;
-        {
-            const uint32_t r0 = (uint32_t)clampi(j0a, 0, (int)H - 1), r1 = (uint32_t)clampi(j0a + 1, 0, (int)H - 1);
-            const TexelPair a0 = pair_at(depth, r0, W, i0a), a1 = pair_at(depth, r1, W, i0a);
-            const bool xa = (uint32_t)i0a < W, xb = (uint32_t)(i0a + 1) < W, y0 = (uint32_t)j0a < H, y1 = (uint32_t)(j0a + 1) < H;
-            t00.x = d24_to_float((xa && y0) ? a0.a : 0x00FFFFFFu); t10.x = d24_to_float((xb && y0) ? a0.b : 0x00FFFFFFu);
-            t01.x = d24_to_float((xa && y1) ? a1.a : 0x00FFFFFFu); t11.x = d24_to_float((xb && y1) ? a1.b : 0x00FFFFFFu);
-        }
-        {
-            const uint32_t r0 = (uint32_t)clampi(j0b, 0, (int)H - 1), r1 = (uint32_t)clampi(j0b + 1, 0, (int)H - 1);
-            const TexelPair a0 = pair_at(depth, r0, W, i0b), a1 = pair_at(depth, r1, W, i0b);
-            const bool xa = (uint32_t)i0b < W, xb = (uint32_t)(i0b + 1) < W, y0 = (uint32_t)j0b < H, y1 = (uint32_t)(j0b + 1) < H;
-            t00.y = d24_to_float((xa && y0) ? a0.a : 0x00FFFFFFu); t10.y = d24_to_float((xb && y0) ? a0.b : 0x00FFFFFFu);
-            t01.y = d24_to_float((xa && y1) ? a1.a : 0x00FFFFFFu); t11.y = d24_to_float((xb && y1) ? a1.b : 0x00FFFFFFu);
-        }
+        float a00, a10, a01, a11, b00, b10, b01, b11;
+        depth.footprint(i0a, j0a, a00, a10, a01, a11);
+        depth.footprint(i0b, j0b, b00, b10, b01, b11);
+        const v2f t00{ a00, b00 }, t10{ a10, b10 }, t01{ a01, b01 }, t11{ a11, b11 };
         const v2f zndc = lerp2(lerp2(t00, t10, fx), lerp2(t01, t11, fx), fy);
         const v2f rz = B * rcp2(zndc - A);                                        // :164-165
         const v2f sc = rz * rqz;                                                  // :171

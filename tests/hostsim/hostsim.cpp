@@ -43,24 +43,43 @@ void hs_eval_array(int kind, size_t n, const float* in, const float* in2, float*
     }
 }
 
-void hs_ssao(const crychic_ssao_constants* cb, const void* normal, const uint32_t* depth, const uint8_t* randvec,
-             uint16_t* ambient, void* edge_base, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows)
+// use_pairs != 0: the product's default path -- build the decoded depth-pairs plane in the edge workspace (the body of
+// depth_pairs_kernel) and let the taps gather from it; 0: taps on the raw D24 plane (what runs without a workspace).
+void hs_ssao_path(const crychic_ssao_constants* cb, const void* normal, const uint32_t* depth, const uint8_t* randvec,
+                  uint16_t* ambient, void* edge_base, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows, int use_pairs)
 {
     const uint32_t w2 = W / 2;
     EdgePlane e{};
     if (edge_base) e = edge_plane_carve(edge_base, W, H);
     const u2* nrm = (const u2*)normal;
+    const bool pairs = use_pairs && edge_base;
+    if (pairs) {
+        f4a* out = (f4a*)const_cast<void*>(e.pairs);
+        const uint32_t halfPitch = depth_pairs_pitch(W) / 2u;
+        for (uint32_t py = 0; py < H + 3u; ++py)
+            for (uint32_t px2 = 0; px2 < halfPitch; ++px2) out[py * halfPitch + px2] = depth_pairs_entry2(depth, W, H, 2 * (int)px2 - 2, (int)py - 2);
+    }
+    const DepthPairs dp{ e.pairs, depth_pairs_pitch(W) };
+    const DepthD24 dd{ depth, W, H };
+    const bool sparse = ssao_projtex_is_sparse(*cb);
     for (uint32_t y = row0; y < row0 + rows; ++y)
         for (uint32_t x = 0; x < w2; ++x) {
-            const SsaoCentre c = ssao_centre(*cb, nrm, depth, W, H, (int)x, (int)y);
+            const SsaoCentre c = pairs ? ssao_centre(*cb, nrm, dp, W, H, (int)x, (int)y) : ssao_centre(*cb, nrm, depth, W, H, (int)x, (int)y);
             if (e.nrm) {
                 e.nrm[y * w2 + x] = c.nrm_bits;
                 e.vz[y * w2 + x] = c.vz;
                 if (x == 0) e.gcol[y] = nrm[(2u * y + 1u) * W];
                 if (y == row0) e.grow[x] = nrm[2u * x + 1u];
             }
-            if (ambient) ambient[y * w2 + x] = (uint16_t)ssao_pixel(*cb, c, depth, (const uint32_t*)randvec, W, H, x, y, ssao_projtex_is_sparse(*cb));
+            if (ambient)
+                ambient[y * w2 + x] = (uint16_t)(pairs ? ssao_pixel(*cb, c, dp, (const uint32_t*)randvec, W, H, x, y, sparse)
+                                                       : ssao_pixel(*cb, c, dd, (const uint32_t*)randvec, W, H, x, y, sparse));
         }
+}
+void hs_ssao(const crychic_ssao_constants* cb, const void* normal, const uint32_t* depth, const uint8_t* randvec,
+             uint16_t* ambient, void* edge_base, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows)
+{
+    hs_ssao_path(cb, normal, depth, randvec, ambient, edge_base, W, H, row0, rows, 1);
 }
 
 void hs_blur(const crychic_ssao_constants* cb, void* edge_base, const uint16_t* in, uint16_t* out, uint32_t W,

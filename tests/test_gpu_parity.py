@@ -90,6 +90,12 @@ def test_ssao_bit_exact(ctx, built_lib, oracle, W, H):
     got = dev_u16(c.a0)
     assert np.array_equal(got, ref), "ambient differs in %d of %d pixels" % ((got != ref).sum(), ref.size)
     assert ref.min() < 65535  # the scene really occludes something
+    # without a workspace the taps gather from the raw D24 plane instead of the decoded depth-pairs plane: same bits
+    c.a0.zero_()
+    check(lib.crychic_ssao(ctx.handle, C.byref(c.consts.ssao_cb), ptr(c.dev["normal"]), ptr(c.dev["depth"]),
+                           ptr(c.dev["randvec"]), ptr(c.a0), None, W, H, 0, H // 2, stream(ctx)))
+    torch.cuda.synchronize()
+    assert np.array_equal(dev_u16(c.a0), ref)
 
 
 @pytest.mark.parametrize("W,H", SIZES)

@@ -27,6 +27,11 @@ def test_ssao_and_blur_chain(built_lib, oracle, hostsim, W, H):
     got, edge = hostsim.ssao(c.ssao_cb, p["normal"], p["depth"], p["randvec"], eb)
     assert np.array_equal(got, ref)
     assert ref.min() < 65535
+    # the taps on the raw D24 plane (no workspace) and on the decoded depth-pairs plane (default) are the same bits
+    raw, edge_raw = hostsim.ssao(c.ssao_cb, p["normal"], p["depth"], p["randvec"], eb, pairs=False)
+    assert np.array_equal(raw, ref)
+    n26 = (W // 2) * (H // 2) * 26 + (W // 2 + H // 2) * 8
+    assert np.array_equal(edge[:n26], edge_raw[:n26])      # centre normals / depths identical either way
     # blur on the SSAO output and on noise (noise exercises every accept/reject combination)
     rng = np.random.default_rng(W * 7 + H)
     for start in (ref, rng.integers(0, 65536, size=ref.shape, dtype=np.uint16)):
