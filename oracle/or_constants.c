@@ -5,10 +5,26 @@
  */
 #include "crychic_oracle.h"
 #include "or_math.h"
+#ifdef _OPENMP
 #include <omp.h>
+#endif
 
-int or_num_threads(void) { return omp_get_max_threads(); }
-void or_set_num_threads(int n) { omp_set_num_threads(n); }
+int or_num_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;   /* the sanitizer build runs single-threaded */
+#endif
+}
+void or_set_num_threads(int n)
+{
+#ifdef _OPENMP
+    omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
 
 /* MSVC CRT rand() (ucrt rand.cpp): state = state * 214013 + 2531011; return (state >> 16) & 0x7fff. */
 int or_msvc_rand(uint32_t* state)

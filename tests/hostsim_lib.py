@@ -13,7 +13,25 @@ CSRC = os.path.join(ROOT, "crychic_renderer_amd", "csrc")
 CLANG = "/opt/rocm/lib/llvm/bin/clang++"
 
 
+SANITIZE = os.environ.get("CRYCHIC_SANITIZE") == "1"      # tools/sanitize.sh: ASan + UBSan build of the kernel bodies
+SAN_DIR = os.path.join(ROOT, "tests", "hostsim", "_san")
+SAN_FLAGS = ["-O1", "-g", "-fno-omit-frame-pointer", "-fsanitize=address,undefined,float-cast-overflow", "-fno-sanitize-recover=all", "-shared-libsan"]
+
+
+def build_sanitized(name, sources, extra=()):
+    """clang ASan + UBSan shared object under tests/hostsim/_san (loaded with the sanitizer runtime preloaded: tools/sanitize.sh)."""
+    os.makedirs(SAN_DIR, exist_ok=True)
+    out = os.path.join(SAN_DIR, name)
+    deps = list(sources) + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hpp")] + [os.path.join(ROOT, "include", "crychic_hip.h")]
+    if not os.path.exists(out) or any(os.path.getmtime(d) > os.path.getmtime(out) for d in deps):
+        subprocess.run([CLANG, "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-mfma"] + SAN_FLAGS + list(extra) +
+                       ["-I", os.path.join(ROOT, "include"), "-I", CSRC] + list(sources) + ["-o", out], check=True)
+    return out
+
+
 def build():
+    if SANITIZE:
+        return build_sanitized("libhostsim.so", [SRC])
     deps = [SRC] + [os.path.join(CSRC, f) for f in ("devmath.hpp", "ssao_core.hpp", "light_core.hpp", "raster_core.hpp")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         subprocess.run([CLANG, "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-mfma",

@@ -39,7 +39,13 @@ class OrCamera(C.Structure):
                 ("aspect", C.c_float), ("nearZ", C.c_float), ("farZ", C.c_float)]
 
 
+SANITIZE = os.environ.get("CRYCHIC_SANITIZE") == "1"      # tools/sanitize.sh: load the ASan + UBSan builds instead
+
+
 def build(force=False):
+    if SANITIZE:
+        subprocess.run(["make", "-C", ORACLE_DIR, "asan"], check=True, stdout=subprocess.DEVNULL)
+        return os.path.join(ORACLE_DIR, "_san", "liboracle.so")
     srcs = [os.path.join(ORACLE_DIR, f) for f in os.listdir(ORACLE_DIR) if f.endswith((".c", ".h")) or f == "Makefile"]
     if force or not os.path.exists(LIB) or any(os.path.getmtime(s) > os.path.getmtime(LIB) for s in srcs):
         subprocess.run(["make", "-C", ORACLE_DIR, "-B", "liboracle.so"], check=True, stdout=subprocess.DEVNULL)
