@@ -293,7 +293,7 @@ __global__ __launch_bounds__(256) void blur_replay_pair_kernel(crychic_ssao_cons
 
 // ---- deferred lighting -----------------------------------------------------------------------------------------
 // Shaders/DeferredShading.hlsl:23-101 as a full-screen pass over rows [row0, row1), masked by depth < 1.
-template <bool ZERO_RADIUS>
+template <bool ZERO_RADIUS, bool FIX>
 __global__ __launch_bounds__(256) void light_kernel(LightParams P, const f4a* __restrict__ g0,
                                                     const f4a* __restrict__ g1, const f4a* __restrict__ g2,
                                                     const uint32_t* __restrict__ depth,
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void light_kernel(LightParams P, const f4a* __
     // coverage: the reference re-rasterises the opaque items with LESS against depth cleared to 1.0
     // (CRYCHIC.cpp:248,273) -- exactly the pixels whose normal/depth pass depth is below the clear value.
     if ((depth[idx] & 0x00FFFFFFu) < 0x00FFFFFFu) {
-        lit = light_pixel<ZERO_RADIUS>(P, g0[idx], g1[idx], g2[idx], ambient, cube);
+        lit = light_pixel<ZERO_RADIUS, NoPointLights, FIX>(P, g0[idx], g1[idx], g2[idx], ambient, cube);
     } else if (P.flags & CRYCHIC_LIGHT_SKY) {
         lit = sky_pixel(P, cube, x, y);
     } else {
@@ -388,18 +388,18 @@ __global__ __launch_bounds__(256) void light_points_kernel(LightParams P, const 
     // 3. shade
     f4 lit;
     if (covered) {
-        auto culled = [&](f3 pos, f3 albedo, float roughness, float metalness, f3 normal, f3 view, f3& result) {
+        auto culled = [&](f3 pos, f3 albedo, float roughness, float metalness, f3 normal, f3 view, f3& result, bool fixQ3, bool fixQ4) {
             const uint32_t words = (P.numPointLights + 31u) >> 5;
             for (uint32_t w = 0; w < words; ++w) {
                 uint32_t m = s_mask[w];
                 while (m) {
                     const uint32_t b = (uint32_t)__builtin_ctz(m);
                     m &= m - 1u;
-                    pbr_point_light(P.pointLights[w * 32u + b], pos, albedo, roughness, metalness, normal, view, result);
+                    pbr_point_light(P.pointLights[w * 32u + b], pos, albedo, roughness, metalness, normal, view, result, fixQ3, fixQ4);
                 }
             }
         };
-        lit = light_pixel<ZERO_RADIUS>(P, G0, g1[idx], g2[idx], ambient, cube, culled);
+        lit = light_pixel<ZERO_RADIUS, decltype(culled), true>(P, G0, g1[idx], g2[idx], ambient, cube, culled);
     } else if (P.flags & CRYCHIC_LIGHT_SKY) {
         lit = sky_pixel(P, cube, x, y);
     } else {
@@ -504,14 +504,12 @@ hipError_t launch_light(const LightParams& P, const float* g0, const float* g1, 
                                depth, ambient, (const uint32_t*)cube, (uint32_t*)out, (f4a*)radiance, row0, row0 + rows);
         return hipGetLastError();
     }
-    if (P.pcfSearchRadius == 0.0f)
-        hipLaunchKernelGGL(light_kernel<true>, grid, dim3(256), 0, stream, P, (const f4a*)g0, (const f4a*)g1,
-                           (const f4a*)g2, depth, ambient, (const uint32_t*)cube, (uint32_t*)out, (f4a*)radiance, row0,
-                           row0 + rows);
-    else
-        hipLaunchKernelGGL(light_kernel<false>, grid, dim3(256), 0, stream, P, (const f4a*)g0, (const f4a*)g1,
-                           (const f4a*)g2, depth, ambient, (const uint32_t*)cube, (uint32_t*)out, (f4a*)radiance, row0,
-                           row0 + rows);
+    const bool fix = (P.flags & (CRYCHIC_FIX_Q1 | CRYCHIC_FIX_Q3 | CRYCHIC_FIX_Q4)) != 0;
+#define CRY_LAUNCH_LIGHT(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, P, (const f4a*)g0, (const f4a*)g1, (const f4a*)g2, depth, ambient, \
+                                               (const uint32_t*)cube, (uint32_t*)out, (f4a*)radiance, row0, row0 + rows)
+    if (P.pcfSearchRadius == 0.0f) { if (fix) CRY_LAUNCH_LIGHT((light_kernel<true, true>)); else CRY_LAUNCH_LIGHT((light_kernel<true, false>)); }
+    else { if (fix) CRY_LAUNCH_LIGHT((light_kernel<false, true>)); else CRY_LAUNCH_LIGHT((light_kernel<false, false>)); }
+#undef CRY_LAUNCH_LIGHT
     return hipGetLastError();
 }
 

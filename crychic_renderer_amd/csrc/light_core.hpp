@@ -115,9 +115,10 @@ CRY_HD float pow5(float x) { float x2 = x * x, x4 = x2 * x2; return x4 * x; }
 
 // GetPBRDesc (PBR.hlsl:72-88) + GetBRDF (:45-70) for light direction `lightDir`; adds scale * brdf * (strength * nDotl * att)
 // in the shader's association order.  Directional lights: att = 1 is skipped (POINT = false).
+// fixQ3 / fixQ4: the CRYCHIC_FIX_Q3 / Q4 forms (crychic_hip.h); both false = the reference as written.
 template <bool POINT>
 CRY_HD void pbr_light(f3 lightDir, const float* strength, float att, f3 albedo, float roughness, float metalness, f3 normal,
-                      f3 view, float scale, f3& result)
+                      f3 view, float scale, f3& result, bool fixQ3 = false, bool fixQ4 = false)
 {
     const f3 halfVec = normalize3(f3{ view.x + lightDir.x, view.y + lightDir.y, view.z + lightDir.z });
     const float hDotv = maxnn(dot3(halfVec, view), 0.001f);
@@ -135,7 +136,7 @@ CRY_HD void pbr_light(f3 lightDir, const float* strength, float att, f3 albedo, 
     // GeometrySmith :29-38 (true nDotv)
     const float k = 0.125f * (roughness + 1.0f) * (roughness + 1.0f);
     const float G = divf(nDotv, fma(nDotv, 1.0f - k, k)) * divf(nDotl, fma(nDotl, 1.0f - k, k));
-    const float rdenom = rcp(nDotl * nDotvQ);
+    const float rdenom = rcp(nDotl * (fixQ3 ? nDotv : nDotvQ));
     const float invPi = 1.0f / CRY_PBR_PI;
     const float oneMinusMetal = 1.0f - metalness;
 
@@ -149,7 +150,7 @@ CRY_HD void pbr_light(f3 lightDir, const float* strength, float att, f3 albedo, 
         fs = fs * rdenom;
         const float fd = alb[ch] * invPi;
         const float kd = (1.0f - F) * oneMinusMetal;
-        const float brdf = fma(F, fs, kd * fd);  // ks = F (Q4)
+        const float brdf = fixQ4 ? kd * fd + fs : fma(F, fs, kd * fd);  // ks = F (Q4)
         float lightStrength = strength[ch] * nDotl;           // :104 / :118
         if (POINT) lightStrength = lightStrength * att;       // :120
         res[ch] = fma(scale * brdf, lightStrength, res[ch]);  // :105 / :122
@@ -159,16 +160,16 @@ CRY_HD void pbr_light(f3 lightDir, const float* strength, float att, f3 albedo, 
 
 // One directional light of PBRShading (PBR.hlsl:99-106).
 CRY_HD void pbr_dir_light(const crychic_light& L, f3 albedo, float roughness, float metalness, f3 normal, f3 view,
-                          float shadow, f3& result)
+                          float shadow, f3& result, bool fixQ3 = false, bool fixQ4 = false)
 {
     pbr_light<false>(f3{ -L.Direction[0], -L.Direction[1], -L.Direction[2] }, L.Strength, 1.0f, albedo, roughness, metalness, normal,
-                     view, pow5(shadow), result);
+                     view, pow5(shadow), result, fixQ3, fixQ4);
 }
 
 // Point light, BUILD-DEFINED EXTENSION: the reference's branch (PBR.hlsl:109-124) is dead code; enabled as evidently
 // intended -- range test d > FalloffEnd (LightingUtil.hlsl:104-105), l /= d, linear attenuation, shadowFactor 1.
 CRY_HD void pbr_point_light(const crychic_light& L, f3 pos, f3 albedo, float roughness, float metalness, f3 normal, f3 view,
-                            f3& result)
+                            f3& result, bool fixQ3 = false, bool fixQ4 = false)
 {
     const f3 l{ L.Position[0] - pos.x, L.Position[1] - pos.y, L.Position[2] - pos.z };
     const float d = len_from_sq(dot3(l, l));
@@ -176,7 +177,7 @@ CRY_HD void pbr_point_light(const crychic_light& L, f3 pos, f3 albedo, float rou
     const float rd = rcp(d);
     const f3 ln{ l.x * rd, l.y * rd, l.z * rd };
     const float att = saturate(divf(L.FalloffEnd - d, L.FalloffEnd - L.FalloffStart));
-    pbr_light<true>(ln, L.Strength, att, albedo, roughness, metalness, normal, view, 1.0f, result);
+    pbr_light<true>(ln, L.Strength, att, albedo, roughness, metalness, normal, view, 1.0f, result, fixQ3, fixQ4);
 }
 
 // TextureCube.Sample(gsamLinearWrap, r): D3D major-axis face selection (ties x >= y >= z), bilinear inside the
@@ -222,21 +223,24 @@ CRY_HD float ambient_linear_clamp(const uint16_t* __restrict__ a, uint32_t w2, u
 
 // DeferredShading.hlsl:23-101 for one covered pixel.
 struct NoPointLights {
-    CRY_HD void operator()(f3, f3, float, float, f3, f3, f3&) const {}
+    CRY_HD void operator()(f3, f3, float, float, f3, f3, f3&, bool, bool) const {}
 };
 // Iterates every point light of the buffer (what the oracle does); the tiled kernel substitutes a culled iteration.
 struct AllPointLights {
     const crychic_light* lights; uint32_t n;
-    CRY_HD void operator()(f3 pos, f3 albedo, float roughness, float metalness, f3 normal, f3 view, f3& result) const
+    CRY_HD void operator()(f3 pos, f3 albedo, float roughness, float metalness, f3 normal, f3 view, f3& result, bool fixQ3, bool fixQ4) const
     {
-        for (uint32_t i = 0; i < n; ++i) pbr_point_light(lights[i], pos, albedo, roughness, metalness, normal, view, result);
+        for (uint32_t i = 0; i < n; ++i) pbr_point_light(lights[i], pos, albedo, roughness, metalness, normal, view, result, fixQ3, fixQ4);
     }
 };
 
-template <bool ZERO_RADIUS, class PointLights = NoPointLights>
+// FIX: a compile-time promise that P.flags may carry CRYCHIC_FIX_* bits; false = the reference as written, with no trace of
+// the switches in the instantiation the benchmark runs.
+template <bool ZERO_RADIUS, class PointLights = NoPointLights, bool FIX = false>
 CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16_t* __restrict__ ambient,
                       const uint32_t* __restrict__ cube, PointLights pointLights = PointLights())
 {
+    const bool fixQ1 = FIX && (P.flags & CRYCHIC_FIX_Q1), fixQ3 = FIX && (P.flags & CRYCHIC_FIX_Q3), fixQ4 = FIX && (P.flags & CRYCHIC_FIX_Q4);
     const f3 posW{ G0.x, G0.y, G0.z };                         // GBuffer.hlsl:37-41
     const float metalness = G0.w;
     const f3 albedo{ G1.x, G1.y, G1.z };
@@ -288,7 +292,9 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
             return pcf_poisson<ZERO_RADIUS, false>(P.shadow[k], P.shadowDim, spx, spy, spz, spw, P.pcfSearchRadius);
         };
         const float a = cascade(j);
-        if (j < 3) shadow0 = 0.5f * (a + cascade(j + 1));      // :66
+        const float radiusJ = j == 0 ? 30.0f : (j == 1 ? 50.0f : (j == 2 ? 80.0f : 100.0f));
+        const bool blend = j < 3 && (!fixQ1 || __builtin_fabsf(distance - radiusJ) < 5.0f);   // Q1: as written, every j < 3 blends
+        if (blend) shadow0 = 0.5f * (a + cascade(j + 1));      // :66
         else shadow0 = a;                                       // :73
     }
 
@@ -296,8 +302,8 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
 
     f3 direct{ 0.0f, 0.0f, 0.0f };
     for (int i = 0; i < P.numDirLights; ++i)                    // PBR.hlsl:99-106; shadowFactors[i>0] == 1 (:46-51)
-        pbr_dir_light(P.Lights[i], albedo, roughness, metalness, normalW, view, i == 0 ? shadow0 : 1.0f, direct);
-    pointLights(posW, albedo, roughness, metalness, normalW, view, direct);   // extension; a no-op in the reference configuration
+        pbr_dir_light(P.Lights[i], albedo, roughness, metalness, normalW, view, i == 0 ? shadow0 : 1.0f, direct, fixQ3, fixQ4);
+    pointLights(posW, albedo, roughness, metalness, normalW, view, direct, fixQ3, fixQ4);   // extension; a no-op in the reference configuration
 
     const float invGamma = 1.0f / 2.2f;
     f4 lit;

@@ -177,6 +177,15 @@ int crychic_ssao_compute(crychic_ctx* ctx, const crychic_ssao_constants* cb, con
 
 /* ---- deferred lighting (DeferredShading.hlsl:PS, Shaders/DeferredShading.hlsl:23-101) ------------------ */
 #define CRYCHIC_LIGHT_SKY 1u /* fill uncovered pixels from the cubemap (sky.hlsl:21-47) instead of the clear colour */
+/* The reference's shader quirks are reproduced by default (SURVEY.md quirk checklist); each switch selects the evidently
+ * intended form instead, for callers that want the fixed maths (parity is then against this repo's oracle with the same flag):
+ *   Q1  DeferredShading.hlsl:60 `abs(distance - radius[j] < 5.0f)` (abs of a bool: always blends cascades j and j+1)
+ *       -> `abs(distance - radius[j]) < 5.0f`, the form of the forward shader (Default.hlsl:131)
+ *   Q3  PBR.hlsl:58,66 the specular denominator uses hDotv where nDotv is meant -> nDotl * nDotv
+ *   Q4  PBR.hlsl:61-68 `ks * fs` with fs already holding F (Fresnel applied twice) -> kd * fd + fs */
+#define CRYCHIC_FIX_Q1 0x100u
+#define CRYCHIC_FIX_Q3 0x200u
+#define CRYCHIC_FIX_Q4 0x400u
 
 /* Full-screen replacement of the geometry re-draw at CRYCHIC.cpp:238-273 over full-res rows
  * [row0, row0+rows): pixels with depth < 1.0 are lit, the others get Colors::LightSteelBlue

@@ -163,8 +163,9 @@ float or_pcf_search_radius(uint32_t shadowWidth, int literal);
 
 /* Shaders/DeferredShading.hlsl:23-101 as a full-screen pass masked by depth < 1.
  * ambient may be NULL (SSAO off: ambientAccess = 1).  radiance_out (optional) receives litColor before
- * UNORM8 quantisation as 4 floats per pixel.  Uncovered pixels get clear_rgba8 (CRYCHIC.cpp:247) or, when
- * sky != 0, the sky cubemap along the view ray (Shaders/sky.hlsl:21-47). */
+ * UNORM8 quantisation as 4 floats per pixel.  `sky` is a flag word: bit 0 = uncovered pixels get the sky cubemap along
+ * the view ray (Shaders/sky.hlsl:21-47) instead of the clear colour (CRYCHIC.cpp:247); 0x100 / 0x200 / 0x400 select the
+ * evidently intended forms of quirks Q1 / Q3 / Q4 (same bits as CRYCHIC_FIX_* of the product's ABI); 0 = as written. */
 void or_deferred_light(const or_pass_constants* cb, const float* g0, const float* g1, const float* g2,
                        const uint32_t* depth, const uint16_t* ambient, const uint32_t* const shadow[4],
                        uint32_t shadowDim, const uint8_t* cube, uint32_t cubeDim, uint8_t* out_rgba8,

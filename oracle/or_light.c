@@ -81,8 +81,12 @@ static inline float ndf_ggx(const float n[3], const float h[3], float a)
 static inline float geometry_schlick_ggx(float nDotvec, float k) { return or_div(nDotvec, fmaf(nDotvec, 1.0f - k, k)); }
 
 /* One directional light: PBR.hlsl:72-88 (GetPBRDesc), :45-70 (GetBRDF), :99-106 (PBRShading loop body). */
+#define OR_FIX_Q1 0x100 /* cascade blend only within 5 units of the cascade radius (Default.hlsl:131's form) */
+#define OR_FIX_Q3 0x200 /* specular denominator nDotl * nDotv */
+#define OR_FIX_Q4 0x400 /* brdf = kd * fd + fs */
+
 static void pbr_light(const float lightDir[3], const float strength[3], const float albedo[3], float roughness, float metalness,
-                      const float normal[3], const float view[3], float shadowTerm, float result[3])
+                      const float normal[3], const float view[3], float shadowTerm, int flags, float result[3])
 {
     float vl[3] = { view[0] + lightDir[0], view[1] + lightDir[1], view[2] + lightDir[2] }, halfVec[3];
     or_normalize3(vl, halfVec);
@@ -96,7 +100,8 @@ static void pbr_light(const float lightDir[3], const float strength[3], const fl
     float k = 0.125f * (roughness + 1.0f) * (roughness + 1.0f);
     float G = geometry_schlick_ggx(nDotv, k) * geometry_schlick_ggx(nDotl, k); /* true nDotv :29-38 */
     float s5 = shadowTerm;
-    float rdenom = or_rcp(nDotl * nDotvQ);    /* PBR.hlsl:66 `/ (nDotl * nDotv)`, the same quotient for every channel */
+    /* PBR.hlsl:66 `/ (nDotl * nDotv)` with the local nDotv = hDotv (Q3), the same quotient for every channel */
+    float rdenom = or_rcp(nDotl * ((flags & OR_FIX_Q3) ? nDotv : nDotvQ));
     for (int c = 0; c < 3; ++c) {
         float f0 = or_lerp(0.04f, albedo[c], metalness);
         float F = fmaf(1.0f - f0, fr, f0);
@@ -105,17 +110,17 @@ static void pbr_light(const float lightDir[3], const float strength[3], const fl
         float fd = albedo[c] * (1.0f / OR_PI);
         float ks = F;                         /* quirk Q4: F applied twice */
         float kd = (1.0f - F) * (1.0f - metalness);
-        float brdf = fmaf(ks, fs, kd * fd);
+        float brdf = (flags & OR_FIX_Q4) ? kd * fd + fs : fmaf(ks, fs, kd * fd);
         float irradiance = strength[c] * nDotl;
         result[c] = fmaf(s5 * brdf, irradiance, result[c]);
     }
 }
 
 static void pbr_dir_light(const or_light* L, const float albedo[3], float roughness, float metalness,
-                          const float normal[3], const float view[3], float shadow, float result[3])
+                          const float normal[3], const float view[3], float shadow, int flags, float result[3])
 {
     float lightDir[3] = { -L->Direction[0], -L->Direction[1], -L->Direction[2] };   /* PBR.hlsl:101 */
-    pbr_light(lightDir, L->Strength, albedo, roughness, metalness, normal, view, pow5(shadow) /* :105 */, result);
+    pbr_light(lightDir, L->Strength, albedo, roughness, metalness, normal, view, pow5(shadow) /* :105 */, flags, result);
 }
 
 /* BUILD-DEFINED EXTENSION (BASELINE configs[4], parity unpinned): the reference's point-light branch (PBR.hlsl:109-124) does
@@ -123,7 +128,7 @@ static void pbr_dir_light(const or_light* L, const float albedo[3], float roughn
  * intended: l = Position - pos, d = |l|, range test d > FalloffEnd -> no contribution (LightingUtil.hlsl:104-105 and the
  * spot branch :133-137), l /= d, BRDF as for directional lights, strength * nDotl * CalcAttenuation, shadowFactor 1. */
 static void pbr_point_light(const or_light* L, const float pos[3], const float albedo[3], float roughness, float metalness,
-                            const float normal[3], const float view[3], float result[3])
+                            const float normal[3], const float view[3], int flags, float result[3])
 {
     float l[3] = { L->Position[0] - pos[0], L->Position[1] - pos[1], L->Position[2] - pos[2] };
     float d = or_len(or_dot3(l, l));
@@ -142,7 +147,7 @@ static void pbr_point_light(const or_light* L, const float pos[3], const float a
     float fr = pow5(or_saturate(1.0f - nDotvQ));
     float k = 0.125f * (roughness + 1.0f) * (roughness + 1.0f);
     float G = geometry_schlick_ggx(nDotv, k) * geometry_schlick_ggx(nDotl, k);
-    float rdenom = or_rcp(nDotl * nDotvQ);
+    float rdenom = or_rcp(nDotl * ((flags & OR_FIX_Q3) ? nDotv : nDotvQ));
     for (int c = 0; c < 3; ++c) {
         float f0 = or_lerp(0.04f, albedo[c], metalness);
         float F = fmaf(1.0f - f0, fr, f0);
@@ -150,7 +155,7 @@ static void pbr_point_light(const or_light* L, const float pos[3], const float a
         fs = fs * rdenom;
         float fd = albedo[c] * (1.0f / OR_PI);
         float kd = (1.0f - F) * (1.0f - metalness);
-        float brdf = fmaf(F, fs, kd * fd);
+        float brdf = (flags & OR_FIX_Q4) ? kd * fd + fs : fmaf(F, fs, kd * fd);
         float lightStrength = L->Strength[c] * nDotl;      /* PBR.hlsl:118 */
         lightStrength = lightStrength * att;               /* :120 */
         result[c] = fmaf(1.0f * brdf, lightStrength, result[c]);   /* :122 with shadowFactor[i] = 1 */
@@ -165,7 +170,7 @@ static void cube4(const uint8_t* cube, uint32_t dim, const float dir[3], float r
 static void light_pixel(const or_pass_constants* cb, const float* g0, const float* g1, const float* g2,
                         const uint16_t* ambient, const uint32_t* const shadow[4], uint32_t shadowDim,
                         const uint8_t* cube, uint32_t cubeDim, uint32_t W, uint32_t H, size_t idx,
-                        int numDirLights, float pcfRadius, const or_light* pointLights, uint32_t numPointLights, float lit[4])
+                        int numDirLights, float pcfRadius, const or_light* pointLights, uint32_t numPointLights, int flags, float lit[4])
 {
     /* DeferredShading.hlsl:25-30: the anisotropic-wrap fetch at exact texel centres is the texel itself. */
     const float* G0 = g0 + idx * 4; const float* G1 = g1 + idx * 4; const float* G2 = g2 + idx * 4;
@@ -203,6 +208,7 @@ static void light_pixel(const or_pass_constants* cb, const float* g0, const floa
         /* :60 `abs(distance - radius[j] < 5.0f)` is abs() of a bool (quirk Q1): it is 1 whenever
          * distance < radius[j], so the blend branch is taken for every j < 3. */
         int blendTerm = (distance - radius[j] < 5.0f) ? 1 : 0;
+        if (flags & OR_FIX_Q1) blendTerm = fabsf(distance - radius[j]) < 5.0f;   /* the intended test, Default.hlsl:131 */
         if (j < 3 && distance < radius[j] && blendTerm != 0) {
             float sp0[4], sp1[4];
             or_mul_v4_m(pos4, cb->ShadowTransforms[j], sp0);          /* :62 */
@@ -223,9 +229,9 @@ static void light_pixel(const or_pass_constants* cb, const float* g0, const floa
 
     float direct[3] = { 0.0f, 0.0f, 0.0f };
     for (int i = 0; i < numDirLights; ++i)                            /* PBR.hlsl:99-106; NUM_DIR_LIGHTS (Q6) */
-        pbr_dir_light(&cb->Lights[i], albedo, roughness, metalness, normalW, view, shadowFactors[i], direct);
+        pbr_dir_light(&cb->Lights[i], albedo, roughness, metalness, normalW, view, shadowFactors[i], flags, direct);
     for (uint32_t i = 0; i < numPointLights; ++i)                     /* extension: NUM_POINT_LIGHTS lights from a separate buffer */
-        pbr_point_light(&pointLights[i], posW, albedo, roughness, metalness, normalW, view, direct);
+        pbr_point_light(&pointLights[i], posW, albedo, roughness, metalness, normalW, view, flags, direct);
     for (int c = 0; c < 3; ++c) {
         float d = or_div(direct[c], direct[c] + 1.0f);                /* :89 */
         d = or_det_powf_(d, 1.0f / 2.2f);                             /* :90 */
@@ -291,8 +297,8 @@ void or_deferred_light_points(const or_pass_constants* cb, const float* g0, cons
              * is below the clear value. */
             if ((depth[idx] & 0x00FFFFFFu) < 0x00FFFFFFu)
                 light_pixel(cb, g0, g1, g2, ambient, shadow, shadowDim, cube, cubeDim, W, H, idx, numDirLights,
-                            pcfSearchRadius, pointLights, numPointLights, lit);
-            else if (sky)
+                            pcfSearchRadius, pointLights, numPointLights, sky, lit);
+            else if (sky & 1)
                 sky_pixel(cb, cube, cubeDim, W, H, x, (uint32_t)y, lit);
             else
                 for (int c = 0; c < 4; ++c) lit[c] = clearColor[c];

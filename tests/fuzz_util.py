@@ -62,7 +62,7 @@ def random_case(seed, built_lib):
         for j in range(16):
             p.ShadowTransforms[k][j] = float(p.ShadowTransforms[k][j] * rng.choice([0.2, 1.0]))
     knobs = {
-        "blurCount": int(rng.integers(0, 5)), "numDirLights": int(rng.integers(0, 4)),
+        "blurCount": int(rng.integers(0, 7)), "numDirLights": int(rng.integers(0, 4)),
         "pcfSearchRadius": float(rng.choice([0.0, 2.5 / sd, 10.0 / sd])), "sky": int(rng.integers(0, 2)),
         "ssao_on": bool(rng.random() > 0.15),
     }

@@ -147,8 +147,13 @@ void hs_light(const crychic_pass_constants* cb, const float* g0, const float* g1
         for (uint32_t x = 0; x < W; ++x) {
             const uint32_t idx = y * W + x;
             f4 lit;
-            if ((depth[idx] & 0x00FFFFFFu) < 0x00FFFFFFu) lit = (pcfSearchRadius == 0.0f) ? light_pixel<true>(P, G0[idx], G1[idx], G2[idx], ambient, (const uint32_t*)cube, pl)
-                                                                                        : light_pixel<false>(P, G0[idx], G1[idx], G2[idx], ambient, (const uint32_t*)cube, pl);
+            const bool fix = (flags & (CRYCHIC_FIX_Q1 | CRYCHIC_FIX_Q3 | CRYCHIC_FIX_Q4)) != 0;     // as launch_light picks the instantiation
+            if ((depth[idx] & 0x00FFFFFFu) < 0x00FFFFFFu) {
+                if (pcfSearchRadius == 0.0f) lit = fix ? light_pixel<true, AllPointLights, true>(P, G0[idx], G1[idx], G2[idx], ambient, (const uint32_t*)cube, pl)
+                                                       : light_pixel<true, AllPointLights, false>(P, G0[idx], G1[idx], G2[idx], ambient, (const uint32_t*)cube, pl);
+                else lit = fix ? light_pixel<false, AllPointLights, true>(P, G0[idx], G1[idx], G2[idx], ambient, (const uint32_t*)cube, pl)
+                               : light_pixel<false, AllPointLights, false>(P, G0[idx], G1[idx], G2[idx], ambient, (const uint32_t*)cube, pl);
+            }
             else if (flags & CRYCHIC_LIGHT_SKY) lit = sky_pixel(P, (const uint32_t*)cube, x, y);
             else lit = f4{ 0.690196097f, 0.768627524f, 0.870588303f, 1.0f };
             if (radiance) { radiance[4 * idx] = lit.x; radiance[4 * idx + 1] = lit.y; radiance[4 * idx + 2] = lit.z; radiance[4 * idx + 3] = lit.w; }

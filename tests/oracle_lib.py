@@ -135,7 +135,7 @@ class Oracle:
         return a0
 
     def deferred_light(self, cb, g0, g1, g2, depth_u32, ambient, shadow_u32, cube_u8, num_dir_lights, pcf_radius,
-                       sky=False, want_radiance=False, row0=0, rows=None, point_lights=None):
+                       sky=False, want_radiance=False, row0=0, rows=None, point_lights=None, fixes=0):
         H, W = depth_u32.shape
         rows = H - row0 if rows is None else rows
         out = np.zeros((H, W, 4), dtype=np.uint8)
@@ -147,7 +147,7 @@ class Oracle:
         self.lib.or_deferred_light_points(C.addressof(cb), g0.ctypes.data, g1.ctypes.data, g2.ctypes.data, d.ctypes.data,
                                           a.ctypes.data if a is not None else None, sh, s.shape[1], c.ctypes.data, c.shape[1],
                                           out.ctypes.data, rad.ctypes.data if rad is not None else None, W, H, row0, rows,
-                                          num_dir_lights, pcf_radius, 1 if sky else 0,
+                                          num_dir_lights, pcf_radius, (1 if sky else 0) | int(fixes),
                                           C.addressof(point_lights) if point_lights is not None else None,
                                           len(point_lights) if point_lights is not None else 0)
         return (out, rad) if want_radiance else out

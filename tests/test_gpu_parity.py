@@ -118,7 +118,7 @@ def test_blur_sweeps_bit_exact(ctx, built_lib, oracle, W, H):
         cur = ref
 
 
-@pytest.mark.parametrize("blur_count", [0, 1, 3, 4])
+@pytest.mark.parametrize("blur_count", [0, 1, 2, 3, 4, 5, 6])
 def test_compute_ssao_bit_exact(ctx, built_lib, oracle, blur_count):
     W, H = 256, 256
     c = get_case(ctx, built_lib, W, H)
@@ -152,6 +152,26 @@ def test_deferred_light_bit_exact(ctx, built_lib, oracle, W, H, num_dir_lights, 
     assert np.array_equal(got, ref), "RGBA8 differs in %d of %d channels" % ((got != ref).sum(), ref.size)
     # radiance: tolerance 0 ulp (bit pattern equality, NaN-safe)
     assert np.array_equal(got_rad.view(np.uint32), ref_rad.view(np.uint32))
+
+
+@pytest.mark.parametrize("fixes,literal", [(0x100, 1), (0x200, 1), (0x400, 1), (0x700, 0)])
+def test_quirk_fix_switches_on_device(ctx, built_lib, oracle, fixes, literal):
+    """CRYCHIC_FIX_Q1 / Q3 / Q4 through the C ABI == the oracle with the same switches (RGBA8 and radiance bits)."""
+    W, H = 256, 256
+    c = get_case(ctx, built_lib, W, H)
+    lib, check = built_lib.lib, built_lib.check
+    amb = oracle.compute_ssao(c.scb, c.np["normal"], c.np["depth"], c.np["randvec"], 1)
+    c.a0.copy_(torch.from_numpy(amb.view(np.int16)))
+    radius = lib.crychic_pcf_search_radius(c.np["shadow"].shape[1], literal)
+    check(lib.crychic_deferred_light(ctx.handle, C.byref(c.consts.pass_cb), ptr(c.dev["g0"]), ptr(c.dev["g1"]),
+                                     ptr(c.dev["g2"]), ptr(c.dev["depth"]), ptr(c.a0), c.shadow_ptrs, c.np["shadow"].shape[1],
+                                     ptr(c.dev["cube"]), c.np["cube"].shape[1], ptr(c.out), ptr(c.rad), W, H, 0, H, 3, radius, 1 | fixes,
+                                     stream(ctx)))
+    torch.cuda.synchronize()
+    ref, ref_rad = oracle.deferred_light(c.pcb, c.np["g0"], c.np["g1"], c.np["g2"], c.np["depth"], amb, c.np["shadow"], c.np["cube"], 3,
+                                         radius, sky=True, want_radiance=True, fixes=fixes)
+    assert np.array_equal(c.out.cpu().numpy(), ref)
+    assert np.array_equal(c.rad.cpu().numpy().view(np.uint32), ref_rad.view(np.uint32))
 
 
 def test_draw_hot_path_matches_oracle_and_strips(ctx, built_lib, oracle):
@@ -202,12 +222,15 @@ def test_c2_1080p_parity(ctx, built_lib, oracle):
 
 
 def test_c3_4k_properties(ctx, built_lib, oracle):
-    """BASELINE config 3 size (3840x2160, blurCount 4): size-independent properties + oracle spot rows."""
+    """BASELINE configs[2] exactly as bench.py times it (3840x2160, blurCount 4, 3 lights, 4 x 4096^2 cascades, 256^2 cube,
+    literal PCF): size-independent properties, the oracle on two bands (mid-frame; the near ground at the bottom, where the
+    SSAO tap discs are widest) and -- on a many-core host such as the GPU box's -- on the WHOLE frame."""
+    import os
     from crychic_renderer_amd import Crychic
     W, H = 3840, 2160
-    c = get_case(ctx, built_lib, W, H, shadow_dim=2048, cube_dim=256, device=str(ctx.device))
+    c = get_case(ctx, built_lib, W, H, shadow_dim=4096, cube_dim=256, device=str(ctx.device))
     lib, check = built_lib.lib, built_lib.check
-    app = Crychic(ctx, W, H, c.dev["randvec"], c.dev["cube"], shadow_dim=2048)
+    app = Crychic(ctx, W, H, c.dev["randvec"], c.dev["cube"], shadow_dim=4096)
     app.load_scene({**c.dev, "consts": c.consts})
     app.blurCount, app.numDirLights = 4, 3
     app.Draw()
@@ -240,16 +263,31 @@ def test_c3_4k_properties(ctx, built_lib, oracle):
     cov = c.np["depth"] < 0xFFFFFF
     assert (full[~cov] == np.array([176, 196, 222, 255], dtype=np.uint8)).all()
     assert (full[cov][:, 3] == 255).all()
-    # (5) oracle on a band of rows in the middle of the frame (SSAO rows via the oracle's row range)
-    band0, band1 = H // 2 - 24, H // 2 + 24
-    ref_ssao = oracle.ssao(c.scb, c.np["normal"], c.np["depth"], c.np["randvec"], band0 // 2, (band1 - band0) // 2)
+    # (5) oracle on bands of rows (SSAO rows via the oracle's row range): mid-frame and the near ground at the bottom
     check(lib.crychic_ssao(ctx.handle, C.byref(c.consts.ssao_cb), ptr(c.dev["normal"]), ptr(c.dev["depth"]),
-                           ptr(c.dev["randvec"]), ptr(c.a0), None, W, H, 0, H // 2, stream(ctx)))
+                           ptr(c.dev["randvec"]), ptr(c.a0), ptr(c.edge), W, H, 0, H // 2, stream(ctx)))
     torch.cuda.synchronize()
-    assert np.array_equal(dev_u16(c.a0)[band0 // 2:band1 // 2], ref_ssao[band0 // 2:band1 // 2])
-    ref_band = oracle.deferred_light(c.pcb, c.np["g0"], c.np["g1"], c.np["g2"], c.np["depth"], ao, c.np["shadow"], c.np["cube"],
-                                     3, app.pcfSearchRadius, row0=band0, rows=band1 - band0)
-    assert np.array_equal(full[band0:band1], ref_band[band0:band1])
+    raw_ssao = dev_u16(c.a0).copy()
+    for band0, band1 in ((H // 2 - 24, H // 2 + 24), (H - 64, H)):
+        ref_ssao = oracle.ssao(c.scb, c.np["normal"], c.np["depth"], c.np["randvec"], band0 // 2, (band1 - band0) // 2)
+        assert np.array_equal(raw_ssao[band0 // 2:band1 // 2], ref_ssao[band0 // 2:band1 // 2]), (band0, band1)
+        ref_band = oracle.deferred_light(c.pcb, c.np["g0"], c.np["g1"], c.np["g2"], c.np["depth"], ao, c.np["shadow"], c.np["cube"],
+                                         3, app.pcfSearchRadius, row0=band0, rows=band1 - band0)
+        assert np.array_equal(full[band0:band1], ref_band[band0:band1]), (band0, band1)
+    # (6) the whole frame against the oracle where the host can afford it (128 cores: ~1 s)
+    if (os.cpu_count() or 1) >= 32:
+        ref_ao = oracle.compute_ssao(c.scb, c.np["normal"], c.np["depth"], c.np["randvec"], 4)
+        assert np.array_equal(ao, ref_ao), "AO differs in %d texels" % int((ao != ref_ao).sum())
+        ref = oracle.deferred_light(c.pcb, c.np["g0"], c.np["g1"], c.np["g2"], c.np["depth"], ref_ao, c.np["shadow"], c.np["cube"],
+                                    3, app.pcfSearchRadius)
+        assert np.array_equal(full, ref), "frame differs in %d bytes" % int((full != ref).sum())
+        # the evidently intended PCF (2.5-texel rotated Poisson disc), whole frame as well
+        app.pcfSearchRadius = lib.crychic_pcf_search_radius(4096, 0)
+        app.Draw()
+        torch.cuda.synchronize()
+        ref = oracle.deferred_light(c.pcb, c.np["g0"], c.np["g1"], c.np["g2"], c.np["depth"], ref_ao, c.np["shadow"], c.np["cube"],
+                                    3, app.pcfSearchRadius)
+        assert np.array_equal(app.mBackBuffer.cpu().numpy(), ref)
 
 
 def test_flat_wall_ssao_is_unoccluded(ctx, built_lib):

@@ -105,3 +105,19 @@ def test_degenerate_inputs_agree(built_lib, oracle, hostsim):
     r = oracle.ssao(scb, normal, d2, p["randvec"])
     g, _ = hostsim.ssao(c.ssao_cb, normal, d2, p["randvec"], eb)
     assert np.array_equal(g, r)
+
+
+@pytest.mark.parametrize("fixes", [0x100, 0x200, 0x400, 0x700])
+def test_quirk_fix_switches(built_lib, oracle, hostsim, fixes):
+    """CRYCHIC_FIX_Q1 / Q3 / Q4 (crychic_hip.h): the evidently intended forms of the cascade-blend test, the specular
+    denominator and the Fresnel factor.  Kernel bodies == oracle with the same switches, and every switch changes the picture."""
+    W, H = 96, 64
+    p, c, scb, pcb, eb = setup(W, H, built_lib)
+    ao = oracle.compute_ssao(scb, p["normal"], p["depth"], p["randvec"], 1)
+    base = oracle.deferred_light(pcb, p["g0"], p["g1"], p["g2"], p["depth"], ao, p["shadow"], p["cube"], 3, 0.0)
+    for radius in (0.0, 2.5 / 512):
+        ref, rref = oracle.deferred_light(pcb, p["g0"], p["g1"], p["g2"], p["depth"], ao, p["shadow"], p["cube"], 3, radius, fixes=fixes, want_radiance=True)
+        got, rgot = hostsim.light(c.pass_cb, p["g0"], p["g1"], p["g2"], p["depth"], ao, p["shadow"], p["cube"], 3, radius, flags=fixes, want_radiance=True)
+        assert np.array_equal(got, ref) and np.array_equal(rgot.view(np.uint32), rref.view(np.uint32))
+        if radius == 0.0 and fixes != 0x100:        # Q1 only matters where the two blended cascades disagree
+            assert (ref != base).mean() > 0.01
