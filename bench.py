@@ -307,9 +307,11 @@ def pmc_profile(args, world):
     return prof.get("kernels")
 
 
-def time_producers(ctx, planes, args, torch):
+def time_producers(ctx, planes, args, torch, row0, rows):
     """Informational (not part of `value`): the producer passes of the same frame on the device -- 4 shadow cascades,
-    normals+depth and G-buffer of the reference's 100-box + grid scene through the HIP rasteriser."""
+    normals+depth and G-buffer of the reference's 100-box + grid scene through the HIP rasteriser.
+    A rank that lights only rows [row0, row0 + rows) produces its G-buffer for those rows only (depth + normals and the
+    shadow cascades stay whole: SSAO taps and shadow lookups of a strip reach outside it)."""
     from crychic_renderer_amd import SceneGeometry, geometry as g
     from crychic_renderer_amd._lib import PassConstants
     import numpy as np
@@ -330,9 +332,11 @@ def time_producers(ctx, planes, args, torch):
 
     shadow_planes = [shadow[k] for k in range(4)]
 
+    g_rows = (row0, rows) if rows < H else None
+
     def run():
         sgeo.DrawSceneToShadowMaps(cbs, shadow_planes)
-        geo.DrawNormalsDepthAndGBuffer(consts.pass_cb, normal, gb, depth)
+        geo.DrawNormalsDepthAndGBuffer(consts.pass_cb, normal, gb, depth, g_rows=g_rows)
 
     run()
     torch.cuda.synchronize()
@@ -343,14 +347,15 @@ def time_producers(ctx, planes, args, torch):
         e0.record()
         sgeo.DrawSceneToShadowMaps(cbs, shadow_planes)
         e1.record()
-        geo.DrawNormalsDepthAndGBuffer(consts.pass_cb, normal, gb, depth)
+        geo.DrawNormalsDepthAndGBuffer(consts.pass_cb, normal, gb, depth, g_rows=g_rows)
         e2.record()
         torch.cuda.synchronize()
         t_sh += e0.elapsed_time(e1) / n
         t_cam += e1.elapsed_time(e2) / n
     # the rasterised planes and the analytic (ray-cast) planes the hot path is benchmarked on describe the same frame
     cov_agree = float(((depth != 0xFFFFFF) == (planes["depth"] != 0xFFFFFF)).float().mean())
-    return {"shadow_4x%d" % SD: round(t_sh, 3), "normals_depth+gbuffer": round(t_cam, 3), "triangles": int(geo.triangles),
+    return {"shadow_4x%d" % SD: round(t_sh, 3), "normals_depth+gbuffer": round(t_cam, 3), "gbuffer_rows": list(g_rows) if g_rows else None,
+            "triangles": int(geo.triangles),
             "coverage_agreement_with_analytic_scene": round(cov_agree, 6)}
 
 
@@ -629,7 +634,7 @@ def main():
 
     producer_ms = None
     if rank == 0 and not args.no_producers:
-        producer_ms = time_producers(ctx, planes, args, torch)
+        producer_ms = time_producers(ctx, planes, args, torch, row0, rows)
 
     if rank == 0:
         npx = W * H
@@ -687,9 +692,9 @@ def main():
                        "frame_algorithmic_MB": round(frame_bytes / 1e6, 1),
                        "pass_ms": {k: round(v, 4) for k, v in acc.items()},      # one frame at a time on one stream (latency view)
                        "producer_passes_ms": producer_ms,
-                       "full_frame_ms_incl_producers": (round(dt / args.steps * 1e3 + producer_ms["shadow_4x%d" % args.shadow_dim]
-                                                              + producer_ms["normals_depth+gbuffer"], 3)
-                                                        if producer_ms and world == 1 else None)},
+                       # what one rank spends on a frame end to end: its producers (shadow cascades whole, G-buffer for its strip) + the step
+                       "frame_ms_incl_producers_rank0": (round(dt / args.steps * 1e3 + producer_ms["shadow_4x%d" % args.shadow_dim]
+                                                               + producer_ms["normals_depth+gbuffer"], 3) if producer_ms else None)},
             # Frame level per SURVEY.md 8d: algorithmic bytes of the whole frame / measured frame time (N = 1: this GPU's HBM;
             # N > 1: the aggregate over N GPUs against N x peak).  `traffic`: HBM bytes per frame from the committed PMC passes
             # (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction), null unless they were taken on exactly these kernel sources.

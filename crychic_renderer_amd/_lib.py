@@ -126,6 +126,10 @@ PROTOTYPES = {
                                   _u32, _u32, _vp, _sz, _vp]),
     "crychic_draw_normals_depth_and_gbuffer": (_i, [_vp, _P(PassConstants), _P(DrawItem), _u32, _vp, _u32, _P(Texture), _u32, _vp, _vp, _vp, _vp, _vp,
                                                _u32, _u32, _vp, _sz, _vp]),
+    "crychic_draw_gbuffer_rows": (_i, [_vp, _P(PassConstants), _P(DrawItem), _u32, _vp, _u32, _P(Texture), _u32, _vp, _vp, _vp, _vp,
+                                       _u32, _u32, _u32, _u32, _vp, _sz, _vp]),
+    "crychic_draw_normals_depth_and_gbuffer_rows": (_i, [_vp, _P(PassConstants), _P(DrawItem), _u32, _vp, _u32, _P(Texture), _u32, _vp, _vp, _vp, _vp,
+                                                        _vp, _u32, _u32, _u32, _u32, _vp, _sz, _vp]),
 }
 
 

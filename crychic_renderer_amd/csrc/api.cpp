@@ -443,6 +443,41 @@ int crychic_draw_normals_depth_and_gbuffer(crychic_ctx* ctx, const crychic_pass_
     return raster_common(ctx, p, passCB, items, nItems, stream);
 }
 
+int crychic_draw_gbuffer_rows(crychic_ctx* ctx, const crychic_pass_constants* passCB, const crychic_draw_item* items, uint32_t nItems,
+                              const crychic_material_data* materials_dev, uint32_t nMaterials, const crychic_texture* textures,
+                              uint32_t nTextures, float* g0_dev, float* g1_dev, float* g2_dev, uint32_t* depth_dev, uint32_t W, uint32_t H,
+                              uint32_t gRow0, uint32_t gRows, void* workspace_dev, size_t workspaceBytes, void* stream)
+{
+    if (!g0_dev || !g1_dev || !g2_dev) return fail(CRYCHIC_E_INVALID_ARG, "null G-buffer target");
+    if (nTextures && !textures) return fail(CRYCHIC_E_INVALID_ARG, "null texture table");
+    if (gRows == 0 || gRow0 > H || gRows > H - gRow0) return fail(CRYCHIC_E_INVALID_ARG, "G-buffer rows [%u,+%u) outside the %u-row target", gRow0, gRows, H);
+    cry::RasterPass p = {};
+    p.mode = 2; p.W = W; p.H = H; p.depth = depth_dev; p.g0 = g0_dev; p.g1 = g1_dev; p.g2 = g2_dev;
+    p.materials = materials_dev; p.nMaterials = nMaterials;
+    p.textures = reinterpret_cast<const cry::Texture*>(textures); p.nTextures = nTextures;
+    p.workspace = workspace_dev; p.workspaceBytes = workspaceBytes;
+    p.gRow0 = gRow0; p.gRows = gRows;
+    return raster_common(ctx, p, passCB, items, nItems, stream);
+}
+
+int crychic_draw_normals_depth_and_gbuffer_rows(crychic_ctx* ctx, const crychic_pass_constants* passCB, const crychic_draw_item* items, uint32_t nItems,
+                                                const crychic_material_data* materials_dev, uint32_t nMaterials, const crychic_texture* textures,
+                                                uint32_t nTextures, void* normal_dev, float* g0_dev, float* g1_dev, float* g2_dev, uint32_t* depth_dev,
+                                                uint32_t W, uint32_t H, uint32_t gRow0, uint32_t gRows, void* workspace_dev, size_t workspaceBytes,
+                                                void* stream)
+{
+    if (!normal_dev || !g0_dev || !g1_dev || !g2_dev) return fail(CRYCHIC_E_INVALID_ARG, "null normal / G-buffer target");
+    if (nTextures && !textures) return fail(CRYCHIC_E_INVALID_ARG, "null texture table");
+    if (gRows == 0 || gRow0 > H || gRows > H - gRow0) return fail(CRYCHIC_E_INVALID_ARG, "G-buffer rows [%u,+%u) outside the %u-row target", gRow0, gRows, H);
+    cry::RasterPass p = {};
+    p.mode = 3; p.W = W; p.H = H; p.depth = depth_dev; p.normal = normal_dev; p.g0 = g0_dev; p.g1 = g1_dev; p.g2 = g2_dev;
+    p.materials = materials_dev; p.nMaterials = nMaterials;
+    p.textures = reinterpret_cast<const cry::Texture*>(textures); p.nTextures = nTextures;
+    p.workspace = workspace_dev; p.workspaceBytes = workspaceBytes;
+    p.gRow0 = gRow0; p.gRows = gRows;
+    return raster_common(ctx, p, passCB, items, nItems, stream);
+}
+
 int crychic_strip_rows(uint32_t H, int nranks, int rank, uint32_t* row0, uint32_t* rows)
 {
     if (!row0 || !rows || nranks <= 0 || rank < 0 || rank >= nranks || (H & 1u))

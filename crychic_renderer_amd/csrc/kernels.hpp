@@ -44,6 +44,7 @@ struct RasterPass {
     int depthBias; float slopeScaledDepthBias;
     uint32_t* depth; void* normal; float* g0; float* g1; float* g2;
     void* workspace; size_t workspaceBytes;
+    uint32_t gRow0, gRows;                  // G-buffer rows to render (a rank's strip); gRows == 0 = the whole target
     // fused shadow pass (mode 0, nTargets 2..4): one ViewProj and one depth target per cascade, same items
     uint32_t nTargets; const float* viewProjN[4]; uint32_t* depthN[4];
 };

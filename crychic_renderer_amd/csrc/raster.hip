@@ -46,14 +46,15 @@ struct ItemBatch {
 __global__ __launch_bounds__(128) void setup_kernel(ItemBatch batch, const crychic_material_data* __restrict__ materials,
                                                     uint32_t nMaterials, ViewProjSet vps, uint32_t W, uint32_t H,
                                                     SetupTri* __restrict__ tris, uint32_t slotBase, uint32_t slotsPerTarget,
-                                                    uint32_t* __restrict__ live, uint32_t liveCapacity, RasterCounters* __restrict__ counters)
+                                                    uint32_t* __restrict__ live, uint32_t liveCapacity, RasterCounters* __restrict__ counters,
+                                                    uint32_t yLo, uint32_t yHi)
 {
     const uint32_t target = blockIdx.y;                                // shadow cascades of one fused pass; 0 otherwise
     const crychic_pass_constants_viewproj& vp = vps.m[target];
     // small triangles are listed from the front of `live`, large ones (pixel box > kLargeBox) from its back
     auto append = [&](const SetupTri& s, uint32_t slot) {
-        const PixelBox b = triangle_box(s, W, H);
-        if (b.x0 > b.x1 || b.y0 > b.y1) return;                       // covers no pixel centre inside the target
+        const PixelBox b = triangle_box(s, W, yLo, yHi);
+        if (b.x0 > b.x1 || b.y0 > b.y1) return;                       // covers no pixel centre inside the target (or its scissor rows)
         if ((b.x1 - b.x0 + 1) * (b.y1 - b.y0 + 1) > kLargeBox) live[liveCapacity - 1u - atomicAdd(&counters->nlarge, 1u)] = slot;
         else live[atomicAdd(&counters->nlive, 1u)] = slot;
     };
@@ -131,7 +132,8 @@ __global__ __launch_bounds__(256) void clear_depth_kernel(uint32_t* __restrict__
 template <bool SHADOW, int FWL2>
 __global__ __launch_bounds__(256) void raster_kernel(const SetupTri* __restrict__ tris, const uint32_t* __restrict__ live, uint32_t liveCapacity,
                                                      const RasterCounters* __restrict__ counters, unsigned long long* __restrict__ vis,
-                                                     DepthTargets depthTargets, uint32_t W, uint32_t H, int depthBias, float slopeBias)
+                                                     DepthTargets depthTargets, uint32_t W, uint32_t H, int depthBias, float slopeBias,
+                                                     uint32_t yLo, uint32_t yHi)
 {
     const uint32_t nsmall = counters->nlive, nlarge = counters->nlarge;   // written by the setup kernels that precede this launch
     const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void raster_kernel(const SetupTri* __restrict_
     auto sweep = [&](uint32_t slot, int yfirst, int ystep) {
         const SetupTri t = tris[slot];
         uint32_t* __restrict__ depth = depthTargets.p[SHADOW ? (t.pad & 3u) : 0u];
-        const PixelBox b = triangle_box(t, W, H);
+        const PixelBox b = triangle_box(t, W, yLo, yHi);
         const EdgeFlags e = triangle_edge_flags(t);
         const double bias = SHADOW ? triangle_depth_bias(t, depthBias, slopeBias) : 0.0;
         for (int y = b.y0 + ly + yfirst; y <= b.y1; y += ystep)
@@ -161,15 +163,17 @@ __global__ __launch_bounds__(256) void resolve_kernel(int mode, const unsigned l
                                                       crychic_pass_constants_viewproj view, const crychic_material_data* __restrict__ materials,
                                                       uint32_t nMaterials, const Texture* __restrict__ textures, uint32_t nTextures,
                                                       uint32_t W, uint32_t H, uint32_t* __restrict__ depth, u2* __restrict__ normal,
-                                                      f4a* __restrict__ g0, f4a* __restrict__ g1, f4a* __restrict__ g2)
+                                                      f4a* __restrict__ g0, f4a* __restrict__ g1, f4a* __restrict__ g2, uint32_t gLo, uint32_t gHi)
 {
     const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u), y = blockIdx.y * 4u + (threadIdx.x >> 6);
     if (x >= W || y >= H) return;
+    // G-buffer rows [gLo, gHi) only (a rank's strip): outside them the G-buffer stage of this pixel does not run and its
+    // texels are left untouched; a G-buffer-only pass leaves the whole pixel (its depth target too) untouched there.
+    if (y < gLo || y >= gHi) { mode &= ~2; if (mode == 0) return; }
     const uint32_t idx = y * W + x;
     const uint64_t key = vis[idx];
     const uint32_t serial = (uint32_t)(key & 0xFFFFFFFFull);
     depth[idx] = (uint32_t)(key >> 32);
-    if (mode == 0) return;
     if (serial == 0) {                       // nothing drawn here: the pass's clear values
         if (mode & 1) normal[idx] = u2{ 0u, 0x00003C00u };                      // (0, 0, 1, 0) in fp16, Ssao.cpp:317
         if (mode & 2) { g0[idx] = f4a{ 0, 0, 0, 0 }; g1[idx] = f4a{ 0, 0, 0, 0 }; g2[idx] = f4a{ 0, 0, 0, 0 }; }   // CRYCHIC.cpp:2554
@@ -227,6 +231,11 @@ hipError_t launch_raster_pass(const RasterPass& p, hipStream_t stream)
     }
     crychic_pass_constants_viewproj view;
     for (int i = 0; i < 16; ++i) view.m[i] = p.view[i];
+    // Scissor rows (a rank's strip): the G-buffer stage of the resolve runs on rows [gLo, gHi) only; a pass that renders the
+    // G-buffer alone (mode 2) needs no visibility outside them either, so its rasterisation is limited to the same rows.
+    const uint32_t gLo = p.gRows ? p.gRow0 : 0u, gHi = p.gRows ? p.gRow0 + p.gRows : p.H;
+    if (gLo > p.H || gHi > p.H) return hipErrorInvalidValue;
+    const uint32_t yLo = p.mode == 2 ? gLo : 0u, yHi = p.mode == 2 ? gHi : p.H;
     uint32_t slotBase = 0;
     for (uint32_t i0 = 0; i0 < p.nItems;) {
         ItemBatch b;
@@ -242,18 +251,18 @@ hipError_t launch_raster_pass(const RasterPass& p, hipStream_t stream)
         if (b.n == 0) continue;
         const uint64_t n = b.first[b.n];
         hipLaunchKernelGGL(setup_kernel, dim3((uint32_t)((n + 127u) / 128u), nT), dim3(128), 0, stream, b, p.materials, p.nMaterials,
-                           vps, p.W, p.H, tris, slotBase, (uint32_t)slotsPerTarget, live, (uint32_t)slots, counters);
+                           vps, p.W, p.H, tris, slotBase, (uint32_t)slotsPerTarget, live, (uint32_t)slots, counters, yLo, yHi);
         slotBase += (uint32_t)(n * 3u);
     }
     if (slots) {
-#define CRY_RASTER(S, F) hipLaunchKernelGGL((raster_kernel<S, F>), dim3(256u * 8u), dim3(256), 0, stream, tris, live, (uint32_t)slots, counters, vis, targets, p.W, p.H, p.depthBias, p.slopeScaledDepthBias)
+#define CRY_RASTER(S, F) hipLaunchKernelGGL((raster_kernel<S, F>), dim3(256u * 8u), dim3(256), 0, stream, tris, live, (uint32_t)slots, counters, vis, targets, p.W, p.H, p.depthBias, p.slopeScaledDepthBias, yLo, yHi)
         if (shadow) CRY_RASTER(true, 4); else CRY_RASTER(false, 4);     // 16 x 4 footprint: measured best of 8x8 / 16x4 / 64x1
 #undef CRY_RASTER
     }
     if (shadow) return hipGetLastError();
     hipLaunchKernelGGL(resolve_kernel, dim3((p.W + 63u) / 64u, (p.H + 3u) / 4u), dim3(256), 0, stream, p.mode, vis, tris, view,
                        p.materials, p.nMaterials, p.nTextures ? texDev : nullptr, p.nTextures, p.W, p.H, p.depth, (u2*)p.normal,
-                       (f4a*)p.g0, (f4a*)p.g1, (f4a*)p.g2);
+                       (f4a*)p.g0, (f4a*)p.g1, (f4a*)p.g2, gLo, gHi);
     return hipGetLastError();
 }
 

@@ -119,7 +119,8 @@ CRY_HD bool setup_triangle(const VsOut& v0, const VsOut& v1, const VsOut& v2, ui
 }
 
 struct PixelBox { int x0, y0, x1, y1; };   // inclusive pixel range whose centres can be covered
-CRY_HD PixelBox triangle_box(const SetupTri& t, uint32_t W, uint32_t H)
+// Rows are limited to [yLo, yHi): the whole target, or the scissor of a strip-limited pass.
+CRY_HD PixelBox triangle_box(const SetupTri& t, uint32_t W, uint32_t yLo, uint32_t yHi)
 {
     int32_t minX = t.X[0], maxX = t.X[0], minY = t.Y[0], maxY = t.Y[0];
     for (int i = 1; i < 3; ++i) {
@@ -129,10 +130,11 @@ CRY_HD PixelBox triangle_box(const SetupTri& t, uint32_t W, uint32_t H)
     PixelBox b;
     b.x0 = (minX - 128 + 255) >> 8; b.x1 = (maxX - 128) >> 8;
     b.y0 = (minY - 128 + 255) >> 8; b.y1 = (maxY - 128) >> 8;
-    b.x0 = b.x0 < 0 ? 0 : b.x0; b.y0 = b.y0 < 0 ? 0 : b.y0;
-    b.x1 = b.x1 > (int)W - 1 ? (int)W - 1 : b.x1; b.y1 = b.y1 > (int)H - 1 ? (int)H - 1 : b.y1;
+    b.x0 = b.x0 < 0 ? 0 : b.x0; b.y0 = b.y0 < (int)yLo ? (int)yLo : b.y0;
+    b.x1 = b.x1 > (int)W - 1 ? (int)W - 1 : b.x1; b.y1 = b.y1 > (int)yHi - 1 ? (int)yHi - 1 : b.y1;
     return b;
 }
+CRY_HD PixelBox triangle_box(const SetupTri& t, uint32_t W, uint32_t H) { return triangle_box(t, W, 0u, H); }
 
 // Depth bias of the shadow PSO (CRYCHIC.cpp:1601-1603): DepthBias * 2^-24 + SlopeScaledDepthBias * max |dz/dx|,|dz/dy|
 CRY_HD double triangle_depth_bias(const SetupTri& t, int depthBias, float slopeScaledDepthBias)

@@ -308,19 +308,31 @@ class SceneGeometry:
         check(lib.crychic_draw_normals_and_depth(self.ctx.handle, C.byref(pass_cb), self.items, len(self.items), _ptr(normal_map), _ptr(depth),
                                                  W, H, _ptr(ws), ws.numel(), _stream(self.ctx.device)))
 
-    def DrawNormalsDepthAndGBuffer(self, pass_cb, normal, gbuffer, depth):
+    def DrawNormalsDepthAndGBuffer(self, pass_cb, normal, gbuffer, depth, g_rows=None):
         """DrawNormalsAndDepth + DrawGBuffer on one rasterisation (same items, same ViewProj => same visibility); every plane is
-        bit-identical to the two separate passes."""
+        bit-identical to the two separate passes.  g_rows = (row0, rows): a rank's strip -- depth and normals for the whole
+        frame, G0..G2 for those rows only (crychic_draw_normals_depth_and_gbuffer_rows)."""
         H, W = int(depth.shape[0]), int(depth.shape[1])
         ws = self.workspace(W, H)
+        if g_rows is not None:
+            check(lib.crychic_draw_normals_depth_and_gbuffer_rows(self.ctx.handle, C.byref(pass_cb), self.items, len(self.items), _ptr(self.materials),
+                                                                  self.n_materials, self.textures, self.n_textures, _ptr(normal), _ptr(gbuffer[0]),
+                                                                  _ptr(gbuffer[1]), _ptr(gbuffer[2]), _ptr(depth), W, H, int(g_rows[0]), int(g_rows[1]),
+                                                                  _ptr(ws), ws.numel(), _stream(self.ctx.device)))
+            return
         check(lib.crychic_draw_normals_depth_and_gbuffer(self.ctx.handle, C.byref(pass_cb), self.items, len(self.items), _ptr(self.materials),
                                                          self.n_materials, self.textures, self.n_textures, _ptr(normal), _ptr(gbuffer[0]),
                                                          _ptr(gbuffer[1]), _ptr(gbuffer[2]), _ptr(depth), W, H, _ptr(ws), ws.numel(),
                                                          _stream(self.ctx.device)))
 
-    def DrawGBuffer(self, pass_cb, gbuffer, depth):  # CRYCHIC.cpp:2545-2571
+    def DrawGBuffer(self, pass_cb, gbuffer, depth, g_rows=None):  # CRYCHIC.cpp:2545-2571; g_rows = (row0, rows): scissored to a strip
         H, W = int(depth.shape[0]), int(depth.shape[1])
         ws = self.workspace(W, H)
+        if g_rows is not None:
+            check(lib.crychic_draw_gbuffer_rows(self.ctx.handle, C.byref(pass_cb), self.items, len(self.items), _ptr(self.materials), self.n_materials,
+                                                self.textures, self.n_textures, _ptr(gbuffer[0]), _ptr(gbuffer[1]), _ptr(gbuffer[2]), _ptr(depth), W, H,
+                                                int(g_rows[0]), int(g_rows[1]), _ptr(ws), ws.numel(), _stream(self.ctx.device)))
+            return
         check(lib.crychic_draw_gbuffer(self.ctx.handle, C.byref(pass_cb), self.items, len(self.items), _ptr(self.materials), self.n_materials,
                                        self.textures, self.n_textures, _ptr(gbuffer[0]), _ptr(gbuffer[1]), _ptr(gbuffer[2]), _ptr(depth), W, H,
                                        _ptr(ws), ws.numel(), _stream(self.ctx.device)))

@@ -503,12 +503,14 @@ private:
         size_t bytes;
         void* ws = RasterWorkspace(mSceneTriangles, mClientWidth, mClientHeight, &bytes);
         const PassConstants& cb = mCurrFrameResource->PassCB->Element(0);
-        CrychicThrowIfFailed(crychic_draw_gbuffer(
+        // the scissor rectangle of this pass (CRYCHIC.cpp:2547-2548) is this GPU's strip when the frame is shared (SetStrip / JoinNode)
+        CrychicThrowIfFailed(crychic_draw_gbuffer_rows(
             md3dDevice->Ctx(), reinterpret_cast<const crychic_pass_constants*>(&cb), items.data(), (uint32_t)items.size(),
             reinterpret_cast<const crychic_material_data*>(mCurrFrameResource->MaterialBuffer->Resource()->Data()), (uint32_t)mMaterials.size(),
             mTextures.empty() ? nullptr : mTextures.data(), (uint32_t)mTextures.size(), static_cast<float*>(mDeferred->Resource(0)->Data()),
             static_cast<float*>(mDeferred->Resource(1)->Data()), static_cast<float*>(mDeferred->Resource(2)->Data()),
-            static_cast<uint32_t*>(mDepthStencilBuffer->Data()), mClientWidth, mClientHeight, ws, bytes, mCommandList->Stream()));
+            static_cast<uint32_t*>(mDepthStencilBuffer->Data()), mClientWidth, mClientHeight, mStripRow0,
+            mStripRows ? mStripRows : mClientHeight - mStripRow0, ws, bytes, mCommandList->Stream()));
     }
     void DrawNormalsDepthAndGBuffer()  // DrawNormalsAndDepth + DrawGBuffer: same items, same ViewProj, same visibility -> one rasterisation
     {
@@ -516,13 +518,13 @@ private:
         size_t bytes;
         void* ws = RasterWorkspace(mSceneTriangles, mClientWidth, mClientHeight, &bytes);
         const PassConstants& cb = mCurrFrameResource->PassCB->Element(0);
-        CrychicThrowIfFailed(crychic_draw_normals_depth_and_gbuffer(
+        CrychicThrowIfFailed(crychic_draw_normals_depth_and_gbuffer_rows(
             md3dDevice->Ctx(), reinterpret_cast<const crychic_pass_constants*>(&cb), items.data(), (uint32_t)items.size(),
             reinterpret_cast<const crychic_material_data*>(mCurrFrameResource->MaterialBuffer->Resource()->Data()), (uint32_t)mMaterials.size(),
             mTextures.empty() ? nullptr : mTextures.data(), (uint32_t)mTextures.size(), mSsao->NormalMap()->Data(),
             static_cast<float*>(mDeferred->Resource(0)->Data()), static_cast<float*>(mDeferred->Resource(1)->Data()),
             static_cast<float*>(mDeferred->Resource(2)->Data()), static_cast<uint32_t*>(mDepthStencilBuffer->Data()), mClientWidth, mClientHeight,
-            ws, bytes, mCommandList->Stream()));
+            mStripRow0, mStripRows ? mStripRows : mClientHeight - mStripRow0, ws, bytes, mCommandList->Stream()));
     }
     void UpdateCascadeShadowTransform(const GameTimer&)  // CRYCHIC.cpp:634-815
     {

@@ -342,6 +342,24 @@ int crychic_draw_normals_depth_and_gbuffer(crychic_ctx* ctx, const crychic_pass_
                                            float* g1_dev, float* g2_dev, uint32_t* depth_dev, uint32_t W, uint32_t H,
                                            void* workspace_dev, size_t workspaceBytes, void* stream);
 
+/* Strip-limited producers (SURVEY.md 8e "G-buffer for own strip only"; the reference scissors its passes to the whole client
+ * area, CRYCHIC.cpp:2547-2548 -- with N GPUs each rank scissors the G-buffer pass to the rows it lights).  As the two entry
+ * points above, but G0..G2 are produced for rows [gRow0, gRow0 + gRows) only; G-buffer texels outside those rows are left
+ * untouched.  crychic_draw_gbuffer_rows also limits rasterisation and its depth target to the rows;
+ * crychic_draw_normals_depth_and_gbuffer_rows still renders depth and view normals for the WHOLE frame (the SSAO taps of a
+ * strip reach far outside it) and only skips the G-buffer stage elsewhere.  Inside the rows every plane is bit-identical to
+ * the unscissored pass. */
+int crychic_draw_gbuffer_rows(crychic_ctx* ctx, const crychic_pass_constants* passCB, const crychic_draw_item* items,
+                              uint32_t nItems, const crychic_material_data* materials_dev, uint32_t nMaterials,
+                              const crychic_texture* textures, uint32_t nTextures, float* g0_dev, float* g1_dev, float* g2_dev,
+                              uint32_t* depth_dev, uint32_t W, uint32_t H, uint32_t gRow0, uint32_t gRows, void* workspace_dev,
+                              size_t workspaceBytes, void* stream);
+int crychic_draw_normals_depth_and_gbuffer_rows(crychic_ctx* ctx, const crychic_pass_constants* passCB, const crychic_draw_item* items,
+                                                uint32_t nItems, const crychic_material_data* materials_dev, uint32_t nMaterials,
+                                                const crychic_texture* textures, uint32_t nTextures, void* normal_dev, float* g0_dev,
+                                                float* g1_dev, float* g2_dev, uint32_t* depth_dev, uint32_t W, uint32_t H,
+                                                uint32_t gRow0, uint32_t gRows, void* workspace_dev, size_t workspaceBytes, void* stream);
+
 /* ---- multi-GPU strip plan (pure host arithmetic) ---------------------------------------------- */
 /* Full-res rows [*row0, *row0 + *rows) owned by `rank` of `nranks` for an H-row frame: strips are multiples
  * of 2 rows (half-res alignment); the last rank takes the remainder. */

@@ -53,6 +53,25 @@ def device_frame(ctx, built_lib, consts, items, shadow_items, materials, texture
     assert torch.equal(n2.view(torch.int16), app.mSsao.mNormalMap.view(torch.int16)) and torch.equal(d2, app.mDepthStencilBuffer)
     for a, b in zip(g2, app.mDeferred.mGBuffer):
         assert torch.equal(a.view(torch.int32), b.view(torch.int32))
+    # Strip-limited producers (a rank of an N-GPU frame): inside the rows every plane equals the unscissored pass bit for bit,
+    # G-buffer texels outside the rows are left untouched; the fused form still fills depth + normals for the whole frame.
+    for (r0, rn) in ((0, H), (H // 4 & ~1, H // 2 & ~1), (H - 2, 2)):
+        poison = 0x7FC01234
+        n3 = torch.zeros_like(n2); d3 = torch.zeros_like(d2)
+        g3 = [torch.full_like(g, float("nan")).view(torch.int32).fill_(poison).view(torch.float32) for g in app.mDeferred.mGBuffer]
+        geo.DrawNormalsDepthAndGBuffer(app.mMainPassCB, n3, g3, d3, g_rows=(r0, rn))
+        g4 = [torch.full_like(g, float("nan")).view(torch.int32).fill_(poison).view(torch.float32) for g in app.mDeferred.mGBuffer]
+        d4 = torch.full_like(d2, 0x12345)
+        geo.DrawGBuffer(app.mMainPassCB, g4, d4, g_rows=(r0, rn))
+        torch.cuda.synchronize()
+        assert torch.equal(n3.view(torch.int16), app.mSsao.mNormalMap.view(torch.int16)) and torch.equal(d3, app.mDepthStencilBuffer)
+        assert torch.equal(d4[r0:r0 + rn], app.mDepthStencilBuffer[r0:r0 + rn])
+        outside = torch.ones(H, dtype=torch.bool, device=dev); outside[r0:r0 + rn] = False
+        assert bool((d4[outside] == 0x12345).all())
+        for a, b, full in zip(g3, g4, app.mDeferred.mGBuffer):
+            for t in (a, b):
+                assert torch.equal(t[r0:r0 + rn].view(torch.int32), full[r0:r0 + rn].view(torch.int32))
+                assert bool((t[outside].view(torch.int32) == poison).all())
     app.blurCount, app.numDirLights, app.pcfSearchRadius, app.flags = blur_count, ndl, radius, (LIGHT_SKY if sky else 0)
     app.Draw()
     torch.cuda.synchronize()
