@@ -61,6 +61,12 @@ int bind(crychic_ctx* ctx)
     return 0;
 }
 
+uint32_t next_stamp(crychic_ctx* ctx)
+{
+    ctx->frameStamp = ctx->frameStamp + 1u ? ctx->frameStamp + 1u : 1u;      // never 0
+    return ctx->frameStamp;
+}
+
 void clamp_rows(uint32_t limit, int64_t lo, int64_t hi, uint32_t* row0, uint32_t* rows)
 {
     if (lo < 0) lo = 0;
@@ -83,8 +89,9 @@ int ssao_compute_impl(crychic_ctx* ctx, const crychic_ssao_constants* cb, const 
     clamp_rows(h2, (int64_t)row0 - 5 * blurCount, (int64_t)row0 + rows + 5 * blurCount, &r0, &rn);
     // With a workspace at hand the depth plane is re-laid once per frame as decoded pairs (whole plane: the taps of any row
     // reach far up and down the frame) and the taps gather from that; its cost is part of the SSAO pass.
-    if (edge) CRY_HIP(cry::launch_depth_pairs(depth, edge, W, H, stream));
-    CRY_HIP(cry::launch_ssao(*cb, normal, depth, randvec, ambient0, edge, W, H, r0, rn, true, edge != nullptr, stream));
+    const uint32_t stamp = next_stamp(ctx);
+    if (edge) CRY_HIP(cry::launch_depth_pairs(depth, edge, W, H, stamp, stream));
+    CRY_HIP(cry::launch_ssao(*cb, normal, depth, randvec, ambient0, edge, W, H, r0, rn, true, edge != nullptr, stamp, stream));
     if (afterSsao) CRY_HIP(hipEventRecord(afterSsao, stream));
     // Iteration 0 records each direction's tap decisions; iterations 1.. replay them (same geometry, same rows or fewer).
     // Replay iterations run as one fused H+V launch each (in -> out, out != in).  The result has to end in ambient0
@@ -173,6 +180,8 @@ int crychic_ctx_create(int device_ordinal, crychic_ctx** out)
     snprintf(ctx->name, sizeof ctx->name, "%s %s", prop.gcnArchName, prop.name);
     ctx->profiling = false;
     ctx->times_valid = false;
+    ctx->frameStamp = 0x5EED0000u;
+    ctx->rasterStatus = nullptr;
     for (auto& ev : ctx->ev) {
         hipError_t ee = hipEventCreate(&ev);
         if (ee != hipSuccess) { delete ctx; return fail(CRYCHIC_E_HIP, "hipEventCreate failed: %s", hipGetErrorString(ee)); }
@@ -201,9 +210,10 @@ int crychic_ssao(crychic_ctx* ctx, const crychic_ssao_constants* cb, const void*
     if (int rc = check_dims(W, H)) return rc;
     if (!cb || !normal_dev || !depth_dev || !randvec_dev || !ambient_out_dev) return fail(CRYCHIC_E_INVALID_ARG, "null argument");
     if (row0 > H / 2 || rows > H / 2 - row0) return fail(CRYCHIC_E_INVALID_ARG, "rows [%u,+%u) outside the %u-row ambient map", row0, rows, H / 2);
-    if (edge_dev) CRY_HIP(cry::launch_depth_pairs(depth_dev, edge_dev, W, H, (hipStream_t)stream));
+    const uint32_t stamp = next_stamp(ctx);
+    if (edge_dev) CRY_HIP(cry::launch_depth_pairs(depth_dev, edge_dev, W, H, stamp, (hipStream_t)stream));
     CRY_HIP(cry::launch_ssao(*cb, normal_dev, depth_dev, randvec_dev, ambient_out_dev, edge_dev, W, H, row0, rows, true, edge_dev != nullptr,
-                             (hipStream_t)stream));
+                             stamp, (hipStream_t)stream));
     return 0;
 }
 
@@ -215,7 +225,7 @@ int crychic_ssao_edges(crychic_ctx* ctx, const crychic_ssao_constants* cb, const
     if (int rc = check_dims(W, H)) return rc;
     if (!cb || !normal_dev || !depth_dev || !edge_dev) return fail(CRYCHIC_E_INVALID_ARG, "null argument");
     if (row0 > H / 2 || rows > H / 2 - row0) return fail(CRYCHIC_E_INVALID_ARG, "rows [%u,+%u) outside the %u-row ambient map", row0, rows, H / 2);
-    CRY_HIP(cry::launch_ssao(*cb, normal_dev, depth_dev, nullptr, nullptr, edge_dev, W, H, row0, rows, false, false, (hipStream_t)stream));
+    CRY_HIP(cry::launch_ssao(*cb, normal_dev, depth_dev, nullptr, nullptr, edge_dev, W, H, row0, rows, false, false, 0u, (hipStream_t)stream));
     return 0;
 }
 
@@ -368,8 +378,20 @@ static int raster_common(crychic_ctx* ctx, cry::RasterPass& p, const crychic_pas
     p.items = items;
     p.nItems = nItems;
     hipError_t e = cry::launch_raster_pass(p, (hipStream_t)stream);
+    if (e == hipSuccess) ctx->rasterStatus = p.statusWord;
     if (e == hipErrorInvalidValue) return fail(CRYCHIC_E_INVALID_ARG, "raster workspace too small (need crychic_raster_workspace_bytes) or too many textures");
     if (e != hipSuccess) return fail(CRYCHIC_E_HIP, "raster pass failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
+int crychic_raster_status(crychic_ctx* ctx, void* stream, uint32_t* flags)
+{
+    if (int rc = bind(ctx)) return rc;
+    if (!flags) return fail(CRYCHIC_E_INVALID_ARG, "flags is null");
+    *flags = 0;
+    if (!ctx->rasterStatus) return fail(CRYCHIC_E_INVALID_ARG, "no producer pass has been issued on this context");
+    CRY_HIP(hipMemcpyAsync(flags, ctx->rasterStatus, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
+    CRY_HIP(hipStreamSynchronize((hipStream_t)stream));
     return 0;
 }
 

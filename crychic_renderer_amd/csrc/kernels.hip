@@ -62,13 +62,26 @@ __device__ __forceinline__ void tile_origin_2d(uint32_t& bx, uint32_t& by, uint3
 // ---- SSAO ------------------------------------------------------------------------------------------------
 // Re-lays the D24 depth plane as decoded {d(x, y), d(x, y+1)} entries with a BORDER guard band (ssao_core.hpp "depth pairs"):
 // one lane per two horizontally adjacent entries (a 16-byte store), rows y = -2 .. H, entries x = -2 .. W+1.
-__global__ __launch_bounds__(256) void depth_pairs_kernel(const uint32_t* __restrict__ depth, f4a* __restrict__ pairs, uint32_t W, uint32_t H)
+// By-product: the coarse geometry map of the sky shortcut (ssao_core.hpp).  A wave covers texel columns
+// [128 blockIdx.x - 2, 128 blockIdx.x + 126) of row y = py - 2 (through the .x / .z components of its entries); if any of them
+// lies below the clear depth it stamps the cell (blockIdx.x, y / 32) with this frame's stamp -- a plain store: every writer of
+// a cell stores the same value, and a stale or uninitialised word can only read as "geometry" (no shortcut), never as "sky".
+__global__ __launch_bounds__(256) void depth_pairs_kernel(const uint32_t* __restrict__ depth, f4a* __restrict__ pairs, uint32_t* __restrict__ geo,
+                                                          uint32_t stamp, uint32_t W, uint32_t H)
 {
     const uint32_t halfPitch = depth_pairs_pitch(W) / 2u;
     const uint32_t px2 = blockIdx.x * 64u + (threadIdx.x & 63u);
     const uint32_t py = blockIdx.y * 4u + (threadIdx.x >> 6);
-    if (px2 >= halfPitch || py >= H + 3u) return;
-    pairs[py * halfPitch + px2] = depth_pairs_entry2(depth, W, H, 2 * (int)px2 - 2, (int)py - 2);
+    if (py >= H + 3u) return;                                   // wave-uniform
+    bool geometry = false;
+    if (px2 < halfPitch) {
+        const f4a e = depth_pairs_entry2(depth, W, H, 2 * (int)px2 - 2, (int)py - 2);
+        pairs[py * halfPitch + px2] = e;
+        geometry = (e.x != 1.0f) | (e.z != 1.0f);              // texels (x, y), (x + 1, y): BORDER and clear-depth texels decode to 1.0
+    }
+    const uint32_t y = py - 2u;
+    if (__builtin_amdgcn_ballot_w64(geometry) != 0 && (threadIdx.x & 63u) == 0 && y < H)
+        geo[(y >> 5) * geo_map_cols(W) + blockIdx.x] = stamp;
 }
 
 // Shaders/Ssao.hlsl:117-199 over half-res rows [row0, row1).  EMIT_AO = false builds only the edge workspace.
@@ -78,7 +91,8 @@ __global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, co
                                                    const uint32_t* __restrict__ depth,
                                                    const uint32_t* __restrict__ randvec,
                                                    uint16_t* __restrict__ ambient, EdgePlane edge, uint32_t W,
-                                                   uint32_t H, uint32_t row0, uint32_t row1, uint32_t SX, uint32_t SY, int sparseProjTex)
+                                                   uint32_t H, uint32_t row0, uint32_t row1, uint32_t SX, uint32_t SY, int sparseProjTex,
+                                                   SkyReach sky, uint32_t stamp)
 {
     const uint32_t w2 = W / 2;
     uint32_t bx, by;
@@ -96,6 +110,21 @@ __global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, co
         edge.vz[idx] = c.vz;
         if (x == 0) edge.gcol[y] = normal[(2u * y + 1u) * W];   // texel (0, 2y+1)
         if (y == row0) edge.grow[x] = normal[2u * x + 1u];      // texel (2x+1, 0)
+    }
+    // Sky shortcut (ssao_core.hpp): every live lane of this wave is a sky pixel and no cell its taps can reach holds geometry
+    if (EMIT_AO && PAIRS && sky.enabled && __builtin_amdgcn_ballot_w64(!c.sky) == 0) {
+        const uint32_t x0 = bx * 64u, n = (w2 - x0) < 64u ? (w2 - x0) : 64u;
+        const GeoCells g = ssao_sky_cells(sky, W, H, x0, n, y);
+        const uint32_t ncx = g.cx1 - g.cx0 + 1u, ncells = ncx * (g.cy1 - g.cy0 + 1u), pitch = geo_map_cols(W);
+        bool geometry = false;
+        for (uint32_t k = threadIdx.x & 63u; k < ncells; k += n) {          // the wave's n live lanes (0 .. n-1) share the cells
+            const uint32_t cy = k / ncx, cx = k - cy * ncx;
+            geometry |= edge.geo[(g.cy0 + cy) * pitch + g.cx0 + cx] == stamp;
+        }
+        if (__builtin_amdgcn_ballot_w64(geometry) == 0) {
+            ambient[y * w2 + x] = (uint16_t)0xFFFFu;
+            return;
+        }
     }
     if (EMIT_AO) {
         const uint32_t v = PAIRS ? ssao_pixel(cb, c, dp, randvec, W, H, x, y, sparseProjTex != 0) : ssao_pixel(cb, c, dd, randvec, W, H, x, y, sparseProjTex != 0);
@@ -424,17 +453,17 @@ static inline dim3 grid_for(uint32_t width, uint32_t rows, uint32_t rows_per_blo
     return dim3((width + 63u) / 64u, (rows + rows_per_block - 1u) / rows_per_block, 1);
 }
 
-hipError_t launch_depth_pairs(const uint32_t* depth, void* edge_base, uint32_t W, uint32_t H, hipStream_t stream)
+hipError_t launch_depth_pairs(const uint32_t* depth, void* edge_base, uint32_t W, uint32_t H, uint32_t stamp, hipStream_t stream)
 {
     const EdgePlane e = edge_plane_carve(edge_base, W, H);
-    const dim3 grid((depth_pairs_pitch(W) / 2u + 63u) / 64u, (H + 3u + 3u) / 4u, 1);
-    hipLaunchKernelGGL(depth_pairs_kernel, grid, dim3(256), 0, stream, depth, (f4a*)const_cast<void*>(e.pairs), W, H);
+    const dim3 grid((depth_pairs_pitch(W) / 2u + 63u) / 64u, (H + 3u + 3u) / 4u, 1);      // grid.x == geo_map_cols(W)
+    hipLaunchKernelGGL(depth_pairs_kernel, grid, dim3(256), 0, stream, depth, (f4a*)const_cast<void*>(e.pairs), e.geo, stamp, W, H);
     return hipGetLastError();
 }
 
 hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, const uint32_t* depth,
                        const uint8_t* randvec, uint16_t* ambient, void* edge_base, uint32_t W, uint32_t H,
-                       uint32_t row0, uint32_t rows, bool emit_ao, bool use_pairs, hipStream_t stream)
+                       uint32_t row0, uint32_t rows, bool emit_ao, bool use_pairs, uint32_t stamp, hipStream_t stream)
 {
     if (rows == 0) return hipSuccess;
     EdgePlane e{};
@@ -450,7 +479,9 @@ hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, con
     grid.x = (grid.x + SX - 1u) / SX * SX;
     grid.y = (grid.y + SY - 1u) / SY * SY;
     const int sparse = ssao_projtex_is_sparse(cb) ? 1 : 0;
-#define CRY_LAUNCH_SSAO(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, cb, (const u2*)normal, depth, (const uint32_t*)randvec, ambient, e, W, H, row0, row0 + rows, SX, SY, sparse)
+    SkyReach sky = ssao_sky_reach(cb, W, H);
+    if (!use_pairs || stamp == 0u) sky.enabled = 0;      // stamp 0: the caller did not build the geometry map
+#define CRY_LAUNCH_SSAO(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, cb, (const u2*)normal, depth, (const uint32_t*)randvec, ambient, e, W, H, row0, row0 + rows, SX, SY, sparse, sky, stamp)
     if (emit_ao && use_pairs) CRY_LAUNCH_SSAO((ssao_kernel<true, true>));
     else if (emit_ao) CRY_LAUNCH_SSAO((ssao_kernel<true, false>));
     else CRY_LAUNCH_SSAO((ssao_kernel<false, false>));

@@ -9,11 +9,12 @@ namespace cry {
 struct LightParams;
 
 // D24 depth plane -> the decoded, BORDER-padded pairs plane inside the edge workspace (ssao_core.hpp "depth pairs"); whole plane.
-hipError_t launch_depth_pairs(const uint32_t* depth, void* edge_base, uint32_t W, uint32_t H, hipStream_t stream);
+// `stamp` (non-zero, different from the previous frame's) marks the cells of the coarse geometry map written by this call.
+hipError_t launch_depth_pairs(const uint32_t* depth, void* edge_base, uint32_t W, uint32_t H, uint32_t stamp, hipStream_t stream);
 // use_pairs: the taps read the pairs plane (launch_depth_pairs earlier on the same stream) instead of the raw D24 plane.
 hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, const uint32_t* depth,
                        const uint8_t* randvec, uint16_t* ambient, void* edge_base, uint32_t W, uint32_t H,
-                       uint32_t row0, uint32_t rows, bool emit_ao, bool use_pairs, hipStream_t stream);
+                       uint32_t row0, uint32_t rows, bool emit_ao, bool use_pairs, uint32_t stamp, hipStream_t stream);
 
 // Plain: a self-contained sweep.  Record: same, and stores the per-pixel tap decisions + totalWeight of this
 // direction in the edge workspace.  Replay: uses what a Record sweep of the same direction stored (same geometry).
@@ -45,10 +46,12 @@ struct RasterPass {
     uint32_t* depth; void* normal; float* g0; float* g1; float* g2;
     void* workspace; size_t workspaceBytes;
     uint32_t gRow0, gRows;                  // G-buffer rows to render (a rank's strip); gRows == 0 = the whole target
+    const uint32_t* statusWord;             // OUT: device address of the pass's status word (bit 0: a vertex left the +-2^22 px
+                                            // range and its triangle was dropped; bit 1: a vertex index outside the vertex buffer)
     // fused shadow pass (mode 0, nTargets 2..4): one ViewProj and one depth target per cascade, same items
     uint32_t nTargets; const float* viewProjN[4]; uint32_t* depthN[4];
 };
 size_t raster_workspace_bytes(uint64_t triangles, uint32_t W, uint32_t H);
-hipError_t launch_raster_pass(const RasterPass& p, hipStream_t stream);
+hipError_t launch_raster_pass(RasterPass& p, hipStream_t stream);
 
 }  // namespace cry

@@ -195,7 +195,7 @@ size_t raster_workspace_bytes(uint64_t triangles, uint32_t W, uint32_t H)
     return (size_t)((uint64_t)W * H * 8u + slots * sizeof(SetupTri) + slots * 4u + 64u * sizeof(Texture) + sizeof(RasterCounters) + 1024u);
 }
 
-hipError_t launch_raster_pass(const RasterPass& p, hipStream_t stream)
+hipError_t launch_raster_pass(RasterPass& p, hipStream_t stream)
 {
     // carve the workspace: vis | tris | live | textures | counters (all 16-byte aligned)
     uint64_t total = 0;
@@ -213,6 +213,7 @@ hipError_t launch_raster_pass(const RasterPass& p, hipStream_t stream)
     uint32_t* live = (uint32_t*)(base + off); off += ((size_t)slots * 4u + 15u) & ~(size_t)15u;
     Texture* texDev = (Texture*)(base + off); off += 64u * sizeof(Texture);
     RasterCounters* counters = (RasterCounters*)(base + off);
+    p.statusWord = &counters->overflow;
 
     const uint32_t npx = p.W * p.H;
     ViewProjSet vps;

@@ -29,6 +29,7 @@ struct EdgePlane {
     float* total_v;
     uint16_t* spare;   // a third ambient plane: lets an odd number of fused replay iterations end in ambient0 (api.cpp)
     const void* pairs; // DepthPairs plane (below), depth_pairs_bytes(W, H)
+    uint32_t* geo;     // coarse geometry map (below "sky shortcut"), geo_map_bytes(W, H)
 };
 
 // ---- depth pairs -----------------------------------------------------------------------------------------------------
@@ -46,7 +47,14 @@ CRY_HD size_t edge_plane_pairs_offset(uint32_t W, uint32_t H)
     size_t w2 = W / 2, h2 = H / 2;
     return (w2 * h2 * 26 + (w2 + h2) * 8 + 15) & ~(size_t)15;
 }
-CRY_HD size_t edge_plane_bytes(uint32_t W, uint32_t H) { return edge_plane_pairs_offset(W, H) + depth_pairs_bytes(W, H); }
+// Coarse geometry map: one word per cell of 128 x 32 depth texels, holding the frame stamp of the last frame in which the
+// cell contained a texel below the clear depth.  Cell cx covers texel columns [128 cx - 2, 128 cx + 126) -- the footprint of
+// one wave of depth_pairs_kernel -- and cell cy rows [32 cy, 32 cy + 32).
+CRY_HD uint32_t geo_map_cols(uint32_t W) { return (W + 2u) / 128u + 1u; }
+CRY_HD uint32_t geo_map_rows(uint32_t H) { return (H + 31u) / 32u; }
+CRY_HD size_t geo_map_bytes(uint32_t W, uint32_t H) { return (size_t)geo_map_cols(W) * geo_map_rows(H) * 4u; }
+CRY_HD size_t edge_plane_geo_offset(uint32_t W, uint32_t H) { return (edge_plane_pairs_offset(W, H) + depth_pairs_bytes(W, H) + 15) & ~(size_t)15; }
+CRY_HD size_t edge_plane_bytes(uint32_t W, uint32_t H) { return edge_plane_geo_offset(W, H) + geo_map_bytes(W, H); }
 // Entries (x, y) and (x + 1, y) of the pairs plane from the D24 plane; x even (so the two texels of a row are one 8-byte load).
 CRY_HD f4a depth_pairs_entry2(const uint32_t* __restrict__ depth, uint32_t W, uint32_t H, int x, int y)
 {
@@ -72,6 +80,7 @@ CRY_HD EdgePlane edge_plane_carve(void* base, uint32_t W, uint32_t H)
     e.grow = e.gcol + h2;                 // w2 * 8
     e.spare = (uint16_t*)(b + n * 24 + (w2 + h2) * 8);   // n * 2
     e.pairs = b + edge_plane_pairs_offset(W, H);
+    e.geo = (uint32_t*)(b + edge_plane_geo_offset(W, H));
     return e;
 }
 
@@ -179,31 +188,6 @@ CRY_HD f3 randvec_linear_wrap(const uint32_t* __restrict__ rv, float u, float v)
     return o;
 }
 
-struct SsaoCentre {
-    u2 nrm_bits;  // raw fp16 normal texel
-    float vz;        // linear view depth at the pixel centre
-};
-
-CRY_HD SsaoCentre ssao_centre(const crychic_ssao_constants& cb, const u2* __restrict__ normal,
-                              const uint32_t* __restrict__ depth, uint32_t W, uint32_t H, int x, int y)
-{
-    SsaoCentre c;
-    c.nrm_bits = normal_texel_bits(normal, W, H, x, y);
-    c.vz = ndc_to_view(cb, depth_at_half_pixel(depth, W, H, x, y));
-    return c;
-}
-// The same from the pairs plane (pixel inside the half-res map): the footprint at (2x, 2y) with weights 1/2.
-CRY_HD SsaoCentre ssao_centre(const crychic_ssao_constants& cb, const u2* __restrict__ normal, const DepthPairs depth,
-                              uint32_t W, uint32_t H, int x, int y)
-{
-    SsaoCentre c;
-    c.nrm_bits = normal_texel_bits(normal, W, H, x, y);
-    float t00, t10, t01, t11;
-    depth.footprint(2 * x, 2 * y, t00, t10, t01, t11);
-    c.vz = ndc_to_view(cb, bilerp(t00, t10, t01, t11, 0.5f, 0.5f));
-    return c;
-}
-
 // gProjTex = Proj * T (CRYCHIC.cpp:828-834,918) has seven structural zeros and a one for every perspective projection:
 //   x' = q.x PT[0] + q.z PT[2],  y' = q.y PT[5] + q.z PT[6],  w' = q.z.
 // Skipping the products with exact zeros changes no output bit as long as q is finite (x * 0 = +-0, and a +-0 term can
@@ -222,6 +206,105 @@ CRY_HD bool ssao_projtex_is_sparse(const crychic_ssao_constants& cb)
     for (int i = 0; i < 14; ++i)
         for (int k = 0; k < 3; ++k) ok = ok && __builtin_fabsf(cb.OffsetVectors[i][k]) < big;   // false for NaN too
     return ok;
+}
+
+// ---- sky shortcut -------------------------------------------------------------------------------------------------------
+// A pixel whose own footprint and every tap footprint read only texels at the clear depth has ambient access exactly 1:
+// every tap then samples z_ndc = 1, so rz equals the pixel's own pz bit for bit, distZ = p.z - r.z is a few ulps of the far
+// distance -- below SurfaceEpsilon -- the occlusion term is 0 and a finite dp times 0 leaves the sum at +0.  Where the taps
+// of such a pixel can land is bounded on the host from the constants (SkyReach); whether that neighbourhood is free of geometry
+// is answered by the coarse geometry map the depth-pairs pass fills.  A wavefront of such pixels writes 65535 and skips its
+// 14 taps (arithmetic and gather); in the benchmark frame that is about 45 % of all wavefronts.  Exact by construction and by
+// the parity / fuzz tests, which run the kernel bodies with the shortcut against an oracle that has none.
+struct SkyReach {
+    int enabled;          // 0: the constants do not allow the argument (see ssao_sky_reach)
+    uint32_t rx, ry;      // a sky pixel's taps stay within +-rx / +-ry depth texels of its own 2 x 2 footprint
+};
+CRY_HD SkyReach ssao_sky_reach(const crychic_ssao_constants& cb, uint32_t W, uint32_t H)
+{
+    SkyReach r{ 0, 0u, 0u };
+    if (!ssao_projtex_is_sparse(cb)) return r;
+    const double A = cb.Proj[4 * 2 + 2], B = cb.Proj[4 * 2 + 3];
+    const double farZ = B / (1.0 - A);                            // view depth of z_ndc = 1 (Ssao.hlsl:110-115)
+    const double eps = cb.SurfaceEpsilon, R = __builtin_fabs((double)cb.OcclusionRadius);
+    if (!(farZ > 0.0) || !(farZ < 1.0e6) || !(eps > farZ * 1.52587890625e-5)) return r;      // |distZ| <= a few ulp(far) << 2^-16 far < eps
+    double omax = 0.0;
+    for (int i = 0; i < 14; ++i) {
+        const double o = __builtin_sqrt((double)cb.OffsetVectors[i][0] * cb.OffsetVectors[i][0] + (double)cb.OffsetVectors[i][1] * cb.OffsetVectors[i][1] +
+                                        (double)cb.OffsetVectors[i][2] * cb.OffsetVectors[i][2]);
+        omax = o > omax ? o : omax;
+    }
+    // |reflect(o, rv)| <= |o| (1 + 2 |rv|^2) with rv in [-1, 1]^3; the tap moves q by at most D in view space
+    const double D = R * omax * 7.0 * 1.001;
+    if (!(D < 0.5 * farZ)) return r;
+    // view-ray slopes |PosV.x / PosV.z|, |PosV.y / PosV.z| at the screen corners (VS :58-72)
+    double tx = 0.0, ty = 0.0;
+    for (int c = 0; c < 4; ++c) {
+        const double hx = (c & 1) ? 1.0 : -1.0, hy = (c & 2) ? 1.0 : -1.0;
+        double ph[4];
+        for (int j = 0; j < 4; ++j) ph[j] = hx * cb.InvProj[4 * j + 0] + hy * cb.InvProj[4 * j + 1] + cb.InvProj[4 * j + 3];
+        if (!(__builtin_fabs(ph[2]) > 1.0e-12)) return r;
+        const double sx = __builtin_fabs(ph[0] / ph[2]), sy = __builtin_fabs(ph[1] / ph[2]);
+        tx = sx > tx ? sx : tx; ty = sy > ty ? sy : ty;
+    }
+    // u = PT0 q.x / q.z + PT2 (sparse gProjTex): |q.x / q.z - p.x / p.z| <= D (1 + t) / (far - D), in texels times W |PT0|;
+    // + 2 for the bilinear footprint, + 6 of slack for the binary32 evaluation of both sides
+    const double dx = (double)W * __builtin_fabs((double)cb.ProjTex[0]) * D * (1.0 + tx) / (farZ - D);
+    const double dy = (double)H * __builtin_fabs((double)cb.ProjTex[5]) * D * (1.0 + ty) / (farZ - D);
+    if (!(dx < 4096.0) || !(dy < 4096.0)) return r;
+    r.enabled = 1;
+    r.rx = (uint32_t)dx + 8u;
+    r.ry = (uint32_t)dy + 8u;
+    return r;
+}
+// Lane predicate: the pixel's own footprint is four texels at the clear depth (so pz is the far distance exactly) and its
+// normal is finite (an infinite normal would turn 0 * dp into NaN).
+CRY_HD bool ssao_sky_lane(float t00, float t10, float t01, float t11, u2 nrmBits)
+{
+    const f3 n = unpack_normal(nrmBits);
+    const bool finite = (__builtin_fabsf(n.x) < 3.0e38f) & (__builtin_fabsf(n.y) < 3.0e38f) & (__builtin_fabsf(n.z) < 3.0e38f);
+    return (t00 == 1.0f) & (t10 == 1.0f) & (t01 == 1.0f) & (t11 == 1.0f) & finite;
+}
+// The cells of the coarse geometry map that the taps of half-res pixels [x0, x0 + n) of half-res row y can reach.
+struct GeoCells { uint32_t cx0, cx1, cy0, cy1; };
+CRY_HD GeoCells ssao_sky_cells(const SkyReach& r, uint32_t W, uint32_t H, uint32_t x0, uint32_t n, uint32_t y)
+{
+    const int xa = 2 * (int)x0 - (int)r.rx, xb = 2 * (int)(x0 + n) - 1 + (int)r.rx;      // texel columns, inclusive
+    const int ya = 2 * (int)y - (int)r.ry, yb = 2 * (int)y + 1 + (int)r.ry;
+    GeoCells g;                                       // texels outside the plane are BORDER = the clear depth: nothing to look up
+    g.cx0 = (uint32_t)((clampi(xa, 0, (int)W - 1) + 2) / 128);
+    g.cx1 = (uint32_t)((clampi(xb, 0, (int)W - 1) + 2) / 128);
+    g.cy0 = (uint32_t)(clampi(ya, 0, (int)H - 1) / 32);
+    g.cy1 = (uint32_t)(clampi(yb, 0, (int)H - 1) / 32);
+    return g;
+}
+
+struct SsaoCentre {
+    u2 nrm_bits;  // raw fp16 normal texel
+    float vz;        // linear view depth at the pixel centre
+    bool sky;        // ssao_sky_lane(): candidate for the sky shortcut (pairs path only)
+};
+
+CRY_HD SsaoCentre ssao_centre(const crychic_ssao_constants& cb, const u2* __restrict__ normal,
+                              const uint32_t* __restrict__ depth, uint32_t W, uint32_t H, int x, int y)
+{
+    SsaoCentre c;
+    c.nrm_bits = normal_texel_bits(normal, W, H, x, y);
+    c.vz = ndc_to_view(cb, depth_at_half_pixel(depth, W, H, x, y));
+    c.sky = false;
+    return c;
+}
+// The same from the pairs plane (pixel inside the half-res map): the footprint at (2x, 2y) with weights 1/2.
+CRY_HD SsaoCentre ssao_centre(const crychic_ssao_constants& cb, const u2* __restrict__ normal, const DepthPairs depth,
+                              uint32_t W, uint32_t H, int x, int y)
+{
+    SsaoCentre c;
+    c.nrm_bits = normal_texel_bits(normal, W, H, x, y);
+    float t00, t10, t01, t11;
+    depth.footprint(2 * x, 2 * y, t00, t10, t01, t11);
+    c.vz = ndc_to_view(cb, bilerp(t00, t10, t01, t11, 0.5f, 0.5f));
+    c.sky = ssao_sky_lane(t00, t10, t01, t11, c.nrm_bits);
+    return c;
 }
 
 // Ssao.hlsl:117-199 for half-res pixel (x, y); returns the R16_UNORM ambient value.  `sparseProjTex` = ssao_projtex_is_sparse(cb).

@@ -326,6 +326,14 @@ int crychic_draw_gbuffer(crychic_ctx* ctx, const crychic_pass_constants* passCB,
                          const crychic_texture* textures, uint32_t nTextures, float* g0_dev, float* g1_dev, float* g2_dev,
                          uint32_t* depth_dev, uint32_t W, uint32_t H, void* workspace_dev, size_t workspaceBytes, void* stream);
 
+/* What the most recent producer pass on this context had to drop (its workspace must still be alive): waits for `stream`, then
+ * *flags = CRYCHIC_RASTER_* bits, 0 when every triangle was rasterised.  The D3D12 runtime clips to a guard band and would render
+ * such triangles; this rasteriser clips to 0 <= z <= w only and DROPS a triangle with a vertex beyond +-2^22 pixels (its
+ * fixed-point edge functions are defined up to there) -- a caller that can produce such geometry should check. */
+#define CRYCHIC_RASTER_COORD_OVERFLOW 1u   /* a post-clip vertex left the +-2^22 pixel range: triangle dropped */
+#define CRYCHIC_RASTER_BAD_INDEX 2u        /* an index pointed outside the item's vertex buffer: triangle dropped */
+int crychic_raster_status(crychic_ctx* ctx, void* stream, uint32_t* flags);
+
 /* All cascades of CRYCHIC::DrawSceneToShadowMap (CRYCHIC.cpp:2477-2510 loops over four) in one pass: passCBs[c].ViewProj and
  * shadow_dev[c] per cascade, the same items for all.  Bit-identical to nCascades calls of crychic_draw_scene_to_shadow_map;
  * the workspace must hold crychic_raster_workspace_bytes(nCascades * triangles, shadowDim, shadowDim). */

@@ -74,3 +74,38 @@ def same_floats(a, b):
     a = np.ascontiguousarray(a); b = np.ascontiguousarray(b)
     an, bn = np.isnan(a), np.isnan(b)
     return bool(np.array_equal(an, bn) and np.array_equal(a.view(np.uint32)[~an], b.view(np.uint32)[~bn]))
+
+
+def sky_probe_case(seed):
+    """Inputs for the SSAO sky-shortcut probe (tests/test_hostsim_parity.py::test_sky_shortcut_is_exact and its device twin): a sky
+    field with small patches of geometry within OcclusionFadeEnd of the far distance."""
+    import oracle_lib
+    from crychic_renderer_amd import scene
+    rng = np.random.default_rng(1000 + seed)
+    W, H = int(rng.choice([640, 770, 1024])), int(rng.choice([384, 400, 512]))       # several cells of the coarse geometry map each way
+    c = scene.Constants(W, H, shadow_dim=64)
+    scb = oracle_lib.as_oracle_cb(c.ssao_cb, oracle_lib.OrSsaoConstants)
+    A, B = c.ssao_cb.Proj[10], c.ssao_cb.Proj[11]
+    depth = np.full((H, W), 0xFFFFFF, dtype=np.uint32)
+    # sky normals facing the camera (with the reference's clear value (0, 0, 1) an occluder in front of a far-plane pixel always
+    # has dp = 0): random unit-ish vectors or (0, 0, -1), so that a tap landing on a patch really contributes
+    normal = np.zeros((H, W, 4), dtype=np.float16); normal[..., 2] = -1.0
+    if seed % 2:
+        normal[..., :3] = rng.standard_normal((H, W, 3)).astype(np.float16)
+    for _ in range(int(rng.integers(1, 5))):
+        pw, ph = int(rng.integers(1, 24)), int(rng.integers(1, 16))
+        x0, y0 = int(rng.integers(0, W - pw)), int(rng.integers(0, H - ph))
+        if seed >= 12:      # hug the corner of a cell of the coarse geometry map (128 x 32 texels, columns offset by -2): worst case for the reach bound
+            pw, ph = int(rng.integers(1, 3)), int(rng.integers(1, 3))
+            x0 = min(W - pw, 128 * int(rng.integers(1, W // 128)) - 2 - int(rng.integers(0, 2)) * pw)
+            y0 = min(H - ph, 32 * int(rng.integers(1, H // 32)) - int(rng.integers(0, 2)) * ph)
+        vz = rng.uniform(99.0, 99.999, size=(ph, pw))                       # inside the occluding band of a pixel at the far distance
+        zndc = A + B / vz
+        depth[y0:y0 + ph, x0:x0 + pw] = np.round(zndc * 16777215.0).astype(np.uint32)
+        normal[y0:y0 + ph, x0:x0 + pw, :3] = rng.standard_normal((ph, pw, 3)).astype(np.float16)
+    if seed % 4 == 3:
+        normal[rng.random((H, W)) < 0.01, 0] = np.inf                        # a non-finite normal keeps its wavefront off the shortcut
+    randvec = rng.integers(0, 256, size=(256, 256, 4), dtype=np.uint8)
+    if seed >= 12:
+        randvec = (rng.integers(0, 2, size=(256, 256, 4), dtype=np.uint8) * 255).astype(np.uint8)      # |randVec| = sqrt(3): the longest reflected offsets
+    return W, H, c, scb, depth, normal, randvec

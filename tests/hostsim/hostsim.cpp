@@ -43,6 +43,9 @@ void hs_eval_array(int kind, size_t n, const float* in, const float* in2, float*
     }
 }
 
+static uint32_t g_sky_waves = 0;     // wavefronts the last hs_ssao_path call resolved through the sky shortcut
+uint32_t hs_last_sky_waves(void) { return g_sky_waves; }
+
 // use_pairs != 0: the product's default path -- build the decoded depth-pairs plane in the edge workspace (the body of
 // depth_pairs_kernel) and let the taps gather from it; 0: taps on the raw D24 plane (what runs without a workspace).
 void hs_ssao_path(const crychic_ssao_constants* cb, const void* normal, const uint32_t* depth, const uint8_t* randvec,
@@ -62,19 +65,51 @@ void hs_ssao_path(const crychic_ssao_constants* cb, const void* normal, const ui
     const DepthPairs dp{ e.pairs, depth_pairs_pitch(W) };
     const DepthD24 dd{ depth, W, H };
     const bool sparse = ssao_projtex_is_sparse(*cb);
-    for (uint32_t y = row0; y < row0 + rows; ++y)
+    // the coarse geometry map as depth_pairs_kernel fills it (stamp 1 on a zeroed map), and the sky shortcut per "wavefront"
+    // of 64 consecutive pixels of a row, exactly as ssao_kernel takes it
+    SkyReach sky = ssao_sky_reach(*cb, W, H);
+    if (!pairs) sky.enabled = 0;
+    const uint32_t stamp = 1u, gpitch = geo_map_cols(W);
+    if (pairs) {
+        std::memset(e.geo, 0, geo_map_bytes(W, H));
+        const uint32_t halfPitch = depth_pairs_pitch(W) / 2u;
+        const f4a* pp = (const f4a*)e.pairs;
+        for (uint32_t py = 2; py < H + 2u; ++py)
+            for (uint32_t px2 = 0; px2 < halfPitch; ++px2) {
+                const f4a v = pp[py * halfPitch + px2];
+                if (v.x != 1.0f || v.z != 1.0f) e.geo[((py - 2u) >> 5) * gpitch + px2 / 64u] = stamp;
+            }
+    }
+    std::vector<SsaoCentre> row(w2);
+    g_sky_waves = 0;
+    for (uint32_t y = row0; y < row0 + rows; ++y) {
         for (uint32_t x = 0; x < w2; ++x) {
             const SsaoCentre c = pairs ? ssao_centre(*cb, nrm, dp, W, H, (int)x, (int)y) : ssao_centre(*cb, nrm, depth, W, H, (int)x, (int)y);
+            row[x] = c;
             if (e.nrm) {
                 e.nrm[y * w2 + x] = c.nrm_bits;
                 e.vz[y * w2 + x] = c.vz;
                 if (x == 0) e.gcol[y] = nrm[(2u * y + 1u) * W];
                 if (y == row0) e.grow[x] = nrm[2u * x + 1u];
             }
-            if (ambient)
-                ambient[y * w2 + x] = (uint16_t)(pairs ? ssao_pixel(*cb, c, dp, (const uint32_t*)randvec, W, H, x, y, sparse)
-                                                       : ssao_pixel(*cb, c, dd, (const uint32_t*)randvec, W, H, x, y, sparse));
         }
+        if (!ambient) continue;
+        for (uint32_t x0 = 0; x0 < w2; x0 += 64u) {
+            const uint32_t n = (w2 - x0) < 64u ? (w2 - x0) : 64u;
+            bool skip = sky.enabled != 0;
+            for (uint32_t k = 0; k < n && skip; ++k) skip = row[x0 + k].sky;
+            if (skip) {
+                const GeoCells g = ssao_sky_cells(sky, W, H, x0, n, y);
+                for (uint32_t cy = g.cy0; cy <= g.cy1 && skip; ++cy)
+                    for (uint32_t cx = g.cx0; cx <= g.cx1 && skip; ++cx) skip = e.geo[cy * gpitch + cx] != stamp;
+            }
+            g_sky_waves += skip ? 1u : 0u;
+            for (uint32_t x = x0; x < x0 + n; ++x)
+                ambient[y * w2 + x] = skip ? (uint16_t)0xFFFFu
+                                           : (uint16_t)(pairs ? ssao_pixel(*cb, row[x], dp, (const uint32_t*)randvec, W, H, x, y, sparse)
+                                                              : ssao_pixel(*cb, row[x], dd, (const uint32_t*)randvec, W, H, x, y, sparse));
+        }
+    }
 }
 void hs_ssao(const crychic_ssao_constants* cb, const void* normal, const uint32_t* depth, const uint8_t* randvec,
              uint16_t* ambient, void* edge_base, uint32_t W, uint32_t H, uint32_t row0, uint32_t rows)

@@ -53,6 +53,7 @@ class HostSim:
         L.hs_eval_array.argtypes = [i, C.c_size_t, vp, vp, vp]
         L.hs_ssao.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, u32, u32]
         L.hs_ssao_path.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, i]
+        L.hs_last_sky_waves.restype = u32
         L.hs_blur.argtypes = [vp, vp, vp, vp, u32, u32, i, u32, u32]
         L.hs_blur_mode.argtypes = [vp, vp, vp, vp, u32, u32, i, i, u32, u32]
         L.hs_rasterize.restype = i

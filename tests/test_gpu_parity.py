@@ -290,6 +290,31 @@ def test_c3_4k_properties(ctx, built_lib, oracle):
         assert np.array_equal(app.mBackBuffer.cpu().numpy(), ref)
 
 
+@pytest.mark.parametrize("seed", [0, 1, 3, 12, 13, 15, 18])
+def test_sky_shortcut_on_device(ctx, built_lib, oracle, seed):
+    """The SSAO sky shortcut on the device (wave-level skip driven by the coarse geometry map of depth_pairs_kernel) against the
+    oracle, on the probe frames of tests/test_hostsim_parity.py::test_sky_shortcut_is_exact; run twice on the same workspace so
+    that a stale geometry map from the previous frame can only make the second run more conservative, never wrong."""
+    import fuzz_util
+    W, H, c, scb, depth, normal, randvec = fuzz_util.sky_probe_case(seed)
+    lib, check = built_lib.lib, built_lib.check
+    dev = ctx.device
+    d = torch.from_numpy(depth.view(np.int32)).to(dev); n = torch.from_numpy(normal).to(dev); r = torch.from_numpy(randvec).to(dev)
+    a0 = torch.zeros((H // 2, W // 2), dtype=torch.int16, device=dev)
+    edge = torch.zeros((int(lib.crychic_edge_plane_bytes(W, H)),), dtype=torch.uint8, device=dev)
+    ref = oracle.ssao(scb, normal, depth, randvec)
+    check(lib.crychic_ssao(ctx.handle, C.byref(c.ssao_cb), ptr(n), ptr(d), ptr(r), ptr(a0), ptr(edge), W, H, 0, H // 2, stream(ctx)))
+    torch.cuda.synchronize()
+    assert np.array_equal(dev_u16(a0), ref)
+    # next frame on the same workspace: the sky and the geometry swap sides of the frame
+    depth2 = np.ascontiguousarray(depth[:, ::-1]); normal2 = np.ascontiguousarray(normal[:, ::-1])
+    d.copy_(torch.from_numpy(depth2.view(np.int32))); n.copy_(torch.from_numpy(normal2))
+    ref2 = oracle.ssao(scb, normal2, depth2, randvec)
+    check(lib.crychic_ssao(ctx.handle, C.byref(c.ssao_cb), ptr(n), ptr(d), ptr(r), ptr(a0), ptr(edge), W, H, 0, H // 2, stream(ctx)))
+    torch.cuda.synchronize()
+    assert np.array_equal(dev_u16(a0), ref2)
+
+
 def test_flat_wall_ssao_is_unoccluded(ctx, built_lib):
     """a flat plane facing the camera has distZ = 0 <= eps for every tap => access = 1."""
     W, H = 128, 128

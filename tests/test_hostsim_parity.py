@@ -121,3 +121,30 @@ def test_quirk_fix_switches(built_lib, oracle, hostsim, fixes):
         assert np.array_equal(got, ref) and np.array_equal(rgot.view(np.uint32), rref.view(np.uint32))
         if radius == 0.0 and fixes != 0x100:        # Q1 only matters where the two blended cascades disagree
             assert (ref != base).mean() > 0.01
+
+
+@pytest.mark.parametrize("seed", range(20))
+def test_sky_shortcut_is_exact(built_lib, oracle, hostsim, seed):
+    """The SSAO sky shortcut (ssao_core.hpp): a wavefront of clear-depth pixels whose tap neighbourhood holds no geometry writes
+    65535 without running its taps.  Probe its reach bound: a sky field with small patches of geometry placed so close to the
+    far plane that a sky pixel's tap landing on them DOES occlude (view depth within OcclusionFadeEnd of the far distance, and
+    bilinear mixes of patch and sky texels), at random distances from everything else.  Kernel bodies with the shortcut ==
+    oracle without one, the shortcut fires on most wavefronts, and some sky pixel is in fact occluded (so the probe bites)."""
+    import fuzz_util
+    W, H, c, scb, depth, normal, randvec = fuzz_util.sky_probe_case(seed)
+    eb = int(built_lib.lib.crychic_edge_plane_bytes(W, H))
+    ref = oracle.ssao(scb, normal, depth, randvec)
+    got, _ = hostsim.ssao(c.ssao_cb, normal, depth, randvec, eb)
+    skipped = int(hostsim.lib.hs_last_sky_waves())
+    assert np.array_equal(got, ref), int((got != ref).sum())
+    waves = (H // 2) * ((W // 2 + 63) // 64)
+    assert skipped > 0.3 * waves, (skipped, waves)
+    sky_half = (depth.reshape(H // 2, 2, W // 2, 2) == 0xFFFFFF).all(axis=(1, 3))
+    if seed % 4 != 3:
+        assert (ref[sky_half] < 65535).any(), "no sky pixel is occluded: the probe does not test the reach bound"
+    # a SurfaceEpsilon too small for the argument switches the shortcut off (and the result is still the oracle's)
+    c.ssao_cb.SurfaceEpsilon = 1.0e-6
+    scb = oracle_lib.as_oracle_cb(c.ssao_cb, oracle_lib.OrSsaoConstants)
+    got, _ = hostsim.ssao(c.ssao_cb, normal, depth, randvec, eb)
+    assert int(hostsim.lib.hs_last_sky_waves()) == 0
+    assert np.array_equal(got, oracle.ssao(scb, normal, depth, randvec))

@@ -140,6 +140,41 @@ def test_raster_argument_errors(ctx, built_lib):
     assert rc == -1 and b"workspace" in lib.crychic_last_error()
 
 
+@pytest.mark.gpu
+def test_raster_status_reports_dropped_triangles(ctx, built_lib):
+    """crychic_raster_status: a triangle with a post-clip vertex beyond +-2^22 pixels is dropped (no guard-band clipping) and a
+    bad vertex index is refused -- both are REPORTED instead of silently producing a wrong image."""
+    from crychic_renderer_amd import SceneGeometry, geometry as g
+    lib, check = built_lib.lib, built_lib.check
+    W = H = 64
+    flags = C.c_uint32(123)
+    cb = built_lib.PassConstants()
+    eye = np.eye(4, dtype=np.float32)
+    cb.ViewProj[:] = list(eye.reshape(-1)); cb.View[:] = list(eye.reshape(-1))
+    depth = torch.zeros((H, W), dtype=torch.int32, device=ctx.device)
+
+    def tri(pts, idx=(0, 1, 2)):
+        v = np.zeros(len(pts), dtype=g.VERTEX_DT)
+        v["Pos"] = np.asarray(pts, dtype=np.float32); v["Normal"] = (0, 0, -1); v["TangentU"] = (1, 0, 0)
+        both = list(idx) + [idx[0], idx[2], idx[1]]          # both windings: one of them faces the camera
+        return SceneGeometry(ctx, [(v, np.asarray(both, dtype=np.uint32), g.make_instances([np.eye(4, dtype=np.float32)], [0]))])
+
+    def draw(geo):
+        geo.DrawSceneToShadowMap(cb, depth, depth_bias=0, slope_bias=0.0)
+        check(lib.crychic_raster_status(ctx.handle, None, C.byref(flags)))
+        return flags.value, int((depth.cpu() != 0xFFFFFF).sum())
+
+    # an ordinary clockwise triangle inside the clip volume: nothing to report, pixels covered
+    st, cov = draw(tri([(-0.5, -0.5, 0.5), (-0.5, 0.5, 0.5), (0.5, -0.5, 0.5)]))
+    assert st == 0 and cov > 100
+    # one vertex 1e6 NDC units away (z inside the clip range, so the z-only clipper keeps it): dropped and flagged
+    st, cov = draw(tri([(-0.5, -0.5, 0.5), (-0.5, 0.5, 0.5), (1.0e6, -0.5, 0.5)]))
+    assert st & 1 and cov == 0
+    # an index outside the 3-vertex buffer
+    st, cov = draw(tri([(-0.5, -0.5, 0.5), (-0.5, 0.5, 0.5), (0.5, -0.5, 0.5)], idx=(0, 1, 7)))
+    assert st & 2 and cov == 0
+
+
 # ---- BASELINE configs[0]: CPU-only plumbing case ----------------------------------------------------------------------
 def test_c1_skull_oracle_matches_golden(built_lib, oracle):
     """256x256, skull.txt + 1 directional light, SSAO off: rendered by the CPU oracle end to end (rasteriser included)
