@@ -104,3 +104,22 @@ def test_gbuffer_with_reference_textures(built_lib, oracle, hostsim):
         assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
     cov = a["depth"] < 0xFFFFFF
     assert len(np.unique(a["g1"][cov][:, 0])) > 50                       # brick / tile texels modulate the albedo
+
+
+def test_save_ppm_round_trip(built_lib, tmp_path):
+    """Present stand-in (row f3; the reference hands the back buffer to IDXGISwapChain::Present, CRYCHIC.cpp:294-297):
+    crychic_save_ppm writes binary P6 with the alpha channel dropped; reading it back returns the RGB bytes."""
+    import ctypes as C
+    lib = built_lib.lib
+    rng = np.random.default_rng(11)
+    for (w, h) in ((1, 1), (5, 3), (800, 600)):
+        img = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+        path = tmp_path / ("f_%dx%d.ppm" % (w, h))
+        assert lib.crychic_save_ppm(str(path).encode(), img.ctypes.data, w, h) == 0
+        raw = path.read_bytes()
+        header = b"P6\n%d %d\n255\n" % (w, h)
+        assert raw.startswith(header) and len(raw) == len(header) + w * h * 3
+        assert np.array_equal(np.frombuffer(raw[len(header):], dtype=np.uint8).reshape(h, w, 3), img[..., :3])
+    assert lib.crychic_save_ppm(str(tmp_path / "no_such_dir" / "x.ppm").encode(), img.ctypes.data, 4, 4) < 0
+    assert lib.crychic_save_ppm(None, img.ctypes.data, 4, 4) < 0 and lib.crychic_save_ppm(str(path).encode(), None, 4, 4) < 0
+    assert lib.crychic_save_ppm(str(path).encode(), img.ctypes.data, 0, 4) < 0
