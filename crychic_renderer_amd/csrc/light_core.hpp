@@ -81,6 +81,11 @@ CRY_HD float pcf_poisson(const uint32_t* __restrict__ s, uint32_t dim, float spx
         // Common.hlsl:305 as written (uint division) gives radius 0: every one of the 16 taps is
         // uv + (+-0) == uv, so one filtered fetch is accumulated 16 times -- bit-identical to the loop.
         const float tap = shadow_cmp_linear(s, dim, x, y, depth);
+#if defined(__HIP_DEVICE_COMPILE__)
+        // fully lit / fully shadowed footprints (all but the shadow edges): 16 additions of 1.0 or +0.0 are exact, and so is the
+        // division by 16 that follows -- the result is the tap itself.  Wave-uniform, so the edges still run the literal loop.
+        if (__builtin_amdgcn_ballot_w64(!((tap == 0.0f) | (tap == 1.0f))) == 0) return tap;
+#endif
 #pragma unroll
         for (int i = 0; i < 16; ++i) percentLit += tap;
     } else {
@@ -185,10 +190,13 @@ CRY_HD void pbr_point_light(const crychic_light& L, f3 pos, f3 albedo, float rou
 CRY_HD f4 cube_linear(const uint32_t* __restrict__ cube, uint32_t dim, f3 r)
 {
     const float ax = __builtin_fabsf(r.x), ay = __builtin_fabsf(r.y), az = __builtin_fabsf(r.z);
-    uint32_t face; float sc, tc, ma;
-    if (ax >= ay && ax >= az) { ma = ax; if (r.x >= 0.0f) { face = 0; sc = -r.z; tc = -r.y; } else { face = 1; sc = r.z; tc = -r.y; } }
-    else if (ay >= az)        { ma = ay; if (r.y >= 0.0f) { face = 2; sc = r.x; tc = r.z; } else { face = 3; sc = r.x; tc = -r.z; } }
-    else                      { ma = az; if (r.z >= 0.0f) { face = 4; sc = r.x; tc = -r.y; } else { face = 5; sc = -r.x; tc = -r.y; } }
+    // major axis (ties x >= y >= z) and the face's (sc, tc) by selects: a wave whose lanes look at different faces stays converged
+    const bool isx = (ax >= ay) & (ax >= az), isy = !isx & (ay >= az);
+    const bool px = r.x >= 0.0f, py = r.y >= 0.0f, pz = r.z >= 0.0f;
+    const float ma = isx ? ax : (isy ? ay : az);
+    const float sc = isx ? (px ? -r.z : r.z) : (isy ? r.x : (pz ? r.x : -r.x));
+    const float tc = isx ? -r.y : (isy ? (py ? r.z : -r.z) : -r.y);
+    const uint32_t face = isx ? (px ? 0u : 1u) : (isy ? (py ? 2u : 3u) : (pz ? 4u : 5u));
     const float rma = rcp(ma);
     const float u = fma(0.5f, sc * rma, 0.5f);      // 0.5 * (sc / ma + 1)
     const float v = fma(0.5f, tc * rma, 0.5f);

@@ -157,7 +157,7 @@ def test_raster_status_reports_dropped_triangles(ctx, built_lib):
         v = np.zeros(len(pts), dtype=g.VERTEX_DT)
         v["Pos"] = np.asarray(pts, dtype=np.float32); v["Normal"] = (0, 0, -1); v["TangentU"] = (1, 0, 0)
         both = list(idx) + [idx[0], idx[2], idx[1]]          # both windings: one of them faces the camera
-        return SceneGeometry(ctx, [(v, np.asarray(both, dtype=np.uint32), g.make_instances([np.eye(4, dtype=np.float32)], [0]))])
+        return SceneGeometry(ctx, [(v, np.asarray(both, dtype=np.uint32), g.make_instances([np.eye(4, dtype=np.float32).reshape(-1)], [0]))])
 
     def draw(geo):
         geo.DrawSceneToShadowMap(cb, depth, depth_bias=0, slope_bias=0.0)
