@@ -114,8 +114,11 @@ int ssao_compute_impl(crychic_ctx* ctx, const crychic_ssao_constants* cb, const 
         }
         clamp_rows(h2, (int64_t)row0 - 5 * (blurCount - i), (int64_t)row0 + rows + 5 * (blurCount - i), &r0, &rn);
         const cry::BlurMode mode = blurCount == 1 ? cry::BlurMode::Plain : (i == 0 ? cry::BlurMode::Record : cry::BlurMode::Replay);
-        CRY_HIP(cry::launch_blur(*cb, edge, ambient0, ambient1, W, H, true, mode, r0, rn, stream));    // Ssao.cpp:240
-        CRY_HIP(cry::launch_blur(*cb, edge, ambient1, ambient0, W, H, false, mode, v0, vn, stream));   // Ssao.cpp:241
+        // unoccluded-tile exit of the record sweeps: a pixel's value after the frame's sweeps depends on inputs within 5 pixels
+        // per iteration along each axis
+        const int margin = 5 * blurCount + 2;
+        CRY_HIP(cry::launch_blur(*cb, edge, ambient0, ambient1, W, H, true, mode, r0, rn, stamp, margin, stream));    // Ssao.cpp:240
+        CRY_HIP(cry::launch_blur(*cb, edge, ambient1, ambient0, W, H, false, mode, v0, vn, stamp, margin, stream));   // Ssao.cpp:241
     }
     return 0;
 }
@@ -238,7 +241,7 @@ int crychic_ssao_blur(crychic_ctx* ctx, const crychic_ssao_constants* cb, const 
     if (!cb || !edge_dev || !ambient_in_dev || !ambient_out_dev) return fail(CRYCHIC_E_INVALID_ARG, "null argument");
     if (ambient_in_dev == ambient_out_dev) return fail(CRYCHIC_E_INVALID_ARG, "blur cannot run in place (the reference ping-pongs, Ssao.cpp:253-266)");
     if (row0 > H / 2 || rows > H / 2 - row0) return fail(CRYCHIC_E_INVALID_ARG, "rows [%u,+%u) outside the %u-row ambient map", row0, rows, H / 2);
-    CRY_HIP(cry::launch_blur(*cb, edge_dev, ambient_in_dev, ambient_out_dev, W, H, horizontal != 0, cry::BlurMode::Plain, row0, rows,
+    CRY_HIP(cry::launch_blur(*cb, edge_dev, ambient_in_dev, ambient_out_dev, W, H, horizontal != 0, cry::BlurMode::Plain, row0, rows, 0u, 0,
                              (hipStream_t)stream));
     return 0;
 }

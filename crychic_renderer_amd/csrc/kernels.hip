@@ -123,12 +123,16 @@ __global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, co
         }
         if (__builtin_amdgcn_ballot_w64(geometry) == 0) {
             ambient[y * w2 + x] = (uint16_t)0xFFFFu;
+            if ((threadIdx.x & 63u) == 0) edge.ones[y * ones_map_cols(W) + bx] = stamp;
             return;
         }
     }
     if (EMIT_AO) {
         const uint32_t v = PAIRS ? ssao_pixel(cb, c, dp, randvec, W, H, x, y, sparseProjTex != 0) : ssao_pixel(cb, c, dd, randvec, W, H, x, y, sparseProjTex != 0);
         ambient[y * w2 + x] = (uint16_t)v;
+        // unoccluded-wavefront map (ssao_core.hpp "unoccluded tiles"): lane 0 is live whenever the wave is (x = 64 bx < w2)
+        if (PAIRS && stamp != 0u && __builtin_amdgcn_ballot_w64(v != 0xFFFFu) == 0 && (threadIdx.x & 63u) == 0)
+            edge.ones[y * ones_map_cols(W) + bx] = stamp;
     }
 }
 
@@ -141,7 +145,7 @@ __global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, co
 template <bool HORZ, bool RECORD>
 __global__ __launch_bounds__(256) void blur_kernel(crychic_ssao_constants cb, EdgePlane edge,
                                                    const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
-                                                   uint32_t W, uint32_t H, uint32_t row0, uint32_t row1)
+                                                   uint32_t W, uint32_t H, uint32_t row0, uint32_t row1, uint32_t stamp, int onesMargin)
 {
     constexpr int BW = 64, BH = 16, R = 5;
     constexpr int SW = HORZ ? BW + 2 * R : BW;
@@ -153,6 +157,34 @@ __global__ __launch_bounds__(256) void blur_kernel(crychic_ssao_constants cb, Ed
     uint32_t bx, by;
     tile_origin<4>(bx, by);
     const int x0 = (int)bx * BW, y0 = (int)row0 + (int)by * BH;
+    if (RECORD && stamp != 0u) {
+        // Unoccluded tile (ssao_core.hpp): every wavefront of the SSAO pass within reach of this frame's sweeps wrote 65535
+        const OnesRegion g = blur_ones_region((uint32_t)w2, (uint32_t)h2, x0, y0, BW, BH, onesMargin);
+        const uint32_t ncol = g.c1 - g.c0 + 1u, ncell = ncol * (g.r1 - g.r0 + 1u), pitch = ones_map_cols(W);
+        bool occluded = false;
+        for (uint32_t k = threadIdx.x; k < ncell; k += 256u) {
+            const uint32_t r = k / ncol, c = k - r * ncol;
+            occluded |= edge.ones[(g.r0 + r) * pitch + g.c0 + c] != stamp;
+        }
+        if (!__syncthreads_or(occluded)) {
+            // The recorded decision is "centre tap only": a neighbouring tile that replays these pixels (the fused replay sweeps
+            // recompute their apron rows) then gets w5 * 1 * rcp(w5) -> 65535, the value every other decision would give too.
+            const int tx = (int)(threadIdx.x & 63u), tyb = (int)(threadIdx.x >> 6), x = x0 + tx;
+            uint16_t* __restrict__ mask_o = HORZ ? edge.mask_h : edge.mask_v;
+            float* __restrict__ total_o = HORZ ? edge.total_h : edge.total_v;
+#pragma unroll
+            for (int j = 0; j < BH / 4; ++j) {
+                const int y = y0 + tyb + 4 * j;
+                if (x < w2 && y < (int)row1) {
+                    const uint32_t p = (uint32_t)y * (uint32_t)w2 + (uint32_t)x;
+                    out[p] = (uint16_t)0xFFFFu;
+                    mask_o[p] = (uint16_t)(1u << 5);
+                    total_o[p] = cb.BlurWeights[1][1];      // w[5]
+                }
+            }
+            return;
+        }
+    }
     const int sx0 = HORZ ? x0 - R : x0, sy0 = HORZ ? y0 : y0 - R;
     const float borderZ = ndc_to_view(cb, 1.0f);
 
@@ -491,12 +523,14 @@ hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, con
 
 hipError_t launch_blur(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out,
                        uint32_t W, uint32_t H, bool horizontal, BlurMode mode, uint32_t row0, uint32_t rows,
-                       hipStream_t stream)
+                       uint32_t stamp, int onesMargin, hipStream_t stream)
 {
     if (rows == 0) return hipSuccess;
     const EdgePlane e = edge_plane_carve(const_cast<void*>(edge_base), W, H);
     const dim3 grid = grid_for(W / 2, rows, 16u);
-#define CRY_LAUNCH_BLUR(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, cb, e, in, out, W, H, row0, row0 + rows)
+    // the unoccluded-tile exit needs finite positive weights (x * rcp(x) of a finite positive total) and the SSAO pass's map
+    if (mode != BlurMode::Record || !blur_weights_positive(cb)) stamp = 0u;
+#define CRY_LAUNCH_BLUR(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, cb, e, in, out, W, H, row0, row0 + rows, stamp, onesMargin)
     if (mode == BlurMode::Replay) {
         const int ones = blur_weights_positive(cb) ? 1 : 0;
         if (horizontal) hipLaunchKernelGGL(blur_replay_kernel<true>, grid, dim3(256), 0, stream, cb, e, in, out, W, H, row0, row0 + rows, ones);

@@ -22,9 +22,11 @@ enum class BlurMode { Plain, Record, Replay };
 // horizontal + vertical replay sweep of one iteration in one launch (in -> out, out != in)
 hipError_t launch_blur_replay_pair(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out,
                                    uint32_t W, uint32_t H, uint32_t row0, uint32_t rows, hipStream_t stream);
+// stamp / onesMargin (Record sweeps): the SSAO pass's frame stamp and 5 pixels per sweep of the frame still to run, for the
+// unoccluded-tile exit (ssao_core.hpp); stamp 0 = no exit.
 hipError_t launch_blur(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out,
                        uint32_t W, uint32_t H, bool horizontal, BlurMode mode, uint32_t row0, uint32_t rows,
-                       hipStream_t stream);
+                       uint32_t stamp, int onesMargin, hipStream_t stream);
 
 hipError_t launch_light(const LightParams& P, const float* g0, const float* g1, const float* g2,
                         const uint32_t* depth, const uint16_t* ambient, const uint8_t* cube, uint8_t* out,

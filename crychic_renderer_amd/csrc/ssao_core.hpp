@@ -30,6 +30,7 @@ struct EdgePlane {
     uint16_t* spare;   // a third ambient plane: lets an odd number of fused replay iterations end in ambient0 (api.cpp)
     const void* pairs; // DepthPairs plane (below), depth_pairs_bytes(W, H)
     uint32_t* geo;     // coarse geometry map (below "sky shortcut"), geo_map_bytes(W, H)
+    uint32_t* ones;    // unoccluded-wavefront map (below "unoccluded tiles"), ones_map_bytes(W, H)
 };
 
 // ---- depth pairs -----------------------------------------------------------------------------------------------------
@@ -54,7 +55,12 @@ CRY_HD uint32_t geo_map_cols(uint32_t W) { return (W + 2u) / 128u + 1u; }
 CRY_HD uint32_t geo_map_rows(uint32_t H) { return (H + 31u) / 32u; }
 CRY_HD size_t geo_map_bytes(uint32_t W, uint32_t H) { return (size_t)geo_map_cols(W) * geo_map_rows(H) * 4u; }
 CRY_HD size_t edge_plane_geo_offset(uint32_t W, uint32_t H) { return (edge_plane_pairs_offset(W, H) + depth_pairs_bytes(W, H) + 15) & ~(size_t)15; }
-CRY_HD size_t edge_plane_bytes(uint32_t W, uint32_t H) { return edge_plane_geo_offset(W, H) + geo_map_bytes(W, H); }
+// Unoccluded-wavefront map: one word per 64 half-res pixels of a row (= one wavefront of the SSAO pass), holding the frame
+// stamp when all 64 ambient values the wavefront wrote are 65535.
+CRY_HD uint32_t ones_map_cols(uint32_t W) { return (W / 2u + 63u) / 64u; }
+CRY_HD size_t ones_map_bytes(uint32_t W, uint32_t H) { return (size_t)ones_map_cols(W) * (H / 2u) * 4u; }
+CRY_HD size_t edge_plane_ones_offset(uint32_t W, uint32_t H) { return (edge_plane_geo_offset(W, H) + geo_map_bytes(W, H) + 15) & ~(size_t)15; }
+CRY_HD size_t edge_plane_bytes(uint32_t W, uint32_t H) { return edge_plane_ones_offset(W, H) + ones_map_bytes(W, H); }
 // Entries (x, y) and (x + 1, y) of the pairs plane from the D24 plane; x even (so the two texels of a row are one 8-byte load).
 CRY_HD f4a depth_pairs_entry2(const uint32_t* __restrict__ depth, uint32_t W, uint32_t H, int x, int y)
 {
@@ -81,6 +87,7 @@ CRY_HD EdgePlane edge_plane_carve(void* base, uint32_t W, uint32_t H)
     e.spare = (uint16_t*)(b + n * 24 + (w2 + h2) * 8);   // n * 2
     e.pairs = b + edge_plane_pairs_offset(W, H);
     e.geo = (uint32_t*)(b + edge_plane_geo_offset(W, H));
+    e.ones = (uint32_t*)(b + edge_plane_ones_offset(W, H));
     return e;
 }
 
@@ -409,6 +416,25 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
     const float access = 1.0f - occlusionSum;                                    // :195
     const float a2 = access * access, a4 = a2 * a2;                              // :198 pow(access, 6)
     return float_to_unorm16(a4 * a2);
+}
+
+// ---- unoccluded tiles --------------------------------------------------------------------------------------------------
+// A blur output whose 11-tap window holds only 1.0 is 1.0 whatever the edge tests decide (the accepted weights are summed into
+// colour and total alike, and x * rcp(x) quantises to 65535).  So if every ambient value within `margin` = 5 pixels per
+// remaining sweep of a tile is 65535 when the first sweep starts, the tile stays 65535 through all sweeps of the frame, the
+// replay sweeps take their all-ones exit on it and never read its recorded masks: the record sweeps may write 65535 and skip
+// staging, edge tests and mask recording for that tile.  Whether the neighbourhood is all ones is answered by the
+// unoccluded-wavefront map the SSAO pass fills (rows outside the rows it computed this frame hold no current stamp: no skip).
+// CLAMP addressing maps taps beyond the map to its edge texels, so the neighbourhood is clamped to the map, not extended.
+struct OnesRegion { uint32_t c0, c1, r0, r1; };      // inclusive cell columns (64-pixel segments) and half-res rows
+CRY_HD OnesRegion blur_ones_region(uint32_t w2, uint32_t h2, int x0, int y0, int bw, int bh, int margin)
+{
+    OnesRegion g;
+    g.c0 = (uint32_t)clampi(x0 - margin, 0, (int)w2 - 1) / 64u;
+    g.c1 = (uint32_t)clampi(x0 + bw - 1 + margin, 0, (int)w2 - 1) / 64u;
+    g.r0 = (uint32_t)clampi(y0 - margin, 0, (int)h2 - 1);
+    g.r1 = (uint32_t)clampi(y0 + bh - 1 + margin, 0, (int)h2 - 1);
+    return g;
 }
 
 // ---- bilateral blur (SsaoBlur.hlsl:85-146) ----------------------------------------------------------------

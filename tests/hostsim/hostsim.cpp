@@ -72,6 +72,7 @@ void hs_ssao_path(const crychic_ssao_constants* cb, const void* normal, const ui
     const uint32_t stamp = 1u, gpitch = geo_map_cols(W);
     if (pairs) {
         std::memset(e.geo, 0, geo_map_bytes(W, H));
+        std::memset(e.ones, 0, ones_map_bytes(W, H));
         const uint32_t halfPitch = depth_pairs_pitch(W) / 2u;
         const f4a* pp = (const f4a*)e.pairs;
         for (uint32_t py = 2; py < H + 2u; ++py)
@@ -104,10 +105,14 @@ void hs_ssao_path(const crychic_ssao_constants* cb, const void* normal, const ui
                     for (uint32_t cx = g.cx0; cx <= g.cx1 && skip; ++cx) skip = e.geo[cy * gpitch + cx] != stamp;
             }
             g_sky_waves += skip ? 1u : 0u;
-            for (uint32_t x = x0; x < x0 + n; ++x)
+            bool allOnes = true;
+            for (uint32_t x = x0; x < x0 + n; ++x) {
                 ambient[y * w2 + x] = skip ? (uint16_t)0xFFFFu
                                            : (uint16_t)(pairs ? ssao_pixel(*cb, row[x], dp, (const uint32_t*)randvec, W, H, x, y, sparse)
                                                               : ssao_pixel(*cb, row[x], dd, (const uint32_t*)randvec, W, H, x, y, sparse));
+                allOnes = allOnes && ambient[y * w2 + x] == 0xFFFFu;
+            }
+            if (pairs && allOnes) e.ones[y * ones_map_cols(W) + x0 / 64u] = stamp;      // the unoccluded-wavefront map, as ssao_kernel writes it
         }
     }
 }
@@ -131,29 +136,47 @@ void hs_blur(const crychic_ssao_constants* cb, void* edge_base, const uint16_t* 
         }
 }
 
-// record = 1: full sweep that also stores masks/totals; record = 2: replay sweep using them
+// record = 1: full sweep that also stores masks/totals; record = 2: replay sweep using them.
+// onesMargin >= 0 (record sweeps): take the unoccluded-tile exit of blur_kernel<.., RECORD> per 64 x 16 tile, against the
+// unoccluded-wavefront map hs_ssao_path left in the workspace (stamp 1).
+static uint32_t g_ones_tiles = 0;
+uint32_t hs_last_ones_tiles(void) { return g_ones_tiles; }
 void hs_blur_mode(const crychic_ssao_constants* cb, void* edge_base, const uint16_t* in, uint16_t* out, uint32_t W,
-                  uint32_t H, int horizontal, int mode, uint32_t row0, uint32_t rows)
+                  uint32_t H, int horizontal, int mode, uint32_t row0, uint32_t rows, int onesMargin)
 {
     const int w2 = (int)(W / 2), h2 = (int)(H / 2);
     const EdgePlane e = edge_plane_carve(edge_base, W, H);
     const float borderZ = ndc_to_view(*cb, 1.0f);
     uint16_t* mask = horizontal ? e.mask_h : e.mask_v;
     float* total = horizontal ? e.total_h : e.total_v;
-    for (int y = (int)row0; y < (int)(row0 + rows); ++y)
-        for (int x = 0; x < w2; ++x) {
-            const uint32_t p = (uint32_t)y * w2 + x;
-            if (mode == 2) {
-                out[p] = (uint16_t)blur_pixel_replay(&cb->BlurWeights[0][0], mask[p], total[p], [&](int i) {
-                    const int xi = clampi(horizontal ? x + i - 5 : x, 0, w2 - 1), yi = clampi(horizontal ? y : y + i - 5, 0, h2 - 1);
-                    return unorm16_to_float(in[(uint32_t)yi * w2 + xi]);
-                });
-            } else {
-                const BlurOut o = blur_pixel_full(&cb->BlurWeights[0][0], [&](int i) {
-                    return blur_fetch(e, in, borderZ, w2, h2, horizontal ? x + i - 5 : x, horizontal ? y : y + i - 5);
-                });
-                out[p] = (uint16_t)o.value; mask[p] = (uint16_t)o.mask; total[p] = o.total;
+    const uint32_t stamp = 1u, pitch = ones_map_cols(W);
+    g_ones_tiles = 0;
+    for (int y0 = (int)row0; y0 < (int)(row0 + rows); y0 += 16)
+        for (int x0 = 0; x0 < w2; x0 += 64) {
+            bool skip = mode == 1 && onesMargin >= 0;
+            if (skip) {
+                const OnesRegion g = blur_ones_region((uint32_t)w2, (uint32_t)h2, x0, y0, 64, 16, onesMargin);
+                for (uint32_t r = g.r0; r <= g.r1 && skip; ++r)
+                    for (uint32_t c = g.c0; c <= g.c1 && skip; ++c) skip = e.ones[r * pitch + c] == stamp;
             }
+            g_ones_tiles += skip ? 1u : 0u;
+            for (int y = y0; y < y0 + 16 && y < (int)(row0 + rows); ++y)
+                for (int x = x0; x < x0 + 64 && x < w2; ++x) {
+                    const uint32_t p = (uint32_t)y * w2 + x;
+                    if (skip) {
+                        out[p] = 0xFFFFu; mask[p] = (uint16_t)(1u << 5); total[p] = cb->BlurWeights[1][1];
+                    } else if (mode == 2) {
+                        out[p] = (uint16_t)blur_pixel_replay(&cb->BlurWeights[0][0], mask[p], total[p], [&](int i) {
+                            const int xi = clampi(horizontal ? x + i - 5 : x, 0, w2 - 1), yi = clampi(horizontal ? y : y + i - 5, 0, h2 - 1);
+                            return unorm16_to_float(in[(uint32_t)yi * w2 + xi]);
+                        });
+                    } else {
+                        const BlurOut o = blur_pixel_full(&cb->BlurWeights[0][0], [&](int i) {
+                            return blur_fetch(e, in, borderZ, w2, h2, horizontal ? x + i - 5 : x, horizontal ? y : y + i - 5);
+                        });
+                        out[p] = (uint16_t)o.value; mask[p] = (uint16_t)o.mask; total[p] = o.total;
+                    }
+                }
         }
 }
 

@@ -55,7 +55,8 @@ class HostSim:
         L.hs_ssao_path.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, i]
         L.hs_last_sky_waves.restype = u32
         L.hs_blur.argtypes = [vp, vp, vp, vp, u32, u32, i, u32, u32]
-        L.hs_blur_mode.argtypes = [vp, vp, vp, vp, u32, u32, i, i, u32, u32]
+        L.hs_blur_mode.argtypes = [vp, vp, vp, vp, u32, u32, i, i, u32, u32, i]
+        L.hs_last_ones_tiles.restype = u32
         L.hs_rasterize.restype = i
         L.hs_rasterize.argtypes = [i, vp, vp, vp, u32, vp, u32, vp, u32, u32, u32, i, f, vp, vp, vp, vp, vp]
         L.hs_light.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp, u32, vp, vp, u32, u32, u32, u32, i, f, u32, vp, u32]
@@ -85,10 +86,12 @@ class HostSim:
         self.lib.hs_blur(C.addressof(cb), edge.ctypes.data, a.ctypes.data, out.ctypes.data, W, H, 1 if horizontal else 0, row0, rows)
         return out
 
-    def blur_mode(self, cb, edge, ambient_in, W, H, horizontal, mode):
+    def blur_mode(self, cb, edge, ambient_in, W, H, horizontal, mode, ones_margin=-1):
+        """mode 1 = record sweep, 2 = replay sweep; ones_margin >= 0 lets record sweeps take the unoccluded-tile exit."""
         out = np.zeros((H // 2, W // 2), dtype=np.uint16)
         a = np.ascontiguousarray(ambient_in)
-        self.lib.hs_blur_mode(C.addressof(cb), edge.ctypes.data, a.ctypes.data, out.ctypes.data, W, H, 1 if horizontal else 0, mode, 0, H // 2)
+        self.lib.hs_blur_mode(C.addressof(cb), edge.ctypes.data, a.ctypes.data, out.ctypes.data, W, H, 1 if horizontal else 0, mode, 0, H // 2,
+                              int(ones_margin))
         return out
 
     def rasterize(self, mode, view_t, viewproj_t, items, materials, textures, W, H, depth_bias=0, slope_bias=0.0):

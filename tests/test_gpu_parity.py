@@ -313,6 +313,13 @@ def test_sky_shortcut_on_device(ctx, built_lib, oracle, seed):
     check(lib.crychic_ssao(ctx.handle, C.byref(c.ssao_cb), ptr(n), ptr(d), ptr(r), ptr(a0), ptr(edge), W, H, 0, H // 2, stream(ctx)))
     torch.cuda.synchronize()
     assert np.array_equal(dev_u16(a0), ref2)
+    # the whole ComputeSsao chain on these frames: the record sweeps take their unoccluded-tile exit next to occluded patches
+    a1 = torch.zeros_like(a0)
+    for blur_count in (2, 5):
+        check(lib.crychic_ssao_compute(ctx.handle, C.byref(c.ssao_cb), ptr(n), ptr(d), ptr(r), ptr(a0), ptr(a1), ptr(edge), W, H, blur_count, 0,
+                                       H // 2, stream(ctx)))
+        torch.cuda.synchronize()
+        assert np.array_equal(dev_u16(a0), oracle.compute_ssao(scb, normal2, depth2, randvec, blur_count)), blur_count
 
 
 def test_flat_wall_ssao_is_unoccluded(ctx, built_lib):

@@ -148,3 +148,26 @@ def test_sky_shortcut_is_exact(built_lib, oracle, hostsim, seed):
     got, _ = hostsim.ssao(c.ssao_cb, normal, depth, randvec, eb)
     assert int(hostsim.lib.hs_last_sky_waves()) == 0
     assert np.array_equal(got, oracle.ssao(scb, normal, depth, randvec))
+
+
+@pytest.mark.parametrize("seed", [0, 1, 5, 12, 14])
+@pytest.mark.parametrize("blur_count", [2, 4])
+def test_unoccluded_tile_exit_is_exact(built_lib, oracle, hostsim, seed, blur_count):
+    """Record sweeps skip tiles whose whole neighbourhood (5 pixels per iteration) came out of the SSAO pass as 65535
+    (ssao_core.hpp "unoccluded tiles") and leave a centre-only decision behind; the chain record -> replay ... must still equal
+    the oracle's blurCount iterations, here on the sky-probe frames (large unoccluded areas next to occluded patches)."""
+    import fuzz_util
+    W, H, c, scb, depth, normal, randvec = fuzz_util.sky_probe_case(seed)
+    eb = int(built_lib.lib.crychic_edge_plane_bytes(W, H))
+    ref = oracle.ssao(scb, normal, depth, randvec)
+    cur, edge = hostsim.ssao(c.ssao_cb, normal, depth, randvec, eb)
+    assert np.array_equal(cur, ref)
+    margin = 5 * blur_count + 2                  # what ssao_compute_impl passes
+    skipped = 0
+    for it in range(blur_count):
+        for horz in (True, False):
+            ref = oracle.blur(scb, normal, depth, ref, horz)
+            cur = hostsim.blur_mode(c.ssao_cb, edge, cur, W, H, horz, 1 if it == 0 else 2, ones_margin=margin)
+            skipped += int(hostsim.lib.hs_last_ones_tiles())
+            assert np.array_equal(cur, ref), (it, horz, int((cur != ref).sum()))
+    assert skipped > 10
