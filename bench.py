@@ -278,10 +278,10 @@ def cpu_baseline(planes, args, pcf_radius):
 
 
 def kernel_source_hash():
-    """Identifies the kernels a committed counter profile was taken on: sha256 over csrc/*.{hip,hpp,cpp} + the build flags."""
+    """Identifies the hot-path kernels a committed counter profile was taken on: sha256 over their sources + the build flags."""
     from crychic_renderer_amd import build
     h = hashlib.sha256()
-    for name in sorted(build.SOURCES + build.HEADERS):
+    for name in ("devmath.hpp", "kernels.hip", "kernels.hpp", "light_core.hpp", "ssao_core.hpp"):
         with open(os.path.join(build.CSRC, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
     h.update(" ".join(build.FLAGS).encode())
