@@ -83,36 +83,31 @@ int channel_shift(uint32_t mask) { int s = 0; while (mask && !(mask & 1u)) { mas
 
 }  // namespace
 
-extern "C" int crychic_load_dds_rgba8(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32_t* width, uint32_t* height)
+namespace {
+
+// Bytes one level of `w` x `h` texels occupies in the file.
+size_t level_file_bytes(const DdsInfo& d, uint32_t w, uint32_t h)
 {
-    if (!path) return CRYCHIC_E_INVALID_ARG;
-    std::ifstream in(path, std::ios::binary);
-    if (!in) return CRYCHIC_E_INVALID_ARG;
-    std::vector<uint8_t> f((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
-    DdsInfo d;
-    if (!parse_header(f, d)) return CRYCHIC_E_UNSUPPORTED;
-    if (width) *width = d.width;
-    if (height) *height = d.height;
-    if (!rgba8) return 0;
-    const size_t need = (size_t)d.width * d.height * 4;
-    if (capacityBytes < need) return CRYCHIC_E_INVALID_ARG;
-    const uint8_t* src = f.data() + d.dataOffset;
-    const size_t avail = f.size() - d.dataOffset;
+    if (d.kind == DdsInfo::RGBA_MASKS) return (size_t)w * h * 4;
+    return (size_t)((w + 3) / 4) * ((h + 3) / 4) * (d.kind == DdsInfo::BC1 ? 8 : 16);
+}
+
+// Decodes one level (w x h texels at `src`) to tightly packed RGBA8.
+void decode_level(const DdsInfo& d, const uint8_t* src, uint32_t w, uint32_t h, uint8_t* rgba8)
+{
     if (d.kind == DdsInfo::RGBA_MASKS) {
-        if (avail < need) return CRYCHIC_E_INVALID_ARG;
         const int rs = channel_shift(d.rMask), gs = channel_shift(d.gMask), bs = channel_shift(d.bMask), as = channel_shift(d.aMask);
-        for (size_t i = 0; i < (size_t)d.width * d.height; ++i) {
+        for (size_t i = 0; i < (size_t)w * h; ++i) {
             const uint32_t px = rd32(src + 4 * i);
             rgba8[4 * i + 0] = (uint8_t)((px & d.rMask) >> rs);
             rgba8[4 * i + 1] = (uint8_t)((px & d.gMask) >> gs);
             rgba8[4 * i + 2] = (uint8_t)((px & d.bMask) >> bs);
             rgba8[4 * i + 3] = d.aMask ? (uint8_t)((px & d.aMask) >> as) : 255;
         }
-        return 0;
+        return;
     }
-    const uint32_t bw = (d.width + 3) / 4, bh = (d.height + 3) / 4;
+    const uint32_t bw = (w + 3) / 4, bh = (h + 3) / 4;
     const size_t blockBytes = d.kind == DdsInfo::BC1 ? 8 : 16;
-    if (avail < (size_t)bw * bh * blockBytes) return CRYCHIC_E_INVALID_ARG;
     for (uint32_t by = 0; by < bh; ++by)
         for (uint32_t bx = 0; bx < bw; ++bx) {
             const uint8_t* blk = src + ((size_t)by * bw + bx) * blockBytes;
@@ -121,13 +116,63 @@ extern "C" int crychic_load_dds_rgba8(const char* path, uint8_t* rgba8, size_t c
             else decode_color_block(blk, true, texels);
             for (int t = 0; t < 16; ++t) {
                 const uint32_t x = bx * 4 + (uint32_t)(t & 3), y = by * 4 + (uint32_t)(t >> 2);
-                if (x >= d.width || y >= d.height) continue;
-                uint8_t* o = rgba8 + ((size_t)y * d.width + x) * 4;
+                if (x >= w || y >= h) continue;
+                uint8_t* o = rgba8 + ((size_t)y * w + x) * 4;
                 o[0] = texels[t][0]; o[1] = texels[t][1]; o[2] = texels[t][2];
                 o[3] = d.kind == DdsInfo::BC3 ? alpha[t] : texels[t][3];
             }
         }
+}
+
+// maxLevels == 1: level 0 only.  Otherwise every level the header announces (DDSD_MIPMAPCOUNT, dwMipMapCount).
+int load_dds(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32_t* width, uint32_t* height, uint32_t* mipLevels, bool wantMips)
+{
+    if (!path) return CRYCHIC_E_INVALID_ARG;
+    std::ifstream in(path, std::ios::binary);
+    if (!in) return CRYCHIC_E_INVALID_ARG;
+    std::vector<uint8_t> f((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    DdsInfo d;
+    if (!parse_header(f, d)) return CRYCHIC_E_UNSUPPORTED;
+    uint32_t levels = 1;
+    if (wantMips && (rd32(&f[8]) & 0x20000u)) {                // DDSD_MIPMAPCOUNT
+        levels = rd32(&f[28]);
+        uint32_t full = 1;
+        for (uint32_t m = d.width > d.height ? d.width : d.height; m > 1; m >>= 1) ++full;
+        if (levels == 0) levels = 1;
+        if (levels > full) return CRYCHIC_E_UNSUPPORTED;        // more levels than a 1 x 1 tail allows: not a file this loader trusts
+    }
+    if (width) *width = d.width;
+    if (height) *height = d.height;
+    if (mipLevels) *mipLevels = levels;
+    if (!rgba8) return 0;
+    size_t need = 0, fileNeed = 0;
+    { uint32_t w = d.width, h = d.height;
+      for (uint32_t k = 0; k < levels; ++k) { need += (size_t)w * h * 4; fileNeed += level_file_bytes(d, w, h); w = w > 1 ? w >> 1 : 1; h = h > 1 ? h >> 1 : 1; } }
+    if (capacityBytes < need) return CRYCHIC_E_INVALID_ARG;
+    if (f.size() - d.dataOffset < fileNeed) return CRYCHIC_E_INVALID_ARG;      // truncated payload
+    const uint8_t* src = f.data() + d.dataOffset;
+    uint32_t w = d.width, h = d.height;
+    for (uint32_t k = 0; k < levels; ++k) {
+        decode_level(d, src, w, h, rgba8);
+        src += level_file_bytes(d, w, h);
+        rgba8 += (size_t)w * h * 4;
+        w = w > 1 ? w >> 1 : 1; h = h > 1 ? h >> 1 : 1;
+    }
     return 0;
+}
+
+}  // namespace
+
+extern "C" int crychic_load_dds_rgba8(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32_t* width, uint32_t* height)
+{
+    return load_dds(path, rgba8, capacityBytes, width, height, nullptr, false);
+}
+
+extern "C" int crychic_load_dds_rgba8_mips(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32_t* width, uint32_t* height,
+                                            uint32_t* mipLevels)
+{
+    if (!mipLevels) return CRYCHIC_E_INVALID_ARG;
+    return load_dds(path, rgba8, capacityBytes, width, height, mipLevels, true);
 }
 
 // Present stand-in: the reference hands the back buffer to the swap chain (CRYCHIC.cpp:294-297); a

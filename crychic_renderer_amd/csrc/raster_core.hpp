@@ -184,26 +184,66 @@ CRY_HD uint16_t float_to_half(float f)
     return u;
 }
 
-struct Texture { const uint8_t* rgba8; uint32_t width, height; };
+// A material texture (gTextureMaps[], Common.hlsl:52): R8G8B8A8 levels stored back to back, level k = max(1, w >> k) x
+// max(1, h >> k) texels; mipLevels 0 or 1 = level 0 only.  Same layout as crychic_texture.
+struct Texture { const uint8_t* rgba8; uint32_t width, height, mipLevels; };
 
-// gsamAnisotropicWrap (CRYCHIC.cpp:2631-2638) as bilinear WRAP on mip 0; missing texture = white / flat normal.
-CRY_HD f4 sample_texture(const Texture* tex, uint32_t nTextures, uint32_t index, bool isNormalMap, float u, float v)
+// One bilinear WRAP fetch inside level `level` (the level's own texel grid).
+CRY_HD f4 sample_texture_level(const Texture& t, uint32_t level, float u, float v)
 {
-    if (!tex || index >= nTextures || !tex[index].rgba8) return isNormalMap ? f4{ 0.5f, 0.5f, 1.0f, 1.0f } : f4{ 1.0f, 1.0f, 1.0f, 1.0f };
-    const Texture t = tex[index];
+    uint32_t w = t.width, h = t.height;
+    size_t off = 0;
+    for (uint32_t k = 0; k < level; ++k) { off += (size_t)w * h; w = w > 1u ? w >> 1 : 1u; h = h > 1u ? h >> 1 : 1u; }
     const float uw = u - __builtin_floorf(u), vw = v - __builtin_floorf(v);
-    const Bilin b = bilinear_setup(uw, vw, t.width, t.height);
+    const Bilin b = bilinear_setup(uw, vw, w, h);
     auto wrap = [](int i, int n) { int m = i % n; return (uint32_t)(m < 0 ? m + n : m); };
-    const uint32_t x0 = wrap(b.i0, (int)t.width), x1 = wrap(b.i0 + 1, (int)t.width);
-    const uint32_t y0 = wrap(b.j0, (int)t.height), y1 = wrap(b.j0 + 1, (int)t.height);
-    const uint32_t* p = (const uint32_t*)t.rgba8;
-    const uint32_t t00 = p[y0 * t.width + x0], t10 = p[y0 * t.width + x1], t01 = p[y1 * t.width + x0], t11 = p[y1 * t.width + x1];
+    const uint32_t x0 = wrap(b.i0, (int)w), x1 = wrap(b.i0 + 1, (int)w);
+    const uint32_t y0 = wrap(b.j0, (int)h), y1 = wrap(b.j0 + 1, (int)h);
+    const uint32_t* p = (const uint32_t*)t.rgba8 + off;
+    const uint32_t t00 = p[y0 * w + x0], t10 = p[y0 * w + x1], t01 = p[y1 * w + x0], t11 = p[y1 * w + x1];
     f4 o;
     o.x = bilerp(unorm8_to_float(t00 & 255u), unorm8_to_float(t10 & 255u), unorm8_to_float(t01 & 255u), unorm8_to_float(t11 & 255u), b.fx, b.fy);
     o.y = bilerp(unorm8_to_float((t00 >> 8) & 255u), unorm8_to_float((t10 >> 8) & 255u), unorm8_to_float((t01 >> 8) & 255u), unorm8_to_float((t11 >> 8) & 255u), b.fx, b.fy);
     o.z = bilerp(unorm8_to_float((t00 >> 16) & 255u), unorm8_to_float((t10 >> 16) & 255u), unorm8_to_float((t01 >> 16) & 255u), unorm8_to_float((t11 >> 16) & 255u), b.fx, b.fy);
     o.w = bilerp(unorm8_to_float(t00 >> 24), unorm8_to_float(t10 >> 24), unorm8_to_float(t01 >> 24), unorm8_to_float(t11 >> 24), b.fx, b.fy);
     return o;
+}
+
+// Screen-space derivatives of the texture coordinate, as the 2 x 2 pixel quad provides them to Sample().
+struct TexGrad { float dudx, dvdx, dudy, dvdy; };
+
+// gsamAnisotropicWrap (CRYCHIC.cpp:2631-2638: D3D12_FILTER_ANISOTROPIC, MaxAnisotropy 8, WRAP) on a mip chain.  D3D leaves
+// the anisotropic kernel to the implementation; this is the definition the oracle and the kernels share:
+//   footprint axes in level-0 texels  Px = (dudx W, dvdx H), Py = (dudy W, dvdy H); major = the longer one
+//   N = clamp(ceil(|major| / |minor|), 1, 8) probes spread evenly along the major axis, centred on (u, v)
+//   lod = clamp(log2(|major| / N), 0, levels - 1); every probe is trilinear (two bilinear WRAP fetches, lerp by frac(lod))
+//   result = the mean of the probes.
+// A texture without a mip chain (mipLevels <= 1) is one bilinear fetch of level 0: what round 1 modelled.
+CRY_HD f4 sample_texture(const Texture* tex, uint32_t nTextures, uint32_t index, bool isNormalMap, float u, float v, const TexGrad& g)
+{
+    if (!tex || index >= nTextures || !tex[index].rgba8) return isNormalMap ? f4{ 0.5f, 0.5f, 1.0f, 1.0f } : f4{ 1.0f, 1.0f, 1.0f, 1.0f };
+    const Texture t = tex[index];
+    if (t.mipLevels <= 1u) return sample_texture_level(t, 0u, u, v);
+    const float W = (float)t.width, H = (float)t.height;
+    const float pxu = g.dudx * W, pxv = g.dvdx * H, pyu = g.dudy * W, pyv = g.dvdy * H;
+    const float lx2 = fma(pxv, pxv, pxu * pxu), ly2 = fma(pyv, pyv, pyu * pyu);
+    const bool majorX = lx2 >= ly2;
+    const float pmax = len_from_sq(majorX ? lx2 : ly2), pmin = len_from_sq(majorX ? ly2 : lx2);
+    const float nf = __builtin_fminf(__builtin_fmaxf(__builtin_ceilf(pmax * rcp(pmin)), 1.0f), 8.0f);      // NaN -> 1
+    const float rn = rcp(nf);
+    const float lod = __builtin_fminf(__builtin_fmaxf(det_log2(pmax * rn), 0.0f), (float)(t.mipLevels - 1u));
+    const float l0f = __builtin_floorf(lod), fl = lod - l0f;
+    const uint32_t l0 = (uint32_t)l0f, l1 = l0 + 1u < t.mipLevels ? l0 + 1u : t.mipLevels - 1u;
+    const float du = majorX ? g.dudx : g.dudy, dv = majorX ? g.dvdx : g.dvdy;
+    const int N = (int)nf;
+    f4 acc{ 0.0f, 0.0f, 0.0f, 0.0f };
+    for (int k = 0; k < N; ++k) {
+        const float s = fma((float)k + 0.5f, rn, -0.5f);
+        const float uu = fma(s, du, u), vv = fma(s, dv, v);
+        const f4 a = sample_texture_level(t, l0, uu, vv), b = sample_texture_level(t, l1, uu, vv);
+        acc.x += lerpf(a.x, b.x, fl); acc.y += lerpf(a.y, b.y, fl); acc.z += lerpf(a.z, b.z, fl); acc.w += lerpf(a.w, b.w, fl);
+    }
+    return f4{ acc.x * rn, acc.y * rn, acc.z * rn, acc.w * rn };
 }
 
 struct ResolveOut {
@@ -240,6 +280,16 @@ CRY_HD ResolveOut resolve_pixel(int mode, const SetupTri& t, int px, int py, con
     const f3 tanW{ interp(t.tangentW[0][0], t.tangentW[1][0], t.tangentW[2][0]), interp(t.tangentW[0][1], t.tangentW[1][1], t.tangentW[2][1]),
                    interp(t.tangentW[0][2], t.tangentW[1][2], t.tangentW[2][2]) };
     const float tu = interp(t.tex[0][0], t.tex[1][0], t.tex[2][0]), tv = interp(t.tex[0][1], t.tex[1][1], t.tex[2][1]);
+    // TexC of this primitive at another pixel of the quad (a helper invocation extrapolates the plane equations there)
+    auto tex_at = [&](int qx, int qy, float& u, float& v) {
+        const int32_t ax = qx * 256 + 128, ay = qy * 256 + 128;
+        const double a0 = (double)orient2d(t.X[1], t.Y[1], t.X[2], t.Y[2], ax, ay), a1 = (double)orient2d(t.X[2], t.Y[2], t.X[0], t.Y[0], ax, ay);
+        const double a2 = (double)orient2d(t.X[0], t.Y[0], t.X[1], t.Y[1], ax, ay);
+        const double r0 = (a0 * invA) * (double)t.invw[0], r1 = (a1 * invA) * (double)t.invw[1], r2 = (a2 * invA) * (double)t.invw[2];
+        const double ir = 1.0 / ((r0 + r1) + r2);
+        u = (float)((((double)t.tex[0][0] * r0 + (double)t.tex[1][0] * r1) + (double)t.tex[2][0] * r2) * ir);
+        v = (float)((((double)t.tex[0][1] * r0 + (double)t.tex[1][1] * r1) + (double)t.tex[2][1] * r2) * ir);
+    };
 
     // GeometryPass.hlsl:44-66; a material index outside the buffer reads MaterialData's defaults (FrameResource.h:17-27)
     float albedoM[3] = { 1.0f, 1.0f, 1.0f }, roughness = 0.5f, metalness = 0.5f;
@@ -249,8 +299,20 @@ CRY_HD ResolveOut resolve_pixel(int mode, const SetupTri& t, int px, int py, con
         albedoM[0] = M.DiffuseAlbedo[0]; albedoM[1] = M.DiffuseAlbedo[1]; albedoM[2] = M.DiffuseAlbedo[2];
         roughness = M.Roughness; metalness = M.Metalness; dmap = M.DiffuseMapIndex; nmap = M.NormalMapIndex;
     }
-    const f4 dtex = sample_texture(textures, nTextures, dmap, false, tu, tv);                   // :53
-    const f4 ntex = sample_texture(textures, nTextures, nmap, true, tu, tv);                    // :60
+    // Implicit derivatives of Sample(): differences inside the pixel's 2 x 2 quad (ddx along its row, ddy along its column).
+    // Only a texture with a mip chain looks at them.
+    TexGrad grad{ 0.0f, 0.0f, 0.0f, 0.0f };
+    const bool mipped = textures && ((dmap < nTextures && textures[dmap].mipLevels > 1u) || (nmap < nTextures && textures[nmap].mipLevels > 1u));
+    if (mipped) {
+        const int qx = px & ~1, qy = py & ~1;
+        float ua, va, ub, vb;
+        tex_at(qx, py, ua, va); tex_at(qx + 1, py, ub, vb);
+        grad.dudx = ub - ua; grad.dvdx = vb - va;
+        tex_at(px, qy, ua, va); tex_at(px, qy + 1, ub, vb);
+        grad.dudy = ub - ua; grad.dvdy = vb - va;
+    }
+    const f4 dtex = sample_texture(textures, nTextures, dmap, false, tu, tv, grad);             // :53
+    const f4 ntex = sample_texture(textures, nTextures, nmap, true, tu, tv, grad);              // :60
     // NormalSampleToWorldSpace  Common.hlsl:112-128
     const f3 nT{ 2.0f * ntex.x - 1.0f, 2.0f * ntex.y - 1.0f, 2.0f * ntex.z - 1.0f };
     const float dtn = dot3(tanW, N);

@@ -271,8 +271,11 @@ typedef struct crychic_draw_item {
     const uint32_t* indices_dev; uint32_t indexCount; uint32_t startIndexLocation; int32_t baseVertexLocation;
     const crychic_instance_data* instances_dev; uint32_t instanceCount;
 } crychic_draw_item;
-/* A mip-0 R8G8B8A8_UNORM texture of gTextureMaps[] (Common.hlsl:52); rgba8_dev may be NULL (white / flat normal). */
-typedef struct crychic_texture { const uint8_t* rgba8_dev; uint32_t width, height; } crychic_texture;
+/* An R8G8B8A8_UNORM texture of gTextureMaps[] (Common.hlsl:52); rgba8_dev may be NULL (white / flat normal).  mipLevels > 1:
+ * the levels follow one another in memory, level k being max(1, width >> k) x max(1, height >> k) texels (what
+ * crychic_load_dds_rgba8_mips returns), and the G-buffer pass samples it as gsamAnisotropicWrap does (anisotropic 8, trilinear;
+ * the kernel D3D leaves open is defined in csrc/raster_core.hpp).  mipLevels 0 or 1: level 0 only, bilinear. */
+typedef struct crychic_texture { const uint8_t* rgba8_dev; uint32_t width, height, mipLevels; } crychic_texture;
 
 /* GeometryGenerator::CreateBox / CreateGrid (Common/GeometryGenerator.cpp:10-101, 551-614) and the Models/<name>.txt loader
  * of CRYCHIC::BuildSkullGeometry (CRYCHIC.cpp:1447-1557), host memory.  Call with NULL buffers to get the counts.
@@ -297,6 +300,11 @@ int crychic_frustum_cull(const crychic_camera* cam, const float boundsCenter[3],
  * crychic_draw_gbuffer samples.  NULL buffer: only *width / *height are written.  Replaces the subset of
  * Common/DDSTextureLoader.cpp + GPU block decompression the path depends on. */
 int crychic_load_dds_rgba8(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32_t* width, uint32_t* height);
+/* The same with the file's whole mip chain (Common/DDSTextureLoader.cpp uploads the stored levels, it generates none): the
+ * levels are written back to back, level k = max(1, w >> k) x max(1, h >> k); *mipLevels = the number of levels decoded.
+ * NULL buffer: only the sizes are written; the bytes needed are the sum over the levels of 4 * w_k * h_k. */
+int crychic_load_dds_rgba8_mips(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32_t* width, uint32_t* height,
+                                uint32_t* mipLevels);
 
 /* Present stand-in (row f3; the reference calls IDXGISwapChain::Present, CRYCHIC.cpp:294-297): writes a HOST R8G8B8A8
  * image as binary PPM (alpha dropped). */
