@@ -144,6 +144,48 @@ def procedural_textures(size=64):
     return out
 
 
+def box_mips(level0):
+    """A mip chain for an H x W x 4 uint8 image by 2 x 2 box filtering with round-to-nearest, down to 1 x 1 (the reference's DDS
+    files carry their own chains; this is for procedural test textures).  Returns the list of levels."""
+    levels = [np.ascontiguousarray(level0)]
+    while levels[-1].shape[0] > 1 or levels[-1].shape[1] > 1:
+        a = levels[-1].astype(np.uint32)
+        h, w = a.shape[0], a.shape[1]
+        a = a[: max(1, h - h % 2) if h > 1 else 1, : max(1, w - w % 2) if w > 1 else 1]
+        if h > 1:
+            a = a[0::2] + a[1::2]
+        if w > 1:
+            a = a[:, 0::2] + a[:, 1::2]
+        div = (2 if h > 1 else 1) * (2 if w > 1 else 1)
+        levels.append(((a + div // 2) // div).astype(np.uint8))
+    return levels
+
+
+def texture_levels(t):
+    """(flat uint8 array of all levels back to back, width, height, mipLevels) for a texture given as one H x W x 4 array or as a
+    list of level arrays (level k = max(1, W >> k) x max(1, H >> k))."""
+    if isinstance(t, (list, tuple)):
+        w, h = t[0].shape[1], t[0].shape[0]
+        for k, lv in enumerate(t):
+            assert lv.shape[:2] == (max(1, h >> k), max(1, w >> k)) and lv.dtype == np.uint8, (k, lv.shape)
+        return np.concatenate([np.ascontiguousarray(lv).reshape(-1) for lv in t]), w, h, len(t)
+    t = np.ascontiguousarray(t)
+    return t.reshape(-1), t.shape[1], t.shape[0], 1
+
+
+def load_dds_mips(path):
+    """A reference material texture with the mip chain its file stores, as a list of level arrays (crychic_load_dds_rgba8_mips)."""
+    w, h, n = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    check(lib.crychic_load_dds_rgba8_mips(path.encode(), None, 0, C.byref(w), C.byref(h), C.byref(n)))
+    sizes = [(max(1, h.value >> k), max(1, w.value >> k)) for k in range(n.value)]
+    flat = np.zeros(sum(a * b * 4 for a, b in sizes), np.uint8)
+    check(lib.crychic_load_dds_rgba8_mips(path.encode(), flat.ctypes.data, flat.size, C.byref(w), C.byref(h), C.byref(n)))
+    out, off = [], 0
+    for a, b in sizes:
+        out.append(flat[off:off + a * b * 4].reshape(a, b, 4)); off += a * b * 4
+    return out
+
+
 def load_dds(path):
     """A reference material texture as an H x W x 4 uint8 array (crychic_load_dds_rgba8, row f4)."""
     w, h = C.c_uint32(), C.c_uint32()

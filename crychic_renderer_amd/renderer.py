@@ -273,9 +273,11 @@ class SceneGeometry:
             for k, t in enumerate(textures):
                 if t is None:
                     continue
-                tt = torch.from_numpy(np.ascontiguousarray(t)).to(dev)
+                from .geometry import texture_levels
+                flat, tw, th, levels = texture_levels(t)          # one array = level 0 only; a list = a mip chain
+                tt = torch.from_numpy(flat.copy()).to(dev)
                 self._keep.append(tt)
-                self.textures[k] = Texture(tt.data_ptr(), t.shape[1], t.shape[0])
+                self.textures[k] = Texture(tt.data_ptr(), tw, th, levels)
             self.n_textures = len(textures)
         self._ws = {}
 

@@ -189,7 +189,9 @@ typedef struct or_draw_item {
     const uint32_t* indices; uint32_t indexCount; uint32_t startIndexLocation; int32_t baseVertexLocation;
     const or_instance_data* instances; uint32_t instanceCount;
 } or_draw_item;
-typedef struct or_texture { const uint8_t* rgba8; uint32_t width, height; } or_texture;
+/* mipLevels > 1: levels back to back, level k = max(1, w >> k) x max(1, h >> k); sampled with the anisotropic kernel defined in
+ * or_raster.c (sample_texture).  0 or 1: level 0 only, bilinear. */
+typedef struct or_texture { const uint8_t* rgba8; uint32_t width, height, mipLevels; } or_texture;
 
 /* Rasterises the items with the default rasteriser state (solid, cull back, clockwise = front, depth clip;
  * Common/d3dx12.h:203-216), depth LESS + write against depth cleared to 1.0, top-left rule, pixel centres at +0.5,
@@ -216,6 +218,8 @@ int or_load_mesh_text(const char* path, or_vertex* v, uint32_t vcap, uint32_t* i
 uint16_t or_float_to_half(float f);
 /* DDS (DXT1 / DXT5 / 32-bit masks) -> R8G8B8A8 mip 0 (row f4); NULL buffer queries the size.  0 on success. */
 int or_load_dds_rgba8(const char* path, uint8_t* rgba8, size_t capacity, uint32_t* width, uint32_t* height);
+/* The same with the file's mip chain (levels back to back); *mips = number of levels decoded. */
+int or_load_dds_rgba8_mips(const char* path, uint8_t* rgba8, size_t capacity, uint32_t* width, uint32_t* height, uint32_t* mips);
 
 /* or_deferred_light plus NUM_POINT_LIGHTS point lights from a separate buffer: BUILD-DEFINED EXTENSION for BASELINE
  * configs[4] (the reference's point-light branch, PBR.hlsl:109-124, is dead code); see or_light.c. */

@@ -137,27 +137,78 @@ uint16_t or_float_to_half(float f)
     return (uint16_t)(sign | (((he << 10) + (q - 0x400u)) & 0x7FFFu));  /* q in [0x400, 0x800]: carry handled by + */
 }
 
+/* One bilinear WRAP fetch in level `level` of a mip chain stored level after level. */
+static void sample_level(const or_texture* t, uint32_t level, float u, float v, float out[4])
+{
+    uint32_t w = t->width, h = t->height;
+    const uint8_t* base = t->rgba8;
+    for (uint32_t k = 0; k < level; ++k) { base += (size_t)w * h * 4; w = w > 1 ? w >> 1 : 1; h = h > 1 ? h >> 1 : 1; }
+    float uw = u - floorf(u), vw = v - floorf(v);
+    or_bilin b = or_bilinear_setup(uw, vw, w, h);
+    int x0 = or_wrap(b.i0, (int)w), x1 = or_wrap(b.i0 + 1, (int)w);
+    int y0 = or_wrap(b.j0, (int)h), y1 = or_wrap(b.j0 + 1, (int)h);
+    for (int c = 0; c < 4; ++c) {
+        float t00 = or_unorm8(base[((size_t)y0 * w + x0) * 4 + c]);
+        float t10 = or_unorm8(base[((size_t)y0 * w + x1) * 4 + c]);
+        float t01 = or_unorm8(base[((size_t)y1 * w + x0) * 4 + c]);
+        float t11 = or_unorm8(base[((size_t)y1 * w + x1) * 4 + c]);
+        out[c] = or_bilerp(t00, t10, t01, t11, b.fx, b.fy);
+    }
+}
+
+/* gsamAnisotropicWrap: D3D12_FILTER_ANISOTROPIC, MaxAnisotropy 8, WRAP (CRYCHIC.cpp:2631-2638), used by GeometryPass.hlsl:53,60.
+ * D3D specifies the sampler's inputs (the quad's derivatives) but leaves the anisotropic kernel to the hardware; the oracle
+ * DEFINES it (DESIGN.md "Oracle definitions"): footprint axes in level-0 texels Px = (dudx W, dvdx H), Py = (dudy W, dvdy H);
+ * N = clamp(ceil(|major| / |minor|), 1, 8) probes spread evenly along the major axis and centred on (u, v);
+ * lod = clamp(log2(|major| / N), 0, levels - 1); each probe trilinear; the result is the mean of the probes.
+ * grad = { dudx, dvdx, dudy, dvdy }.  Without a mip chain: one bilinear fetch of level 0. */
 static void sample_texture(const or_texture* tex, uint32_t nTextures, uint32_t index, int isNormalMap, float u, float v,
-                           float out[4])
+                           const float grad[4], float out[4])
 {
     if (!tex || index >= nTextures || !tex[index].rgba8) {
         if (isNormalMap) { out[0] = 0.5f; out[1] = 0.5f; out[2] = 1.0f; out[3] = 1.0f; }
         else { out[0] = out[1] = out[2] = out[3] = 1.0f; }
         return;
     }
-    /* gsamAnisotropicWrap (CRYCHIC.cpp:2631-2638) restated as bilinear WRAP on mip 0 (anisotropy/mips are not modelled). */
     const or_texture* t = &tex[index];
-    float uw = u - floorf(u), vw = v - floorf(v);
-    or_bilin b = or_bilinear_setup(uw, vw, t->width, t->height);
-    int x0 = or_wrap(b.i0, (int)t->width), x1 = or_wrap(b.i0 + 1, (int)t->width);
-    int y0 = or_wrap(b.j0, (int)t->height), y1 = or_wrap(b.j0 + 1, (int)t->height);
-    for (int c = 0; c < 4; ++c) {
-        float t00 = or_unorm8(t->rgba8[((size_t)y0 * t->width + x0) * 4 + c]);
-        float t10 = or_unorm8(t->rgba8[((size_t)y0 * t->width + x1) * 4 + c]);
-        float t01 = or_unorm8(t->rgba8[((size_t)y1 * t->width + x0) * 4 + c]);
-        float t11 = or_unorm8(t->rgba8[((size_t)y1 * t->width + x1) * 4 + c]);
-        out[c] = or_bilerp(t00, t10, t01, t11, b.fx, b.fy);
+    if (t->mipLevels <= 1) { sample_level(t, 0, u, v, out); return; }
+    float W = (float)t->width, H = (float)t->height;
+    float pxu = grad[0] * W, pxv = grad[1] * H, pyu = grad[2] * W, pyv = grad[3] * H;
+    float lx2 = fmaf(pxv, pxv, pxu * pxu), ly2 = fmaf(pyv, pyv, pyu * pyu);
+    int majorX = lx2 >= ly2;
+    float pmax = or_len(majorX ? lx2 : ly2), pmin = or_len(majorX ? ly2 : lx2);
+    float nf = fminf(fmaxf(ceilf(pmax * or_rcp(pmin)), 1.0f), 8.0f);
+    float rn = or_rcp(nf);
+    float lod = fminf(fmaxf(or_det_log2f_(pmax * rn), 0.0f), (float)(t->mipLevels - 1));
+    float l0f = floorf(lod), fl = lod - l0f;
+    uint32_t l0 = (uint32_t)l0f, l1 = l0 + 1 < t->mipLevels ? l0 + 1 : t->mipLevels - 1;
+    float du = majorX ? grad[0] : grad[2], dv = majorX ? grad[1] : grad[3];
+    int N = (int)nf;
+    float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    for (int k = 0; k < N; ++k) {
+        float s = fmaf((float)k + 0.5f, rn, -0.5f);
+        float uu = fmaf(s, du, u), vv = fmaf(s, dv, v);
+        float a[4], bb[4];
+        sample_level(t, l0, uu, vv, a);
+        sample_level(t, l1, uu, vv, bb);
+        for (int c = 0; c < 4; ++c) acc[c] += or_lerp(a[c], bb[c], fl);
     }
+    for (int c = 0; c < 4; ++c) out[c] = acc[c] * rn;
+}
+
+/* TexC of primitive T at pixel (qx, qy): the plane equations evaluated at a pixel that may lie outside the triangle (what a
+ * helper invocation of the 2 x 2 quad computes). */
+static void tex_at(const setup_tri* T, int qx, int qy, float uv[2])
+{
+    int32_t ax = qx * 256 + 128, ay = qy * 256 + 128;
+    double a0 = (double)orient(T->X[1], T->Y[1], T->X[2], T->Y[2], ax, ay);
+    double a1 = (double)orient(T->X[2], T->Y[2], T->X[0], T->Y[0], ax, ay);
+    double a2 = (double)orient(T->X[0], T->Y[0], T->X[1], T->Y[1], ax, ay);
+    double invA = 1.0 / (double)T->A2;
+    double r0 = (a0 * invA) * (double)T->invw[0], r1 = (a1 * invA) * (double)T->invw[1], r2 = (a2 * invA) * (double)T->invw[2];
+    double ir = 1.0 / ((r0 + r1) + r2);
+    for (int c = 0; c < 2; ++c)
+        uv[c] = (float)((((double)T->tex[0][c] * r0 + (double)T->tex[1][c] * r1) + (double)T->tex[2][c] * r2) * ir);
 }
 
 int or_rasterize(int mode, const float view[16], const float viewProj[16], const or_draw_item* items, uint32_t nItems,
@@ -287,9 +338,19 @@ int or_rasterize(int mode, const float view[16], const float viewProj[16], const
             defmat.DiffuseAlbedo[0] = defmat.DiffuseAlbedo[1] = defmat.DiffuseAlbedo[2] = defmat.DiffuseAlbedo[3] = 1.0f;
             defmat.Roughness = 0.5f; defmat.Metalness = 0.5f;
             const or_material_data* M = (materials && T->matIndex < nMaterials) ? &materials[T->matIndex] : &defmat;
+            /* implicit derivatives of Sample(): differences inside the pixel's 2 x 2 quad (ddx along its row, ddy along its column) */
+            float grad[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+            {
+                int qx = (int)px & ~1, qy = py & ~1;
+                float a[2], b[2];
+                tex_at(T, qx, py, a); tex_at(T, qx + 1, py, b);
+                grad[0] = b[0] - a[0]; grad[1] = b[1] - a[1];
+                tex_at(T, (int)px, qy, a); tex_at(T, (int)px, qy + 1, b);
+                grad[2] = b[0] - a[0]; grad[3] = b[1] - a[1];
+            }
             float dtex[4], ntex[4];
-            sample_texture(textures, nTextures, M->DiffuseMapIndex, 0, tex[0], tex[1], dtex);   /* :53 */
-            sample_texture(textures, nTextures, M->NormalMapIndex, 1, tex[0], tex[1], ntex);    /* :60 */
+            sample_texture(textures, nTextures, M->DiffuseMapIndex, 0, tex[0], tex[1], grad, dtex);   /* :53 */
+            sample_texture(textures, nTextures, M->NormalMapIndex, 1, tex[0], tex[1], grad, ntex);    /* :60 */
             float albedo[3] = { M->DiffuseAlbedo[0] * dtex[0], M->DiffuseAlbedo[1] * dtex[1], M->DiffuseAlbedo[2] * dtex[2] };
             /* NormalSampleToWorldSpace  Common.hlsl:112-128 */
             float nT[3] = { 2.0f * ntex[0] - 1.0f, 2.0f * ntex[1] - 1.0f, 2.0f * ntex[2] - 1.0f };

@@ -53,49 +53,109 @@ static unsigned char bc3_alpha(const unsigned char* blk, int x, int y)
     return (unsigned char)(((6 - sel) * a0 + (sel - 1) * a1 + 2) / 5);
 }
 
-int or_load_dds_rgba8(const char* path, uint8_t* rgba8, size_t capacity, uint32_t* width, uint32_t* height)
+/* One level of w x h texels starting at `src` (at most `avail` bytes): returns the bytes consumed, 0 if the level does not fit.
+ * kind: 1 = DXT1, 5 = DXT5, 0 = 32-bit masks m[0..3] (0 = channel absent: 255). */
+static size_t decode_level(int kind, const uint32_t m[4], const unsigned char* src, size_t avail, uint32_t w, uint32_t h, uint8_t* rgba8)
+{
+    if (kind == 0) {
+        size_t need = (size_t)w * h * 4;
+        if (avail < need) return 0;
+        for (size_t i = 0; i < (size_t)w * h; ++i) {
+            uint32_t px = le32(src + 4 * i);
+            for (int c = 0; c < 4; ++c) {
+                if (!m[c]) { rgba8[4 * i + c] = 255; continue; }
+                uint32_t v = px & m[c], mm = m[c];
+                while (!(mm & 1u)) { mm >>= 1; v >>= 1; }
+                rgba8[4 * i + c] = (uint8_t)v;
+            }
+        }
+        return need;
+    }
+    int bc1 = kind == 1;
+    size_t bsz = bc1 ? 8 : 16;
+    uint32_t bw = (w + 3) / 4, bh = (h + 3) / 4;
+    size_t need = (size_t)bw * bh * bsz;
+    if (avail < need) return 0;
+    for (uint32_t y = 0; y < h; ++y)
+        for (uint32_t x = 0; x < w; ++x) {
+            const unsigned char* blk = src + ((size_t)(y / 4) * bw + x / 4) * bsz;
+            unsigned char* o = rgba8 + ((size_t)y * w + x) * 4;
+            bc_color(bc1 ? blk : blk + 8, bc1, (int)(x & 3), (int)(y & 3), o);
+            if (!bc1) o[3] = bc3_alpha(blk, (int)(x & 3), (int)(y & 3));
+        }
+    return need;
+}
+
+/* want_mips = 0: level 0 only.  Levels are written back to back, level k = max(1, w >> k) x max(1, h >> k)
+ * (Common/DDSTextureLoader.cpp uploads the levels the file stores; it generates none). */
+static int load_dds(const char* path, uint8_t* rgba8, size_t capacity, uint32_t* width, uint32_t* height, uint32_t* mips, int want_mips)
 {
     FILE* f = fopen(path, "rb");
     if (!f) return -1;
     fseek(f, 0, SEEK_END);
     long n = ftell(f);
     fseek(f, 0, SEEK_SET);
-    unsigned char* d = (unsigned char*)malloc((size_t)n);
+    unsigned char* d = (unsigned char*)malloc((size_t)(n > 0 ? n : 1));
     if (fread(d, 1, (size_t)n, f) != (size_t)n) { fclose(f); free(d); return -1; }
     fclose(f);
     int rc = -4;
-    if (n >= 128 && memcmp(d, "DDS ", 4) == 0) {
+    if (n >= 128 && memcmp(d, "DDS ", 4) == 0 && le32(d + 4) == 124) {
         uint32_t h = le32(d + 12), w = le32(d + 16), pf = le32(d + 80);
-        if (width) *width = w;
-        if (height) *height = h;
-        if (!rgba8) rc = 0;
-        else if (capacity < (size_t)w * h * 4) rc = -1;
-        else if ((pf & 4u) && (memcmp(d + 84, "DXT1", 4) == 0 || memcmp(d + 84, "DXT5", 4) == 0)) {
-            int bc1 = d[87] == '1';
-            size_t bsz = bc1 ? 8 : 16;
-            uint32_t bw = (w + 3) / 4;
-            for (uint32_t y = 0; y < h; ++y)
-                for (uint32_t x = 0; x < w; ++x) {
-                    const unsigned char* blk = d + 128 + ((size_t)(y / 4) * bw + x / 4) * bsz;
-                    unsigned char* o = rgba8 + ((size_t)y * w + x) * 4;
-                    bc_color(bc1 ? blk : blk + 8, bc1, (int)(x & 3), (int)(y & 3), o);
-                    if (!bc1) o[3] = bc3_alpha(blk, (int)(x & 3), (int)(y & 3));
-                }
-            rc = 0;
-        } else if ((pf & 0x40u) && le32(d + 88) == 32) {
-            uint32_t m[4] = { le32(d + 92), le32(d + 96), le32(d + 100), (pf & 1u) ? le32(d + 104) : 0 };
-            for (size_t i = 0; i < (size_t)w * h; ++i) {
-                uint32_t px = le32(d + 128 + 4 * i);
-                for (int c = 0; c < 4; ++c) {
-                    if (!m[c]) { rgba8[4 * i + c] = 255; continue; }
-                    uint32_t v = px & m[c], mm = m[c];
-                    while (!(mm & 1u)) { mm >>= 1; v >>= 1; }
-                    rgba8[4 * i + c] = (uint8_t)v;
+        int kind = -1;
+        uint32_t m[4] = { 0, 0, 0, 0 };
+        if ((pf & 4u) && memcmp(d + 84, "DXT1", 4) == 0) kind = 1;
+        else if ((pf & 4u) && memcmp(d + 84, "DXT5", 4) == 0) kind = 5;
+        else if (!(pf & 4u) && (pf & 0x40u) && le32(d + 88) == 32) {
+            kind = 0;
+            m[0] = le32(d + 92); m[1] = le32(d + 96); m[2] = le32(d + 100); m[3] = (pf & 1u) ? le32(d + 104) : 0;
+        }
+        uint32_t levels = 1;
+        if (want_mips && (le32(d + 8) & 0x20000u)) {
+            levels = le32(d + 28);
+            if (levels == 0) levels = 1;
+            uint32_t full = 1;
+            for (uint32_t mm = w > h ? w : h; mm > 1; mm >>= 1) ++full;
+            if (levels > full) kind = -1;
+        }
+        if (kind >= 0 && w > 0 && h > 0) {
+            if (width) *width = w;
+            if (height) *height = h;
+            if (mips) *mips = levels;
+            size_t need = 0;
+            { uint32_t lw = w, lh = h; for (uint32_t k = 0; k < levels; ++k) { need += (size_t)lw * lh * 4; lw = lw > 1 ? lw >> 1 : 1; lh = lh > 1 ? lh >> 1 : 1; } }
+            if (!rgba8) rc = 0;
+            else if (capacity < need) rc = -1;
+            else {
+                const unsigned char* src = d + 128;
+                size_t avail = (size_t)n - 128;
+                uint32_t lw = w, lh = h;
+                rc = 0;
+                /* refuse a truncated file before writing anything */
+                { const unsigned char* s2 = src; size_t a2 = avail; uint32_t w2 = lw, h2 = lh;
+                  for (uint32_t k = 0; k < levels; ++k) {
+                      size_t b = kind == 0 ? (size_t)w2 * h2 * 4 : (size_t)((w2 + 3) / 4) * ((h2 + 3) / 4) * (kind == 1 ? 8 : 16);
+                      if (a2 < b) { rc = -1; break; }
+                      s2 += b; a2 -= b; w2 = w2 > 1 ? w2 >> 1 : 1; h2 = h2 > 1 ? h2 >> 1 : 1;
+                  } }
+                for (uint32_t k = 0; k < levels && rc == 0; ++k) {
+                    size_t used = decode_level(kind, m, src, avail, lw, lh, rgba8);
+                    src += used; avail -= used;
+                    rgba8 += (size_t)lw * lh * 4;
+                    lw = lw > 1 ? lw >> 1 : 1; lh = lh > 1 ? lh >> 1 : 1;
                 }
             }
-            rc = 0;
         }
     }
     free(d);
     return rc;
+}
+
+int or_load_dds_rgba8(const char* path, uint8_t* rgba8, size_t capacity, uint32_t* width, uint32_t* height)
+{
+    return load_dds(path, rgba8, capacity, width, height, NULL, 0);
+}
+int or_load_dds_rgba8_mips(const char* path, uint8_t* rgba8, size_t capacity, uint32_t* width, uint32_t* height, uint32_t* mips)
+{
+    if (!mips) return -1;
+    return load_dds(path, rgba8, capacity, width, height, mips, 1);
 }

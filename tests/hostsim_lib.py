@@ -105,8 +105,9 @@ class HostSim:
         tex = (Texture * max(1, len(textures or [])))()
         for k, t in enumerate(textures or []):
             if t is not None:
-                t = np.ascontiguousarray(t); keep.append(t)
-                tex[k] = Texture(t.ctypes.data, t.shape[1], t.shape[0])
+                from crychic_renderer_amd.geometry import texture_levels
+                flat, tw, th, levels = texture_levels(t); keep.append(flat)
+                tex[k] = Texture(flat.ctypes.data, tw, th, levels)
         mats = np.ascontiguousarray(materials) if materials is not None else None
         depth = np.zeros((H, W), np.uint32)
         normal = np.zeros((H, W, 4), np.uint16) if mode == 1 else None

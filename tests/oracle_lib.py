@@ -186,7 +186,7 @@ class OrDrawItem(C.Structure):
 
 
 class OrTexture(C.Structure):
-    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32)]
+    _fields_ = [("rgba8", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("mipLevels", C.c_uint32)]
 
 
 def _raster_protos(L):
@@ -239,8 +239,9 @@ def rasterize(orc, mode, view_t, viewproj_t, items, materials, textures, W, H, d
     tex = (OrTexture * max(1, len(textures or [])))()
     for k, t in enumerate(textures or []):
         if t is not None:
-            t = np.ascontiguousarray(t); keep.append(t)
-            tex[k] = OrTexture(t.ctypes.data, t.shape[1], t.shape[0])
+            from crychic_renderer_amd.geometry import texture_levels
+            flat, tw, th, levels = texture_levels(t); keep.append(flat)
+            tex[k] = OrTexture(flat.ctypes.data, tw, th, levels)
     mats = np.ascontiguousarray(materials) if materials is not None else None
     depth = np.zeros((H, W), np.uint32)
     normal = np.zeros((H, W, 4), np.uint16) if mode == 1 else None

@@ -124,3 +124,52 @@ def test_clipping_and_culling(built_lib, oracle, hostsim):
     assert not cov[0].any()                                        # nothing above the horizon except the wall band
     assert cov[H // 2 - 6:H // 2, W // 2 - 2:W // 2 + 2].all()    # the wall is drawn (front-facing copy)
     assert a["tris"] == b["tris"]
+
+
+@pytest.mark.parametrize("W,H", [(160, 90), (97, 61)])
+def test_mipped_textures_kernel_bodies_match_oracle(built_lib, oracle, hostsim, W, H):
+    """Material textures with a mip chain go through the anisotropic sampler (gsamAnisotropicWrap, CRYCHIC.cpp:2631-2638 --
+    the kernel D3D leaves open is defined in raster_core.hpp / or_raster.c): kernel bodies == oracle on the G-buffer planes."""
+    from crychic_renderer_amd import geometry as g
+    cs = scene_util.cpu_scene(W, H, 128, 16)["consts"]
+    items, mats = g.cascade_scene_items(), g.reference_materials()
+    tex = [g.box_mips(t) for t in g.procedural_textures(64)]
+    tex[1] = tex[1][:3]                                     # a truncated chain: the lod clamps to the last stored level
+    view = np.array(cs.pass_cb.View, np.float32); vp = np.array(cs.pass_cb.ViewProj, np.float32)
+    a = oracle_lib.rasterize(oracle, 2, view, vp, items, mats.view(oracle_lib.MATERIAL_DT), tex, W, H)
+    b = hostsim.rasterize(2, view, vp, items, mats, tex, W, H)
+    for k in ("g0", "g1", "g2"):
+        assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    plain = oracle_lib.rasterize(oracle, 2, view, vp, items, mats.view(oracle_lib.MATERIAL_DT), [t[0] for t in tex], W, H)
+    cov = a["depth"] < 0xFFFFFF
+    assert (a["g1"][cov] != plain["g1"][cov]).mean() > 0.2       # the chain is really used (minified ground and boxes)
+    assert np.array_equal(a["g0"].view(np.uint32), plain["g0"].view(np.uint32))   # position / metalness do not depend on textures
+
+
+def test_anisotropic_sampler_picks_sensible_levels(built_lib, oracle):
+    """Known answers for the sampler's definition: a texture whose level k is the solid grey 16 k.  Seen on a ground plane that
+    recedes to the horizon, the sampled level (= albedo * 255 / 16) is 0 where the texture is magnified, grows monotonically
+    (within probe noise) up the screen, and never exceeds log2 of the level-0 footprint of the pixel."""
+    from crychic_renderer_amd import geometry as g
+    W, H = 128, 96
+    cs = scene_util.cpu_scene(W, H, 128, 16)["consts"]
+    size = 256
+    levels = [np.full((max(1, size >> k), max(1, size >> k), 4), min(255, 16 * k), np.uint8) for k in range(9)]
+    grid = g.create_grid(20.0, 30.0, 60, 40)
+    mats = g.reference_materials().copy()
+    mats["DiffuseAlbedo"][:] = 1.0
+    mats["DiffuseMapIndex"][:] = 0; mats["NormalMapIndex"][:] = 1
+    items = [(grid[0], grid[1], g.make_instances([g.world_matrix((3, 3, 3))], [0]))]
+    view = np.array(cs.pass_cb.View, np.float32); vp = np.array(cs.pass_cb.ViewProj, np.float32)
+    r = oracle_lib.rasterize(oracle, 2, view, vp, items, mats.view(oracle_lib.MATERIAL_DT), [levels, None], W, H)
+    cov = r["depth"] < 0xFFFFFF
+    lvl = r["g1"][..., 0] * 255.0 / 16.0
+    col = W // 2
+    rows = np.where(cov[:, col])[0]
+    prof = lvl[rows, col]                                   # top of the ground (far) first, bottom (near) last
+    assert prof[-1] < 1.5 and prof[0] > prof[-1] + 1.0      # near: about level 0-1; far: clearly higher levels
+    assert (np.diff(prof) < 0.26).all()                     # going down the screen the level never jumps up
+    assert prof.max() <= 8.0 and (lvl[cov] >= -1e-6).all()
+    # TexTransform / tiling: the grid's TexC spans [0, 1] over 60 x 90 world units, 256 texels -> a few texels per world unit;
+    # at the bottom row one pixel covers well under a texel vertically: magnified, level 0 exactly
+    assert abs(prof[-1]) < 1e-6 or prof[-1] < 1.5

@@ -79,12 +79,14 @@ def device_frame(ctx, built_lib, consts, items, shadow_items, materials, texture
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("W,H,SD", [(256, 256, 512), (322, 190, 256)])
-def test_box_scene_all_on_device(ctx, built_lib, oracle, W, H, SD):
+@pytest.mark.parametrize("W,H,SD,mips", [(256, 256, 512, False), (322, 190, 256, False), (322, 190, 256, True)])
+def test_box_scene_all_on_device(ctx, built_lib, oracle, W, H, SD, mips):
     from crychic_renderer_amd import geometry as g, scene
     consts = raster_util.frame_constants(W, H, SD)
     items, sitems = g.cascade_scene_items(), g.cascade_scene_items(shadow_layer=True)
     mats, tex = g.reference_materials(), g.procedural_textures(64)
+    if mips:        # material textures with mip chains: the anisotropic sampler of the G-buffer pass (gsamAnisotropicWrap)
+        tex = [g.box_mips(t) for t in tex]
     cube = scene.make_cubemap(32, torch.device("cpu")).numpy()
     radius = built_lib.lib.crychic_pcf_search_radius(SD, 0)
     ref = raster_util.oracle_frame(oracle, consts, items, sitems, mats, tex, W, H, SD, cube, 3, 3, radius)

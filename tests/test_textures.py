@@ -104,6 +104,15 @@ def test_gbuffer_with_reference_textures(built_lib, oracle, hostsim):
         assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
     cov = a["depth"] < 0xFFFFFF
     assert len(np.unique(a["g1"][cov][:, 0])) > 50                       # brick / tile texels modulate the albedo
+    # the same with the mip chains the files carry, through the anisotropic sampler (what gsamAnisotropicWrap does in the reference)
+    names = ["bricks2.dds", "bricks2_nmap.dds", "tile.dds", "tile_nmap.dds", "white1x1.dds", "default_nmap.dds"]
+    mtex = [g.load_dds_mips(os.path.join(REF_TEX, n)) for n in names]
+    assert [len(t) for t in mtex][:1] == [10]
+    am = oracle_lib.rasterize(oracle, 2, view, vp, items, mats.view(oracle_lib.MATERIAL_DT), mtex, W, H)
+    bm = hostsim.rasterize(2, view, vp, items, mats, mtex, W, H)
+    for k in ("g0", "g1", "g2"):
+        assert np.array_equal(am[k].view(np.uint32), bm[k].view(np.uint32)), k
+    assert (am["g1"][cov] != a["g1"][cov]).mean() > 0.2                   # minified bricks: the chain changes the albedo
 
 
 def test_save_ppm_round_trip(built_lib, tmp_path):
@@ -123,3 +132,88 @@ def test_save_ppm_round_trip(built_lib, tmp_path):
     assert lib.crychic_save_ppm(str(tmp_path / "no_such_dir" / "x.ppm").encode(), img.ctypes.data, 4, 4) < 0
     assert lib.crychic_save_ppm(None, img.ctypes.data, 4, 4) < 0 and lib.crychic_save_ppm(str(path).encode(), None, 4, 4) < 0
     assert lib.crychic_save_ppm(str(path).encode(), img.ctypes.data, 0, 4) < 0
+
+
+def oracle_load_mips(oracle, path):
+    L = oracle.lib
+    L.or_load_dds_rgba8_mips.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]
+    w, h, n = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    rc = L.or_load_dds_rgba8_mips(path.encode(), None, 0, C.byref(w), C.byref(h), C.byref(n))
+    if rc:
+        return rc
+    sizes = [(max(1, h.value >> k), max(1, w.value >> k)) for k in range(n.value)]
+    flat = np.zeros(sum(a * b * 4 for a, b in sizes), np.uint8)
+    rc = L.or_load_dds_rgba8_mips(path.encode(), flat.ctypes.data, flat.size, C.byref(w), C.byref(h), C.byref(n))
+    if rc:
+        return rc
+    out, off = [], 0
+    for a, b in sizes:
+        out.append(flat[off:off + a * b * 4].reshape(a, b, 4)); off += a * b * 4
+    return out
+
+
+def mip_header(w, h, levels, fourcc=None, masks=None):
+    hdr = bytearray(dds_header(w, h, fourcc, masks))
+    struct.pack_into("<I", hdr, 8, 0x1007 | 0x20000)          # DDSD_MIPMAPCOUNT
+    struct.pack_into("<I", hdr, 28, levels)
+    return bytes(hdr)
+
+
+def test_mip_chain_loader(built_lib, oracle, tmp_path):
+    """crychic_load_dds_rgba8_mips: every level the file stores, back to back (DDSTextureLoader uploads the stored levels);
+    product == oracle on DXT1 / DXT5 / 32-bit chains, non-square and non-multiple-of-four levels included; truncated chains and
+    impossible level counts are refused."""
+    from crychic_renderer_amd import geometry as g
+    rng = np.random.default_rng(21)
+
+    def payload(w, h, levels, block):
+        out = b""
+        for k in range(levels):
+            lw, lh = max(1, w >> k), max(1, h >> k)
+            n = ((lw + 3) // 4) * ((lh + 3) // 4) * block if block else lw * lh * 4
+            out += rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        return out
+
+    cases = [("d1.dds", 16, 8, 5, b"DXT1", None, 8), ("d5.dds", 32, 32, 6, b"DXT5", None, 16), ("d5_partial.dds", 32, 32, 3, b"DXT5", None, 16),
+             ("rgba.dds", 12, 5, 4, None, (0x00FF0000, 0x0000FF00, 0x000000FF, 0xFF000000), 0)]
+    for name, w, h, levels, fourcc, masks, block in cases:
+        p = tmp_path / name
+        p.write_bytes(mip_header(w, h, levels, fourcc, masks) + payload(w, h, levels, block))
+        got = g.load_dds_mips(str(p))
+        ref = oracle_load_mips(oracle, str(p))
+        assert len(got) == levels == len(ref)
+        for k in range(levels):
+            assert got[k].shape == (max(1, h >> k), max(1, w >> k), 4) and np.array_equal(got[k], ref[k]), (name, k)
+        assert np.array_equal(got[0], g.load_dds(str(p)))                 # level 0 is what the single-level entry point returns
+    # a file without the mip flag has one level
+    p = tmp_path / "single.dds"
+    p.write_bytes(dds_header(8, 8, b"DXT1") + payload(8, 8, 1, 8))
+    assert len(g.load_dds_mips(str(p))) == 1
+    # truncated chain / more levels than a 1 x 1 tail allows
+    lib = built_lib.lib
+    w_, h_, n_ = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    p = tmp_path / "short.dds"
+    p.write_bytes(mip_header(16, 16, 5, b"DXT1") + payload(16, 16, 2, 8))
+    buf = np.zeros(16 * 16 * 4 * 2, np.uint8)
+    assert lib.crychic_load_dds_rgba8_mips(str(p).encode(), buf.ctypes.data, buf.size, C.byref(w_), C.byref(h_), C.byref(n_)) < 0
+    assert oracle_load_mips(oracle, str(p)) < 0
+    p = tmp_path / "toomany.dds"
+    p.write_bytes(mip_header(4, 4, 9, b"DXT1") + payload(4, 4, 3, 8))
+    assert lib.crychic_load_dds_rgba8_mips(str(p).encode(), None, 0, C.byref(w_), C.byref(h_), C.byref(n_)) < 0
+    assert lib.crychic_load_dds_rgba8_mips(str(p).encode(), None, 0, C.byref(w_), C.byref(h_), None) < 0
+
+
+@pytest.mark.skipif(not os.path.exists(REF_TEX), reason="reference textures are not on this machine")
+def test_reference_textures_mip_chains(built_lib, oracle):
+    """The reference's material textures with the mip chains their files carry (bricks2.dds: DXT5 512^2, 10 levels)."""
+    from crychic_renderer_amd import geometry as g
+    for name, levels in (("bricks2.dds", 10), ("tile.dds", None), ("bricks2_nmap.dds", None), ("tile_nmap.dds", None), ("white1x1.dds", 1)):
+        got = g.load_dds_mips(os.path.join(REF_TEX, name))
+        ref = oracle_load_mips(oracle, os.path.join(REF_TEX, name))
+        assert len(got) == len(ref) and (levels is None or len(got) == levels), (name, len(got))
+        for a, b in zip(got, ref):
+            assert np.array_equal(a, b), name
+        if len(got) > 3:      # a real chain: each level is about the 2 x 2 average of the one below
+            lo = got[1].astype(np.float32)
+            hi = got[0].astype(np.float32).reshape(lo.shape[0], 2, lo.shape[1], 2, 4).mean(axis=(1, 3))
+            assert np.abs(lo - hi).mean() < 12.0, name
