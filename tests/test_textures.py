@@ -112,7 +112,7 @@ def test_gbuffer_with_reference_textures(built_lib, oracle, hostsim):
     bm = hostsim.rasterize(2, view, vp, items, mats, mtex, W, H)
     for k in ("g0", "g1", "g2"):
         assert np.array_equal(am[k].view(np.uint32), bm[k].view(np.uint32)), k
-    assert (am["g1"][cov] != a["g1"][cov]).mean() > 0.2                   # minified bricks: the chain changes the albedo
+    assert (am["g1"][cov][:, :3] != a["g1"][cov][:, :3]).mean() > 0.2     # minified bricks: the chain changes the albedo
 
 
 def test_save_ppm_round_trip(built_lib, tmp_path):
