@@ -66,6 +66,16 @@ public:
     void ComputeSsao(ID3D12GraphicsCommandList* cmdList, FrameResource* currFrame, int blurCount)
     {
         const SsaoConstants& cb = currFrame->SsaoCB->Element(0);
+        if (mLiteralSequence) {
+            // the reference's own recording order: the SSAO draw (Ssao.cpp:198-222), then BlurAmbientMap (:228), sweep by sweep
+            CrychicThrowIfFailed(crychic_ssao(
+                md3dDevice->Ctx(), reinterpret_cast<const crychic_ssao_constants*>(&cb), mNormalMap->Data(),
+                static_cast<const uint32_t*>(mDepthStencilBuffer->Data()), static_cast<const uint8_t*>(mRandomVectorMap->Data()),
+                static_cast<uint16_t*>(mAmbientMap0->Data()), mEdgePlane->Data(), mRenderTargetWidth, mRenderTargetHeight, 0,
+                mRenderTargetHeight / 2, cmdList->Stream()));
+            BlurAmbientMap(cmdList, currFrame, blurCount);
+            return;
+        }
         CrychicThrowIfFailed(crychic_ssao_compute(
             md3dDevice->Ctx(), reinterpret_cast<const crychic_ssao_constants*>(&cb), mNormalMap->Data(),
             static_cast<const uint32_t*>(mDepthStencilBuffer->Data()), static_cast<const uint8_t*>(mRandomVectorMap->Data()),
@@ -73,23 +83,29 @@ public:
             mRenderTargetWidth, mRenderTargetHeight, blurCount, 0, mRenderTargetHeight / 2, cmdList->Stream()));
     }
 
+    // false (default): ComputeSsao is one crychic_ssao_compute call (record / replay sweeps, fused iterations, exits);
+    // true: the reference's literal sequence of one SSAO pass and 2 * blurCount single sweeps.  Same bits either way
+    // (tests/cpp/veneer_driver.cpp renders both).
+    bool mLiteralSequence = false;
+
     ID3D12Resource* AmbientMap1() { return mAmbientMap1.get(); }
     ID3D12Resource* RandomVectorMap() { return mRandomVectorMap.get(); }
     ID3D12Resource* EdgePlane() { return mEdgePlane.get(); }
 
 private:
-    // Ssao.cpp:231-243
+    // Ssao.cpp:231-243 (Ssao.h:76)
     void BlurAmbientMap(ID3D12GraphicsCommandList* cmdList, FrameResource* currFrame, int blurCount)
     {
+        mBoundFrame = currFrame;            // the reference binds currFrame's SsaoCB on the command list here (Ssao.cpp:234-236)
         for (int i = 0; i < blurCount; ++i) {
-            BlurAmbientMap(cmdList, currFrame, true);
-            BlurAmbientMap(cmdList, currFrame, false);
+            BlurAmbientMap(cmdList, true);
+            BlurAmbientMap(cmdList, false);
         }
     }
-    // Ssao.cpp:245-293 (the reference's overload takes only (cmdList, horzBlur); the constants come from the bound CB)
-    void BlurAmbientMap(ID3D12GraphicsCommandList* cmdList, FrameResource* currFrame, bool horzBlur)
+    // Ssao.cpp:245-293 (Ssao.h:77): the constants come from the constant buffer bound by the caller
+    void BlurAmbientMap(ID3D12GraphicsCommandList* cmdList, bool horzBlur)
     {
-        const SsaoConstants& cb = currFrame->SsaoCB->Element(0);
+        const SsaoConstants& cb = mBoundFrame->SsaoCB->Element(0);
         ID3D12Resource* in = horzBlur ? mAmbientMap0.get() : mAmbientMap1.get();
         ID3D12Resource* out = horzBlur ? mAmbientMap1.get() : mAmbientMap0.get();
         CrychicThrowIfFailed(crychic_ssao_blur(md3dDevice->Ctx(), reinterpret_cast<const crychic_ssao_constants*>(&cb), mEdgePlane->Data(),
@@ -128,6 +144,7 @@ private:
 private:
     ID3D12Device* md3dDevice = nullptr;
     ID3D12Resource* mDepthStencilBuffer = nullptr;
+    FrameResource* mBoundFrame = nullptr;
     std::unique_ptr<ID3D12Resource> mRandomVectorMap, mNormalMap, mAmbientMap0, mAmbientMap1, mEdgePlane;
     UINT mRenderTargetWidth = 0, mRenderTargetHeight = 0;
     DirectX::XMFLOAT4 mOffsets[14];

@@ -67,6 +67,20 @@ int main(int argc, char** argv)
         app.CurrentBackBuffer()->Download(out.data(), out.size(), s);
         std::vector<uint16_t> ao((size_t)(W / 2) * (H / 2));
         app.mSsao->AmbientMap()->Download(ao.data(), ao.size() * 2, s);
+        app.CommandList()->Flush();
+        {   // the reference's literal pass sequence (one SSAO pass, then BlurAmbientMap sweep by sweep) gives the same frame
+            app.mSsao->mLiteralSequence = true;
+            gt.Tick(1.0f / 60.0f);
+            app.Update(gt);
+            app.Draw(gt);
+            std::vector<uint8_t> out2(out.size());
+            std::vector<uint16_t> ao2(ao.size());
+            app.CurrentBackBuffer()->Download(out2.data(), out2.size(), s);
+            app.mSsao->AmbientMap()->Download(ao2.data(), ao2.size() * 2, s);
+            app.CommandList()->Flush();
+            app.mSsao->mLiteralSequence = false;
+            if (out2 != out || ao2 != ao) { std::fprintf(stderr, "literal pass sequence differs from crychic_ssao_compute\n"); return 6; }
+        }
         std::vector<uint8_t> rv(256 * 256 * 4);
         app.mSsao->RandomVectorMap()->Download(rv.data(), rv.size(), s);
         app.CommandList()->Flush();
