@@ -58,10 +58,9 @@ def parse():
     ap.add_argument("--no-producers", action="store_true", help="skip the informational timing of the producer passes")
     ap.add_argument("--frames-in-flight", type=int, default=0,
                     help="independent frame pipelines (own stream + own ambient / edge workspace) alternating frames: the head and "
-                         "tail of one frame's kernels overlap the other's.  0 = auto: 1 at N = 1 (clean per-kernel durations for "
-                         "the roofline object), 4 for the strips of N > 1")
-    ap.add_argument("--also-two-in-flight", action="store_true",
-                    help="N = 1: additionally time the K frames with two frames in flight (informational field)")
+                         "tail of one frame's kernels overlap the other's.  0 = auto: 3 at N = 1 (the reference's own "
+                         "gNumFrameResources, FrameResource.h / CRYCHIC.h), 4 for the strips of N > 1.  At N = 1 the same K frames "
+                         "are also timed one at a time (config.one_frame_at_a_time) and the per-pass list is measured that way")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the strip exchange even with one rank: exercises the N > 1 code path on a 1-GPU box")
     ap.add_argument("--exchange", choices=["abi", "torch"], default="abi",
@@ -485,9 +484,11 @@ def main():
 
     # Frames in flight: consecutive frames are independent, so further pipelines (own stream, own ambient / edge workspace,
     # same read-only input planes) let the short kernels of one strip fill the dispatch gaps of the others.
-    # auto: one frame at a time at N = 1 (the roofline object below needs kernel durations that are not stretched by a
-    # co-running frame, and has to agree with a rocprofv3 trace of this very command), four for the short strips of N > 1
-    nflight = max(1, min(args.frames_in_flight or (4 if rows < H else 1), 4))
+    # auto: three at N = 1 -- what the reference keeps in flight itself (gNumFrameResources = 3: three FrameResources cycled by
+    # CRYCHIC::Update / Draw) -- so the memory-pipe-bound SSAO / blur passes of one frame run under the VALU-bound lighting
+    # pass of another; four for the short strips of N > 1.  The per-pass list of the roofline object and
+    # config.one_frame_at_a_time are measured with one frame at a time (kernel durations not stretched by a co-running frame).
+    nflight = max(1, min(args.frames_in_flight or (4 if rows < H else 3), 4))
     apps, streams = [app], [torch.cuda.current_stream(dev)]
     for _ in range(nflight - 1):
         apps.append(new_app())
@@ -600,25 +601,21 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
 
-    # ---- informational at N = 1: the same K frames with two frames in flight (not `value`, see --frames-in-flight) ----
-    overlapped = None
-    if args.also_two_in_flight and world == 1 and not args.strip and nflight == 1:
-        app2 = new_app()
-        app2.mBackBuffer = torch.zeros_like(planes["out"])
+    # ---- N = 1: the same K frames one at a time on one stream (latency view; not `value` unless --frames-in-flight 1) ----
+    serial = None
+    if world == 1 and not args.strip and nflight > 1 and exchange is None:
         app.mBackBuffer = planes["out"]
-        pair = [(app, torch.cuda.current_stream(dev)), (app2, torch.cuda.Stream(device=dev))]
         for phase in range(2):
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for i in range(args.steps if phase else 10):
-                a_, st_ = pair[i % 2]
-                with torch.cuda.stream(st_):
-                    a_.Draw(row0, rows)
+            for _ in range(args.steps if phase else 10):
+                app.Draw(row0, rows)
             torch.cuda.synchronize()
-            t_ov = time.perf_counter() - t1
-        if not torch.equal(app2.mBackBuffer, planes["out"]):
-            raise SystemExit("bench.py: the two frame pipelines disagree")
-        overlapped = {"Mpixels_per_s": round(W * H * args.steps / t_ov / 1e6, 1), "ms_per_frame": round(t_ov / args.steps * 1e3, 4)}
+            t_serial = time.perf_counter() - t1
+        if not torch.equal(outs[1], planes["out"]):
+            raise SystemExit("bench.py: the frame pipelines disagree")
+        serial = {"ms_per_frame": round(t_serial / args.steps * 1e3, 4), "Mpixels_per_s": round(W * H * args.steps / t_serial / 1e6, 1),
+                  "hbm_roofline_frac": round((59 + 14 * max(args.blur_count, 0)) * W * H / (t_serial / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
 
     # ---- per-pass timing of the same workload (HIP events recorded by the library on the launch stream) ----
     app.set_profiling(True)
@@ -684,7 +681,7 @@ def main():
                        "launcher": os.environ.get("CRYCHIC_BENCH_LAUNCHER", "external (torch.distributed.run)" if world > 1 else "direct"),
                        "sharding": ("%s row strips x%d" % (args.partition, world)) if world > 1 else "single GPU",
                        "exchange": exchange_kind, "exchange_verified": exchange_ok, "frames_in_flight": nflight,
-                       "two_frames_in_flight_informational": overlapped,
+                       "one_frame_at_a_time": serial,
                        "strip_rows": rows, "strip_plan": [b[1] for b in bounds] if bounds and world > 1 else None,
                        "strip_only": args.strip or None,
                        "point_lights": args.point_lights * args.point_lights,

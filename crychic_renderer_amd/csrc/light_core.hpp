@@ -39,23 +39,38 @@ CRY_HD float nrand(float u, float v)
     return __builtin_fabsf(noise + noise) * 0.5f;
 }
 
+// Texture lookups come in two halves -- *_fetch computes the addresses and issues the loads, *_resolve decodes and filters --
+// so that a caller can issue every gather of a pixel (ambient map, shadow cascades, cubemap) before it waits for the first:
+// one memory round trip per pixel instead of one per lookup.
+//
 // gsamShadow: LESS_EQUAL comparison on each texel, then bilinear; BORDER colour 0  (CRYCHIC.cpp:2649-2658)
-CRY_HD float shadow_cmp_linear(const uint32_t* __restrict__ s, uint32_t dim, float u, float v, float ref)
+struct ShadowFetch { TexelPair p0, p1; Bilin b; };
+CRY_HD ShadowFetch shadow_fetch(const uint32_t* __restrict__ s, uint32_t dim, float u, float v)
 {
-    const Bilin b = bilinear_setup(u, v, dim, dim);
-    const uint32_t r0 = (uint32_t)clampi(b.j0, 0, (int)dim - 1), r1 = (uint32_t)clampi(b.j0 + 1, 0, (int)dim - 1);
-    const TexelPair p0 = pair_at(s, r0, dim, b.i0);   // one 8-byte load per footprint row
-    const TexelPair p1 = pair_at(s, r1, dim, b.i0);
+    ShadowFetch f;
+    f.b = bilinear_setup(u, v, dim, dim);
+    const uint32_t r0 = (uint32_t)clampi(f.b.j0, 0, (int)dim - 1), r1 = (uint32_t)clampi(f.b.j0 + 1, 0, (int)dim - 1);
+    f.p0 = pair_at(s, r0, dim, f.b.i0);   // one 8-byte load per footprint row
+    f.p1 = pair_at(s, r1, dim, f.b.i0);
+    return f;
+}
+CRY_HD float shadow_resolve(const ShadowFetch& f, uint32_t dim, float ref)
+{
+    const Bilin& b = f.b;
     const bool xa = (uint32_t)b.i0 < dim, xb = (uint32_t)(b.i0 + 1) < dim;
     const bool y0 = (uint32_t)b.j0 < dim, y1 = (uint32_t)(b.j0 + 1) < dim;
     // the BORDER colour 0 is D24 0: select on the integer texel, then decode unconditionally
-    const float t00 = d24_to_float((xa && y0) ? p0.a : 0u);
-    const float t10 = d24_to_float((xb && y0) ? p0.b : 0u);
-    const float t01 = d24_to_float((xa && y1) ? p1.a : 0u);
-    const float t11 = d24_to_float((xb && y1) ? p1.b : 0u);
+    const float t00 = d24_to_float((xa && y0) ? f.p0.a : 0u);
+    const float t10 = d24_to_float((xb && y0) ? f.p0.b : 0u);
+    const float t01 = d24_to_float((xa && y1) ? f.p1.a : 0u);
+    const float t11 = d24_to_float((xb && y1) ? f.p1.b : 0u);
     const float c00 = (ref <= t00) ? 1.0f : 0.0f, c10 = (ref <= t10) ? 1.0f : 0.0f;
     const float c01 = (ref <= t01) ? 1.0f : 0.0f, c11 = (ref <= t11) ? 1.0f : 0.0f;
     return bilerp(c00, c10, c01, c11, b.fx, b.fy);
+}
+CRY_HD float shadow_cmp_linear(const uint32_t* __restrict__ s, uint32_t dim, float u, float v, float ref)
+{
+    return shadow_resolve(shadow_fetch(s, dim, u, v), dim, ref);
 }
 
 // Common.hlsl:173-183, interleaved x,y
@@ -64,6 +79,21 @@ CRY_HD float shadow_cmp_linear(const uint32_t* __restrict__ s, uint32_t dim, flo
       -0.91588581f, 0.45771432f, -0.81544232f, -0.87912464f, -0.38277543f, 0.27676845f, 0.97484398f, 0.75648379f,   \
       0.44323325f, -0.97511554f, 0.53742981f, -0.47373420f, -0.26496911f, -0.41893023f, 0.79197514f, 0.19090188f,   \
       -0.24188840f, 0.99706507f, -0.81409955f, 0.91437590f, 0.19984126f, 0.78641367f, 0.14383161f, -0.14100790f }
+
+// Common.hlsl:305 as written (uint division) gives radius 0: every one of the 16 taps is uv + (+-0) == uv, so one filtered
+// fetch `tap` is accumulated 16 times and divided by 16 (:308-315) -- bit-identical to the loop.
+CRY_HD float pcf_zero_radius(float tap)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    // fully lit / fully shadowed footprints (all but the shadow edges): 16 additions of 1.0 or +0.0 are exact, and so is the
+    // division by 16 that follows -- the result is the tap itself.  Wave-uniform, so the edges still run the literal loop.
+    if (__builtin_amdgcn_ballot_w64(!((tap == 0.0f) | (tap == 1.0f))) == 0) return tap;
+#endif
+    float percentLit = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) percentLit += tap;
+    return percentLit * 0.0625f;
+}
 
 // CalcCascadeShadowFactorWithPoisson  Common.hlsl:263-317
 // ZERO_RADIUS is a compile-time promise that radius == 0 (the reference's own value): it removes the general tap loop
@@ -78,16 +108,7 @@ CRY_HD float pcf_poisson(const uint32_t* __restrict__ s, uint32_t dim, float spx
     const float x = W_ONE ? spx : spx * rw, y = W_ONE ? spy : spy * rw, depth = W_ONE ? spz : spz * rw;  // :266-269
     float percentLit = 0.0f;
     if (ZERO_RADIUS || radius == 0.0f) {
-        // Common.hlsl:305 as written (uint division) gives radius 0: every one of the 16 taps is
-        // uv + (+-0) == uv, so one filtered fetch is accumulated 16 times -- bit-identical to the loop.
-        const float tap = shadow_cmp_linear(s, dim, x, y, depth);
-#if defined(__HIP_DEVICE_COMPILE__)
-        // fully lit / fully shadowed footprints (all but the shadow edges): 16 additions of 1.0 or +0.0 are exact, and so is the
-        // division by 16 that follows -- the result is the tap itself.  Wave-uniform, so the edges still run the literal loop.
-        if (__builtin_amdgcn_ballot_w64(!((tap == 0.0f) | (tap == 1.0f))) == 0) return tap;
-#endif
-#pragma unroll
-        for (int i = 0; i < 16; ++i) percentLit += tap;
+        return pcf_zero_radius(shadow_cmp_linear(s, dim, x, y, depth));
     } else {
         const float theta = nrand(x, y);                          // :301
         const float c = det_cos(theta), sn = det_sin(theta);      // :302-303
@@ -187,7 +208,8 @@ CRY_HD void pbr_point_light(const crychic_light& L, f3 pos, f3 albedo, float rou
 
 // TextureCube.Sample(gsamLinearWrap, r): D3D major-axis face selection (ties x >= y >= z), bilinear inside the
 // face with clamp-to-edge.  Faces +X,-X,+Y,-Y,+Z,-Z, RGBA8.
-CRY_HD f4 cube_linear(const uint32_t* __restrict__ cube, uint32_t dim, f3 r)
+struct CubeFetch { TexelPair p0, p1; float fx, fy; };
+CRY_HD CubeFetch cube_fetch(const uint32_t* __restrict__ cube, uint32_t dim, f3 r)
 {
     const float ax = __builtin_fabsf(r.x), ay = __builtin_fabsf(r.y), az = __builtin_fabsf(r.z);
     // major axis (ties x >= y >= z) and the face's (sc, tc) by selects: a wave whose lanes look at different faces stays converged
@@ -203,33 +225,50 @@ CRY_HD f4 cube_linear(const uint32_t* __restrict__ cube, uint32_t dim, f3 r)
     const Bilin b = bilinear_setup(u, v, dim, dim);
     const uint32_t y0 = (uint32_t)clampi(b.j0, 0, (int)dim - 1), y1 = (uint32_t)clampi(b.j0 + 1, 0, (int)dim - 1);
     const uint32_t faceRow = mul24(face, dim);   // faces are stacked: row index face*dim + y
-    const TexelPair p0 = pair_at_clamped(cube, faceRow + y0, dim, b.i0);
-    const TexelPair p1 = pair_at_clamped(cube, faceRow + y1, dim, b.i0);
-    const uint32_t t00 = p0.a, t10 = p0.b, t01 = p1.a, t11 = p1.b;
+    CubeFetch f;
+    f.p0 = pair_at_clamped(cube, faceRow + y0, dim, b.i0);
+    f.p1 = pair_at_clamped(cube, faceRow + y1, dim, b.i0);
+    f.fx = b.fx;
+    f.fy = b.fy;
+    return f;
+}
+CRY_HD f4 cube_resolve(const CubeFetch& f)
+{
+    const uint32_t t00 = f.p0.a, t10 = f.p0.b, t01 = f.p1.a, t11 = f.p1.b;
     f4 o;
     o.x = bilerp(unorm8_to_float(t00 & 255u), unorm8_to_float(t10 & 255u), unorm8_to_float(t01 & 255u),
-                 unorm8_to_float(t11 & 255u), b.fx, b.fy);
+                 unorm8_to_float(t11 & 255u), f.fx, f.fy);
     o.y = bilerp(unorm8_to_float((t00 >> 8) & 255u), unorm8_to_float((t10 >> 8) & 255u),
-                 unorm8_to_float((t01 >> 8) & 255u), unorm8_to_float((t11 >> 8) & 255u), b.fx, b.fy);
+                 unorm8_to_float((t01 >> 8) & 255u), unorm8_to_float((t11 >> 8) & 255u), f.fx, f.fy);
     o.z = bilerp(unorm8_to_float((t00 >> 16) & 255u), unorm8_to_float((t10 >> 16) & 255u),
-                 unorm8_to_float((t01 >> 16) & 255u), unorm8_to_float((t11 >> 16) & 255u), b.fx, b.fy);
+                 unorm8_to_float((t01 >> 16) & 255u), unorm8_to_float((t11 >> 16) & 255u), f.fx, f.fy);
     o.w = bilerp(unorm8_to_float(t00 >> 24), unorm8_to_float(t10 >> 24), unorm8_to_float(t01 >> 24),
-                 unorm8_to_float(t11 >> 24), b.fx, b.fy);
+                 unorm8_to_float(t11 >> 24), f.fx, f.fy);
     return o;
 }
+CRY_HD f4 cube_linear(const uint32_t* __restrict__ cube, uint32_t dim, f3 r) { return cube_resolve(cube_fetch(cube, dim, r)); }
 
 // gsamLinearClamp on the half-res R16_UNORM ambient map  (CRYCHIC.cpp:2624-2629)
-CRY_HD float ambient_linear_clamp(const uint16_t* __restrict__ a, uint32_t w2, uint32_t h2, float u, float v)
+struct AmbientFetch { uint16_t t00, t10, t01, t11; float fx, fy; };
+CRY_HD AmbientFetch ambient_fetch(const uint16_t* __restrict__ a, uint32_t w2, uint32_t h2, float u, float v)
 {
     const Bilin b = bilinear_setup(u, v, w2, h2);
     const uint32_t x0 = (uint32_t)clampi(b.i0, 0, (int)w2 - 1), x1 = (uint32_t)clampi(b.i0 + 1, 0, (int)w2 - 1);
     const uint32_t y0 = (uint32_t)clampi(b.j0, 0, (int)h2 - 1), y1 = (uint32_t)clampi(b.j0 + 1, 0, (int)h2 - 1);
     const uint32_t r0 = mul24(y0, w2), r1 = mul24(y1, w2);
-    return bilerp(unorm16_to_float(load_at<uint16_t>(a, (r0 + x0) * 2u)), unorm16_to_float(load_at<uint16_t>(a, (r0 + x1) * 2u)),
-                  unorm16_to_float(load_at<uint16_t>(a, (r1 + x0) * 2u)), unorm16_to_float(load_at<uint16_t>(a, (r1 + x1) * 2u)), b.fx, b.fy);
+    return AmbientFetch{ load_at<uint16_t>(a, (r0 + x0) * 2u), load_at<uint16_t>(a, (r0 + x1) * 2u),
+                         load_at<uint16_t>(a, (r1 + x0) * 2u), load_at<uint16_t>(a, (r1 + x1) * 2u), b.fx, b.fy };
+}
+CRY_HD float ambient_resolve(const AmbientFetch& f)
+{
+    return bilerp(unorm16_to_float(f.t00), unorm16_to_float(f.t10), unorm16_to_float(f.t01), unorm16_to_float(f.t11), f.fx, f.fy);
+}
+CRY_HD float ambient_linear_clamp(const uint16_t* __restrict__ a, uint32_t w2, uint32_t h2, float u, float v)
+{
+    return ambient_resolve(ambient_fetch(a, w2, h2, u, v));
 }
 
-// DeferredShading.hlsl:23-101 for one covered pixel.
+// Point-light iteration policies of light_pixels (extension).
 struct NoPointLights {
     CRY_HD void operator()(f3, f3, float, float, f3, f3, f3&, bool, bool) const {}
 };
@@ -242,6 +281,85 @@ struct AllPointLights {
     }
 };
 
+// DeferredShading.hlsl:53-76: cascade selection and the (blended) shadow factor of the first light for one pixel.
+// `abs(distance - radius[j] < 5.0f)` is abs(bool) (Q1), true whenever distance < radius[j]: every pixel nearer than 80 blends
+// cascades j and j+1.
+CRY_HD int cascade_index(float distance)    // :53-58
+{
+    int j = 4;
+    if (distance < 30.0f) j = 0;
+    else if (distance < 50.0f) j = 1;
+    else if (distance < 80.0f) j = 2;
+    else if (distance < 100.0f) j = 3;
+    return j;
+}
+template <bool ZERO_RADIUS>
+CRY_HD float cascade_shadow(const LightParams& P, f3 posW, float distance, bool fixQ1)
+{
+    const int j = cascade_index(distance);
+    if (j == 4) return 1.0f;
+    // posW bounded => no product with a zero matrix entry is NaN / inf => shadowPosH.w == 1 (light_shadow_w_is_one)
+    const float pmax = 1.2676506e30f;
+    bool wOne = P.shadowWIsOne && __builtin_fabsf(posW.x) < pmax && __builtin_fabsf(posW.y) < pmax && __builtin_fabsf(posW.z) < pmax;
+#if defined(__HIP_DEVICE_COMPILE__)
+    wOne = __builtin_amdgcn_ballot_w64(!wOne) == 0;          // wave-uniform choice of the instantiation
+#endif
+    auto cascade = [&](int k) {
+        const float* T = P.ShadowTransforms[k];
+        const float spx = mulcol1(posW.x, posW.y, posW.z, T + 0), spy = mulcol1(posW.x, posW.y, posW.z, T + 4);
+        const float spz = mulcol1(posW.x, posW.y, posW.z, T + 8);
+        if (wOne) return pcf_poisson<ZERO_RADIUS, true>(P.shadow[k], P.shadowDim, spx, spy, spz, 1.0f, P.pcfSearchRadius);
+        float spw = mulcol1(posW.x, posW.y, posW.z, T + 12);
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(spw));   // keeps the three divisions inside this (rare) branch: the optimiser would otherwise
+                                        // speculate them above the wave-uniform test and select afterwards
+#endif
+        return pcf_poisson<ZERO_RADIUS, false>(P.shadow[k], P.shadowDim, spx, spy, spz, spw, P.pcfSearchRadius);
+    };
+    const float a = cascade(j);
+    const float radiusJ = j == 0 ? 30.0f : (j == 1 ? 50.0f : (j == 2 ? 80.0f : 100.0f));
+    const bool blend = j < 3 && (!fixQ1 || __builtin_fabsf(distance - radiusJ) < 5.0f);   // Q1: as written, every j < 3 blends
+    return blend ? 0.5f * (a + cascade(j + 1)) : a;              // :66 / :73
+}
+
+// The common case of cascade_shadow for a whole wavefront: every pixel in the same cascade J <= 2 (so J and J + 1 are blended,
+// as written), orthographic light projections, the literal zero PCF radius.  The transforms are then wave-uniform (scalar
+// registers) and the footprints of both cascades are fetched together -- one memory round trip where cascade_shadow takes one
+// per lookup.  Same operations per pixel, so the same bits; returns false (nothing done) when the wavefront is not uniform.
+struct CascadePair { ShadowFetch f0, f1; float z0, z1; };
+template <bool ZERO_RADIUS>
+CRY_HD bool cascade_fetch_uniform(const LightParams& P, f3 posW, float distance, bool fixQ1, CascadePair& c)
+{
+    if (!ZERO_RADIUS || fixQ1 || !P.shadowWIsOne) return false;
+    const float pmax = 1.2676506e30f;     // light_shadow_w_is_one: bounded posW
+    const int j = cascade_index(distance);
+    int J = j;
+#if defined(__HIP_DEVICE_COMPILE__)
+    J = __builtin_amdgcn_readfirstlane(J);
+#endif
+    const bool ok = j == J && J <= 2 && __builtin_fabsf(posW.x) < pmax && __builtin_fabsf(posW.y) < pmax && __builtin_fabsf(posW.z) < pmax;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__builtin_amdgcn_ballot_w64(!ok) != 0) return false;
+#else
+    if (!ok) return false;
+#endif
+    const float* T0 = P.ShadowTransforms[J];
+    const float* T1 = P.ShadowTransforms[J + 1];
+    c.f0 = shadow_fetch(P.shadow[J], P.shadowDim, mulcol1(posW.x, posW.y, posW.z, T0 + 0), mulcol1(posW.x, posW.y, posW.z, T0 + 4));
+    c.f1 = shadow_fetch(P.shadow[J + 1], P.shadowDim, mulcol1(posW.x, posW.y, posW.z, T1 + 0), mulcol1(posW.x, posW.y, posW.z, T1 + 4));
+    c.z0 = mulcol1(posW.x, posW.y, posW.z, T0 + 8);
+    c.z1 = mulcol1(posW.x, posW.y, posW.z, T1 + 8);
+    return true;
+}
+CRY_HD float cascade_resolve_uniform(const LightParams& P, const CascadePair& c)
+{
+    const float a = pcf_zero_radius(shadow_resolve(c.f0, P.shadowDim, c.z0));
+    const float b = pcf_zero_radius(shadow_resolve(c.f1, P.shadowDim, c.z1));
+    return 0.5f * (a + b);                                      // :66
+}
+
+// DeferredShading.hlsl:23-101 for one covered pixel.  Every gather of the pixel -- ambient map, cubemap, shadow cascades -- is
+// issued before the first is waited for (one memory round trip instead of one per lookup).
 // FIX: a compile-time promise that P.flags may carry CRYCHIC_FIX_* bits; false = the reference as written, with no trace of
 // the switches in the instantiation the benchmark runs.
 template <bool ZERO_RADIUS, class PointLights = NoPointLights, bool FIX = false>
@@ -260,51 +378,26 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
     const f3 R0{ lerpf(0.04f, albedo.x, metalness), lerpf(0.04f, albedo.y, metalness),
                  lerpf(0.04f, albedo.z, metalness) };           // :35
 
-    float ambientAccess = 1.0f;
+    AmbientFetch af;
     if (ambient) {                                              // :40-42
         const float sx = mulcol1(posW.x, posW.y, posW.z, P.ViewProjTex + 0);
         const float sy = mulcol1(posW.x, posW.y, posW.z, P.ViewProjTex + 4);
         const float rsw = rcp(mulcol1(posW.x, posW.y, posW.z, P.ViewProjTex + 12));
-        ambientAccess = ambient_linear_clamp(ambient, P.W / 2, P.H / 2, sx * rsw, sy * rsw);
+        af = ambient_fetch(ambient, P.W / 2, P.H / 2, sx * rsw, sy * rsw);
     }
-    const f3 amb{ ambientAccess * P.AmbientLight[0] * albedo.x, ambientAccess * P.AmbientLight[1] * albedo.y,
-                  ambientAccess * P.AmbientLight[2] * albedo.z };  // :44
+    const f3 r = reflect3(f3{ -view.x, -view.y, -view.z }, normalW);  // :94
+    const CubeFetch cf = cube_fetch(cube, P.cubeDim, r);        // :95
 
-    // :53-76  cascade selection.  `abs(distance - radius[j] < 5.0f)` is abs(bool) (Q1), true whenever
-    // distance < radius[j]: every pixel nearer than 80 blends cascades j and j+1.
-    float shadow0 = 1.0f;
+    // :53-76  cascade selection and shadow factor of light 0
     const float d2Eye = dot3(toEye, toEye);
     const float distance = len_from_sq(d2Eye);
-    int j = 4;
-    if (distance < 30.0f) j = 0;
-    else if (distance < 50.0f) j = 1;
-    else if (distance < 80.0f) j = 2;
-    else if (distance < 100.0f) j = 3;
-    if (j < 4) {
-        // posW bounded => no product with a zero matrix entry is NaN / inf => shadowPosH.w == 1 (light_shadow_w_is_one)
-        const float pmax = 1.2676506e30f;
-        bool wOne = P.shadowWIsOne && __builtin_fabsf(posW.x) < pmax && __builtin_fabsf(posW.y) < pmax && __builtin_fabsf(posW.z) < pmax;
-#if defined(__HIP_DEVICE_COMPILE__)
-        wOne = __builtin_amdgcn_ballot_w64(!wOne) == 0;          // wave-uniform choice of the instantiation
-#endif
-        auto cascade = [&](int k) {
-            const float* T = P.ShadowTransforms[k];
-            const float spx = mulcol1(posW.x, posW.y, posW.z, T + 0), spy = mulcol1(posW.x, posW.y, posW.z, T + 4);
-            const float spz = mulcol1(posW.x, posW.y, posW.z, T + 8);
-            if (wOne) return pcf_poisson<ZERO_RADIUS, true>(P.shadow[k], P.shadowDim, spx, spy, spz, 1.0f, P.pcfSearchRadius);
-            float spw = mulcol1(posW.x, posW.y, posW.z, T + 12);
-#if defined(__HIP_DEVICE_COMPILE__)
-            asm volatile("" : "+v"(spw));   // keeps the three divisions inside this (rare) branch: the optimiser would otherwise
-                                            // speculate them above the wave-uniform test and select afterwards
-#endif
-            return pcf_poisson<ZERO_RADIUS, false>(P.shadow[k], P.shadowDim, spx, spy, spz, spw, P.pcfSearchRadius);
-        };
-        const float a = cascade(j);
-        const float radiusJ = j == 0 ? 30.0f : (j == 1 ? 50.0f : (j == 2 ? 80.0f : 100.0f));
-        const bool blend = j < 3 && (!fixQ1 || __builtin_fabsf(distance - radiusJ) < 5.0f);   // Q1: as written, every j < 3 blends
-        if (blend) shadow0 = 0.5f * (a + cascade(j + 1));      // :66
-        else shadow0 = a;                                       // :73
-    }
+    CascadePair cp;
+    const float shadow0 = cascade_fetch_uniform<ZERO_RADIUS>(P, posW, distance, fixQ1, cp) ? cascade_resolve_uniform(P, cp)
+                                                                                          : cascade_shadow<ZERO_RADIUS>(P, posW, distance, fixQ1);
+
+    const float ambientAccess = ambient ? ambient_resolve(af) : 1.0f;
+    const f3 amb{ ambientAccess * P.AmbientLight[0] * albedo.x, ambientAccess * P.AmbientLight[1] * albedo.y,
+                  ambientAccess * P.AmbientLight[2] * albedo.z };  // :44
 
     const float shininess = (1.0f - roughness) * 1.0f;          // :84 (normalW.a == 1)
 
@@ -319,8 +412,7 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
     lit.y = det_pow(divf(direct.y, direct.y + 1.0f), invGamma) + amb.y;
     lit.z = det_pow(divf(direct.z, direct.z + 1.0f), invGamma) + amb.z;
 
-    const f3 r = reflect3(f3{ -view.x, -view.y, -view.z }, normalW);  // :94
-    const f4 refl = cube_linear(cube, P.cubeDim, r);            // :95
+    const f4 refl = cube_resolve(cf);
     const float f0 = 1.0f - saturate(dot3(normalW, r));         // LightingUtil.hlsl:54-57
     const float f5 = f0 * f0 * f0 * f0 * f0;
     lit.x = fma(shininess * fma(1.0f - R0.x, f5, R0.x), refl.x, lit.x);  // :97

@@ -3,7 +3,7 @@
 #   tools/measure_all.sh <tag>
 # 1 bench.py default (JSON line incl. cpu_baseline + producers)   2 rocprofv3 kernel trace of the same command
 # 3 PMC passes on the torch-free driver                           4 informational legs (covered camera, intended PCF, 1080p,
-#   8K + 64 point lights, two frames in flight, the eight strips of an 8-GPU run one at a time)
+#   8K + 64 point lights, 1 / 2 / 4 frames in flight, the eight strips of an 8-GPU run one at a time)
 set -o pipefail
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
@@ -23,7 +23,9 @@ cp "$(find "$out/prof_covered" -name '*kernel_stats.csv' | head -1)" "$out/kerne
 $B $L --pcf intended > "$out/bench_pcf_intended.json" 2>> "$out/bench.err" || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_pcf" -- python bench.py --steps 50 --warmup 5 $L --pcf intended > /dev/null 2>> "$out/prof.err" || exit 1
 cp "$(find "$out/prof_pcf" -name '*kernel_stats.csv' | head -1)" "$out/kernel_stats_pcf_intended.csv"
-$B $L --also-two-in-flight > "$out/bench_two_in_flight.json" 2>> "$out/bench.err" || exit 1
+for f in 1 2 4; do $B $L --frames-in-flight $f > "$out/bench_${f}_in_flight.json" 2>> "$out/bench.err" || exit 1; done
+rocprofv3 --kernel-trace --stats --output-format csv -d "$out/prof_serial" -- python bench.py --steps 100 --warmup 10 $L --frames-in-flight 1 > "$out/bench_1_in_flight_under_rocprof.json" 2>> "$out/prof.err" || exit 1
+cp "$(find "$out/prof_serial" -name '*kernel_stats.csv' | head -1)" "$out/kernel_stats_1_in_flight.csv"
 $B $L --width 1920 --height 1080 --blur-count 1 > "$out/bench_c2_1080p.json" 2>> "$out/bench.err" || exit 1
 python bench.py --steps 30 --warmup 5 $L --width 7680 --height 4320 --point-lights 8 > "$out/bench_c5_8k_64lights.json" 2>> "$out/bench.err" || exit 1
 : > "$out/strips.txt"
@@ -35,5 +37,5 @@ o = json.loads(sys.stdin.readline())
 print('$part strip 8:$r rows', o['config']['strip_rows'], 'ms', o['ms_per_step'])" >> "$out/strips.txt" || exit 1
   done
 done
-rm -rf "$out/prof" "$out/prof_covered" "$out/prof_pcf"
+rm -rf "$out/prof" "$out/prof_covered" "$out/prof_pcf" "$out/prof_serial"
 echo "measure_all done"
