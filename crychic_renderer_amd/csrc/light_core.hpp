@@ -215,10 +215,11 @@ CRY_HD CubeFetch cube_fetch(const uint32_t* __restrict__ cube, uint32_t dim, f3 
     // major axis (ties x >= y >= z) and the face's (sc, tc) by selects: a wave whose lanes look at different faces stays converged
     const bool isx = (ax >= ay) & (ax >= az), isy = !isx & (ay >= az);
     const bool px = r.x >= 0.0f, py = r.y >= 0.0f, pz = r.z >= 0.0f;
-    const float ma = isx ? ax : (isy ? ay : az);
-    const float sc = isx ? (px ? -r.z : r.z) : (isy ? r.x : (pz ? r.x : -r.x));
-    const float tc = isx ? -r.y : (isy ? (py ? r.z : -r.z) : -r.y);
-    const uint32_t face = isx ? (px ? 0u : 1u) : (isy ? (py ? 2u : 3u) : (pz ? 4u : 5u));
+    const bool ux = __builtin_unpredictable(isx), uy = __builtin_unpredictable(isy);      // selects, not branches
+    const float ma = ux ? ax : (uy ? ay : az);
+    const float sc = ux ? (px ? -r.z : r.z) : (uy ? r.x : (pz ? r.x : -r.x));
+    const float tc = ux ? -r.y : (uy ? (py ? r.z : -r.z) : -r.y);
+    const uint32_t face = ux ? (px ? 0u : 1u) : (uy ? (py ? 2u : 3u) : (pz ? 4u : 5u));
     const float rma = rcp(ma);
     const float u = fma(0.5f, sc * rma, 0.5f);      // 0.5 * (sc / ma + 1)
     const float v = fma(0.5f, tc * rma, 0.5f);
@@ -286,12 +287,8 @@ struct AllPointLights {
 // cascades j and j+1.
 CRY_HD int cascade_index(float distance)    // :53-58
 {
-    int j = 4;
-    if (distance < 30.0f) j = 0;
-    else if (distance < 50.0f) j = 1;
-    else if (distance < 80.0f) j = 2;
-    else if (distance < 100.0f) j = 3;
-    return j;
+    // the first radius the distance is below (radii ascend, so it is below all later ones as well); NaN -> 4
+    return 4 - ((int)(distance < 30.0f) + (int)(distance < 50.0f) + (int)(distance < 80.0f) + (int)(distance < 100.0f));
 }
 template <bool ZERO_RADIUS>
 CRY_HD float cascade_shadow(const LightParams& P, f3 posW, float distance, bool fixQ1)
@@ -378,13 +375,13 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
     const f3 R0{ lerpf(0.04f, albedo.x, metalness), lerpf(0.04f, albedo.y, metalness),
                  lerpf(0.04f, albedo.z, metalness) };           // :35
 
-    AmbientFetch af;
-    if (ambient) {                                              // :40-42
-        const float sx = mulcol1(posW.x, posW.y, posW.z, P.ViewProjTex + 0);
-        const float sy = mulcol1(posW.x, posW.y, posW.z, P.ViewProjTex + 4);
-        const float rsw = rcp(mulcol1(posW.x, posW.y, posW.z, P.ViewProjTex + 12));
-        af = ambient_fetch(ambient, P.W / 2, P.H / 2, sx * rsw, sy * rsw);
-    }
+    // :40-42; without an ambient map the fetch still runs, on a 1 x 1 stand-in (the cubemap's first bytes), so that no branch
+    // separates it from the other gathers
+    const bool hasAO = ambient != nullptr;
+    const float sx = mulcol1(posW.x, posW.y, posW.z, P.ViewProjTex + 0);
+    const float sy = mulcol1(posW.x, posW.y, posW.z, P.ViewProjTex + 4);
+    const float rsw = rcp(mulcol1(posW.x, posW.y, posW.z, P.ViewProjTex + 12));
+    const AmbientFetch af = ambient_fetch(hasAO ? ambient : (const uint16_t*)cube, hasAO ? P.W / 2 : 1u, hasAO ? P.H / 2 : 1u, sx * rsw, sy * rsw);
     const f3 r = reflect3(f3{ -view.x, -view.y, -view.z }, normalW);  // :94
     const CubeFetch cf = cube_fetch(cube, P.cubeDim, r);        // :95
 
@@ -395,7 +392,7 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
     const float shadow0 = cascade_fetch_uniform<ZERO_RADIUS>(P, posW, distance, fixQ1, cp) ? cascade_resolve_uniform(P, cp)
                                                                                           : cascade_shadow<ZERO_RADIUS>(P, posW, distance, fixQ1);
 
-    const float ambientAccess = ambient ? ambient_resolve(af) : 1.0f;
+    const float ambientAccess = hasAO ? ambient_resolve(af) : 1.0f;
     const f3 amb{ ambientAccess * P.AmbientLight[0] * albedo.x, ambientAccess * P.AmbientLight[1] * albedo.y,
                   ambientAccess * P.AmbientLight[2] * albedo.z };  // :44
 
