@@ -503,9 +503,10 @@ hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, con
     if (use_pairs && !edge_base) return hipErrorInvalidValue;
     dim3 grid = grid_for(W / 2, rows);
     // super-tiles of SX x SY workgroup tiles (64 x 4 half-res pixels each) per XCD; the grid is padded to whole super-tiles
-    // 6 x 32 tiles = 384 x 128 half-res pixels (768 x 256 depth texels, 0.8 MB): measured best of 20 shapes at 4K and 8K
-    // (4K: 208 -> 186 us against full-width stripes of 16 tile rows; 8K: 1.56 -> 0.82 ms)
-    uint32_t SX = 6u, SY = 32u;
+    // 4 x 32 tiles = 256 x 128 half-res pixels (512 x 256 depth texels, 1 MB of the pairs plane plus the reach of the taps
+    // around it, against 4 MiB of L2): best of 11 shapes on the pairs plane at 4K (pass 112.2 us with 6 x 32, the best shape on
+    // the raw D24 plane, 106.4 us with 4 x 32; full-width stripes of 16 tile rows were 208 us in round 1)
+    uint32_t SX = 4u, SY = 32u;
     SX = SX > grid.x ? grid.x : SX;
     SY = SY > grid.y ? grid.y : SY;
     grid.x = (grid.x + SX - 1u) / SX * SX;
