@@ -13,7 +13,9 @@ crychic_allgather_frame -- RCCL over xGMI behind the C ABI (csrc/comm.cpp), enqu
 the strip; torch.distributed (gloo) carries only control traffic (rendezvous id, barriers, the max over ranks).
 Workload = BASELINE.json configs[2]: 3840x2160, 3 directional lights, blurCount 4, cascade PCF.  The PCF radius
 follows the reference shader as written (Common.hlsl:305 unsigned division => 16 coincident taps); --pcf intended
-benches the 2.5-texel variant instead.
+benches the 2.5-texel variant instead.  At N = 1 three independent frames are in flight on three streams, as the reference
+keeps them (gNumFrameResources = 3); the K frames are then also timed one at a time (config.one_frame_at_a_time) and the
+per-pass list is measured that way.  --frames-in-flight 1 makes one-at-a-time the timed region itself.
 
 Rank 0 prints ONE JSON line: metric/value/... plus "roofline" (frame level per SURVEY.md 8d, with a per-kernel
 break-down measured by HIP events on the launch stream) and "cpu_baseline" (the CPU oracle on a band of the frame).

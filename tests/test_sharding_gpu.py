@@ -98,6 +98,10 @@ def test_bench_json_contract(built_lib):
     assert "traffic" in rf and rf["achieved"] > 0 and rf["scope"] == "frame"
     assert rf["traffic"] is None                      # not the workload the committed PMC passes were taken on
     assert [k["kernel"].split()[0] for k in rf["kernels"]] == ["ssao_kernel", "blur", "light_kernel"]
+    # N = 1 default: three frames in flight (the reference's gNumFrameResources), with the same K frames timed one at a time beside it
+    assert out["config"]["frames_in_flight"] == 3
+    serial = out["config"]["one_frame_at_a_time"]
+    assert serial["ms_per_frame"] > 0 and serial["Mpixels_per_s"] > 0 and 0 < serial["hbm_roofline_frac"] < 1
     assert all(k["ms"] > 0 and k["achieved_GBs"] > 0 for k in rf["kernels"])
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Mpixels/s" and isinstance(cb["sample"], str)
