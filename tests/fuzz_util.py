@@ -26,6 +26,15 @@ def random_case(seed, built_lib):
     nrm[(sel >= 0.04) & (sel < 0.05), 1] = np.inf
     nrm[(sel >= 0.05) & (sel < 0.30)] = np.array([0.0, 0.0, -1.0, 0.0], dtype=np.float16)   # flat patches: blur accepts
     g0 = (rng.standard_normal((H, W, 4)) * 20.0).astype(np.float32); g0[..., 3] = rng.random((H, W))
+    if rng.random() < 0.4:
+        # coherent world positions (a tilted plane receding from the eye, a little noise): whole wavefronts then fall into one
+        # shadow cascade, which is what the wave-uniform cascade path of the lighting kernel needs to run at all
+        yy, xx = np.mgrid[0:H, 0:W].astype(np.float32)
+        far = float(rng.choice([25.0, 60.0, 120.0]))
+        eye = np.array(list(c.cam.pos), dtype=np.float32)
+        g0[..., 0] = eye[0] + (xx / W - 0.5) * 6.0
+        g0[..., 1] = eye[1] - 1.0 + rng.standard_normal((H, W)).astype(np.float32) * 0.05
+        g0[..., 2] = eye[2] + 2.0 + (1.0 - yy / H) * far
     g1 = rng.random((H, W, 4)).astype(np.float32)
     g2 = rng.standard_normal((H, W, 4)).astype(np.float32)
     sel = rng.random((H, W))
