@@ -67,9 +67,10 @@ def parse():
                     help="run the strip exchange even with one rank: exercises the N > 1 code path on a 1-GPU box")
     ap.add_argument("--exchange", choices=["abi", "torch"], default="abi",
                     help="abi: crychic_allgather_frame (RCCL behind the C ABI); torch: torch.distributed nccl all_gather (fallback)")
-    ap.add_argument("--partition", choices=["equal", "balanced"], default="equal",
-                    help="N > 1: equal = H/N rows each, one in-place ncclAllGather (default: the plan every test covers); "
-                         "balanced = cost-aware strip heights re-cut from measured strip times + one group of ncclBroadcasts")
+    ap.add_argument("--partition", choices=["equal", "balanced"], default="balanced",
+                    help="N > 1: balanced (default) = cost-aware strip heights, seeded from the depth plane's coverage and re-cut from "
+                         "measured strip times, one group of in-place ncclBroadcasts; falls back to equal if the plan cannot be made or "
+                         "the gathered frame fails its check.  equal = H/N rows each, one in-place ncclAllGather")
     ap.add_argument("--balance-iters", type=int, default=4, help="measured re-balancing steps of the strip plan before the warm-up")
     ap.add_argument("--covered-weight", type=float, default=3.0, help="cost of a fully covered row pair relative to a sky row pair")
     ap.add_argument("--strip", default="", help="N:R -- time only the row strip rank R of N would render (no exchange): what one rank "
@@ -83,6 +84,10 @@ def parse():
                     help="plumbing rehearsal WITHOUT a GPU and without rendering: rank spawning, rendezvous, the strip plan and a gloo "
                          "exchange of synthetic strips; prints a line marked data=dry-run (not a measurement)")
     ap.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)   # tests: this rank exits 7 before the rendezvous
+    ap.add_argument("--fail-first-check", action="store_true", help=argparse.SUPPRESS)      # tests: the first frame check reports a mismatch
+    ap.add_argument("--plan-rehearsal", action="store_true", help=argparse.SUPPRESS)        # tests: N ranks share GPU 0 and render their strips
+    #                                                                                         without the exchange (RCCL refuses two ranks on one
+    #                                                                                         device): rendezvous, measured strip plan, timing
     return ap.parse_args()
 
 
@@ -412,6 +417,8 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (the product has no CPU path); --dry-run rehearses the plumbing without one")
+    if args.plan_rehearsal:
+        local_rank = 0
     if local_rank >= torch.cuda.device_count():
         raise SystemExit("rank %d: LOCAL_RANK %d but only %d GPU(s) visible" % (rank, local_rank, torch.cuda.device_count()))
     torch.cuda.set_device(local_rank)
@@ -456,29 +463,57 @@ def main():
         return int(flag) == 0
 
     # ---- strip plan -------------------------------------------------------------------------------------------------
-    # equal (default): H/N rows per rank -- the plan every parity and gloo test covers, one in-place ncclAllGather.
-    # balanced (opt-in): start from the depth plane's coverage (a covered row costs ~3x a sky row), then let every rank time
-    # its own strip for a few frames, share the times and re-cut (sharding.StripBalancer).
+    # balanced (default): start from the depth plane's coverage (a covered row costs ~3x a sky row), then let every rank time
+    # its own strip for a few frames, share the times and re-cut (sharding.StripBalancer): the frame's cost sits in its lower
+    # half, so H/N rows each would leave the sky ranks idle.  Rank 0's plan is broadcast after every step, so the ranks agree
+    # on it by construction; if anything in this phase fails on any rank, all ranks fall back to equal strips together.
+    # equal: H/N rows per rank, one in-place ncclAllGather.
     bounds = None
     if args.partition == "balanced" and (world > 1 or args.strip or args.force_gather):
-        balancer = sharding.StripBalancer(planes["depth"], int(args.strip.split(":")[0]) if args.strip else world, args.covered_weight)
-        bounds = balancer.bounds()
-        if world > 1:
-            app.mBackBuffer = planes["out"]
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            for _ in range(args.balance_iters):
-                r0_, rn_ = bounds[rank]
-                for _ in range(3):
-                    app.Draw(r0_, rn_)
-                e0.record()
-                for _ in range(20):
-                    app.Draw(r0_, rn_)
-                e1.record()
-                torch.cuda.synchronize()
-                mine = torch.tensor([e0.elapsed_time(e1) / 20.0], dtype=torch.float64)
-                every = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
-                dist.all_gather(every, mine)
-                bounds = balancer.update([float(v) for v in every])      # same inputs, same plan on every rank
+        nstrips = int(args.strip.split(":")[0]) if args.strip else world
+
+        def agreed(b):
+            """rank 0's plan on every rank (control plane)"""
+            if not use_dist:
+                return b
+            t = torch.tensor([v for rb in b for v in rb], dtype=torch.int64)
+            dist.broadcast(t, src=0)
+            return [(int(t[2 * r]), int(t[2 * r + 1])) for r in range(nstrips)]
+
+        ok = True
+        try:
+            balancer = sharding.StripBalancer(planes["depth"], nstrips, args.covered_weight)
+            bounds = balancer.bounds()
+        except Exception as e:  # noqa: BLE001
+            print("bench.py rank %d: no balanced strip plan (%s)" % (rank, e), file=sys.stderr, flush=True)
+            ok = False
+        if all_ranks_ok(ok):
+            bounds = agreed(bounds)
+            if world > 1:
+                app.mBackBuffer = planes["out"]
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                for _ in range(args.balance_iters):
+                    mine = torch.tensor([-1.0], dtype=torch.float64)
+                    try:
+                        r0_, rn_ = bounds[rank]
+                        for _ in range(3):
+                            app.Draw(r0_, rn_)
+                        e0.record()
+                        for _ in range(20):
+                            app.Draw(r0_, rn_)
+                        e1.record()
+                        torch.cuda.synchronize()
+                        mine[0] = e0.elapsed_time(e1) / 20.0
+                    except Exception as e:  # noqa: BLE001
+                        print("bench.py rank %d: strip timing failed (%s)" % (rank, e), file=sys.stderr, flush=True)
+                    every = [torch.zeros(1, dtype=torch.float64) for _ in range(world)]
+                    dist.all_gather(every, mine)
+                    if any(float(v) <= 0.0 for v in every):
+                        break                                            # keep the last agreed plan
+                    bounds = agreed(balancer.update([float(v) for v in every]))
+        else:
+            bounds = None
+            args.partition = "equal (fallback: no balanced plan)"
     row0, rows = bounds[rank] if bounds and not args.strip else sharding.strip_rows(H, world, rank)
     if args.strip:
         sn, sr = (int(v) for v in args.strip.split(":"))
@@ -501,7 +536,7 @@ def main():
     # slot's gather ahead of its next lighting pass, no host wait anywhere).  If the communicator cannot be created on every
     # rank, all ranks fall back together to torch.distributed's nccl all_gather (equal strips only).
     exchange, exchange_kind = None, None
-    if use_dist and not args.strip:
+    if use_dist and not args.strip and not args.plan_rehearsal:
         if args.exchange == "abi":
             idt = torch.zeros(128, dtype=torch.uint8)
             try:
@@ -571,13 +606,13 @@ def main():
         app.Draw(row0, rows)
     torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    fence()
-    exchange_ok = None
-    if exchange is not None and args.warmup > 0:
-        # Every rank must now hold the same complete frame, and it must be the frame one GPU renders alone: compare a checksum
-        # of the last gathered frame across ranks, and the gathered frame with a full local render bit for bit.
+    def warm_and_check():
+        """W warm-up frames, then: every rank must hold the same complete frame, and it must be the frame one GPU renders alone
+        -- a checksum of the last gathered frame compared across ranks, the gathered frame compared with a full local render
+        bit for bit."""
+        for i in range(args.warmup):
+            step(i)
+        fence()
         last = args.warmup - 1
         f = exchange.frame(last % nflight if abi else last)
         chk = int((f.reshape(-1).to(torch.int64) * (torch.arange(f.numel(), device=dev, dtype=torch.int64) % 251 + 1)).sum())
@@ -587,16 +622,36 @@ def main():
         app.Draw(0, H)
         torch.cuda.synchronize()
         exchange_ok = all(int(c) == chk for c in allchk) and bool(torch.equal(f, planes["out"]))
+        if args.fail_first_check:
+            args.fail_first_check, exchange_ok = False, False
+        return exchange_ok, allchk
+
+    exchange_ok = None
+    if exchange is not None and args.warmup > 0:
+        exchange_ok, allchk = warm_and_check()
+        if not all_ranks_ok(exchange_ok) and abi and bounds is not None:
+            # the ragged plan failed its check on some rank: every rank switches to equal strips (same communicator, one
+            # in-place ncclAllGather) and the check runs again
+            print("bench.py rank %d: balanced strips failed the frame check (checksums %s); falling back to equal strips"
+                  % (rank, [int(c) for c in allchk]), file=sys.stderr, flush=True)
+            bounds = None
+            exchange.set_bounds(None)
+            row0, rows = sharding.strip_rows(H, world, rank)
+            args.partition = "equal (fallback: the balanced plan failed the frame check)"
+            exchange_ok, allchk = warm_and_check()
         if not all_ranks_ok(exchange_ok):
             raise SystemExit("bench.py rank %d: the gathered frame differs between ranks or from the single-GPU frame (checksums %s)"
                              % (rank, [int(c) for c in allchk]))
+    elif args.warmup > 0:
+        for i in range(args.warmup):
+            step(i)
         fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(i)
     fence()
     dt = time.perf_counter() - t0
-    if exchange is None and nflight > 1 and not torch.equal(outs[0], outs[1]):
+    if exchange is None and nflight > 1 and not torch.equal(outs[0][row0:row0 + rows], outs[1][row0:row0 + rows]):
         raise SystemExit("bench.py: the frame pipelines disagree")      # same inputs, same kernels: must be the same bytes
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64)
@@ -675,13 +730,14 @@ def main():
             "scaling": "strong",
             "vs_baseline": None,
             "dtype": "f32",
-            "data": "synthetic",
+            "data": "synthetic" if not args.plan_rehearsal else "synthetic (PLAN REHEARSAL: all ranks on one GPU, no exchange -- not a measurement)",
             "config": {"workload": "BASELINE configs[2]: %dx%d, box+grid scene, %d dir lights, 14-tap SSAO + %d-pass bilateral "
                                    "blur + cascade PCF (%s radius), 4x%d^2 D24 shadow maps%s" % (
                                        W, H, args.lights, args.blur_count, args.pcf, args.shadow_dim,
                                        "" if args.camera == "reference" else ", camera pitched down (no sky)"),
                        "launcher": os.environ.get("CRYCHIC_BENCH_LAUNCHER", "external (torch.distributed.run)" if world > 1 else "direct"),
                        "sharding": ("%s row strips x%d" % (args.partition, world)) if world > 1 else "single GPU",
+                       "partition": args.partition if use_dist else None,
                        "exchange": exchange_kind, "exchange_verified": exchange_ok, "frames_in_flight": nflight,
                        "one_frame_at_a_time": serial,
                        "strip_rows": rows, "strip_plan": [b[1] for b in bounds] if bounds and world > 1 else None,

@@ -202,6 +202,19 @@ class StripExchange:
         check(lib.crychic_comm_create(ctx.handle, self.nranks, self.rank, idbuf, C.byref(self.handle)))
         self.render = [torch.zeros((H, W, 4), dtype=torch.uint8, device=ctx.device) for _ in range(int(slots))]
 
+    def set_bounds(self, bounds):
+        """Switch the strip plan (None = equal strips) on the same communicator; the caller makes sure every rank does so
+        between the same two frames."""
+        self.bounds = [tuple(int(v) for v in b) for b in bounds] if bounds is not None else None
+        if self.bounds is not None:
+            assert len(self.bounds) == self.nranks and sum(b[1] for b in self.bounds) == self.H and self.bounds[0][0] == 0
+            flat = [v for b in self.bounds for v in b]
+            self._bounds_arr = (C.c_uint32 * len(flat))(*flat)
+            self.row0, self.rows = self.bounds[self.rank]
+        else:
+            self._bounds_arr = None
+            self.row0, self.rows = strip_rows(self.H, self.nranks, self.rank)
+
     @staticmethod
     def new_unique_id():
         """Rank 0 calls this and hands the bytes to its peers out of band (ncclGetUniqueId)."""

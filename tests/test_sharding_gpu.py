@@ -42,6 +42,41 @@ def test_bench_gather_path_single_rank_rccl(built_lib, exchange, inflight, parti
     assert ("crychic_allgather_frame" in out["config"]["exchange"]) == (exchange == "abi"), out["config"]["exchange"]
 
 
+def test_bench_balanced_plan_falls_back_to_equal(built_lib):
+    """The default (balanced) strip plan whose gathered frame fails its check: every rank switches to equal strips on the same
+    communicator and the check runs again (the failure is injected; one rank on RCCL)."""
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-gather", "--fail-first-check", "--steps", "5", "--warmup", "2",
+           "--width", "640", "--height", "360", "--shadow-dim", "512", "--cube-dim", "64", "--no-cpu-baseline", "--no-producers", "--timeout", "400"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
+    assert out["config"]["exchange_verified"] is True
+    assert out["config"]["partition"].startswith("equal (fallback"), out["config"]["partition"]
+    assert "falling back to equal strips" in r.stderr
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_bench_measured_strip_plan_multi_rank(built_lib, n):
+    """The part of an N > 1 run that needs neither several GPUs nor RCCL, with real ranks: self-spawn, gloo rendezvous, the
+    balanced strip plan re-cut from the strip times the ranks measure and share, rank 0's plan adopted by all, K timed frames,
+    max over ranks.  The ranks share GPU 0 and skip the exchange (RCCL refuses two ranks on one device): --plan-rehearsal."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--plan-rehearsal", "--steps", "5", "--warmup", "2", "--width", "640",
+           "--height", "360", "--shadow-dim", "512", "--cube-dim", "64", "--no-cpu-baseline", "--no-producers", "--timeout", "400"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]
+    out = json.loads(lines[0])
+    cfg = out["config"]
+    assert out["n_gpus"] == n and "REHEARSAL" in out["data"] and cfg["partition"] == "balanced" and cfg["launcher"] == "self-spawn"
+    plan = cfg["strip_plan"]
+    assert len(plan) == n and sum(plan) == 360 and all(p >= 2 and p % 2 == 0 for p in plan)
+    assert plan[0] > plan[-1]                 # the sky strip at the top is the cheap one: it is given more rows
+    assert out["value"] > 0 and out["ms_per_step"] > 0
+
+
 def test_allgather_frame_abi_single_rank(built_lib):
     """crychic_comm_* / crychic_allgather_frame through ctypes with one rank: communicator from a rendezvous id, equal and
     explicit bounds, the stream-ordered barrier, error paths (CRYCHIC_E_COMM / INVALID_ARG never crash)."""
