@@ -90,7 +90,7 @@ int ssao_compute_impl(crychic_ctx* ctx, const crychic_ssao_constants* cb, const 
     // With a workspace at hand the depth plane is re-laid once per frame as decoded pairs (whole plane: the taps of any row
     // reach far up and down the frame) and the taps gather from that; its cost is part of the SSAO pass.
     const uint32_t stamp = next_stamp(ctx);
-    if (edge) CRY_HIP(cry::launch_depth_pairs(depth, edge, W, H, stamp, stream));
+    if (edge) CRY_HIP(cry::launch_depth_pairs(*cb, depth, edge, W, H, stamp, stream));
     CRY_HIP(cry::launch_ssao(*cb, normal, depth, randvec, ambient0, edge, W, H, r0, rn, true, edge != nullptr, stamp, stream));
     if (afterSsao) CRY_HIP(hipEventRecord(afterSsao, stream));
     // Iteration 0 records each direction's tap decisions; iterations 1.. replay them (same geometry, same rows or fewer).
@@ -214,7 +214,7 @@ int crychic_ssao(crychic_ctx* ctx, const crychic_ssao_constants* cb, const void*
     if (!cb || !normal_dev || !depth_dev || !randvec_dev || !ambient_out_dev) return fail(CRYCHIC_E_INVALID_ARG, "null argument");
     if (row0 > H / 2 || rows > H / 2 - row0) return fail(CRYCHIC_E_INVALID_ARG, "rows [%u,+%u) outside the %u-row ambient map", row0, rows, H / 2);
     const uint32_t stamp = next_stamp(ctx);
-    if (edge_dev) CRY_HIP(cry::launch_depth_pairs(depth_dev, edge_dev, W, H, stamp, (hipStream_t)stream));
+    if (edge_dev) CRY_HIP(cry::launch_depth_pairs(*cb, depth_dev, edge_dev, W, H, stamp, (hipStream_t)stream));
     CRY_HIP(cry::launch_ssao(*cb, normal_dev, depth_dev, randvec_dev, ambient_out_dev, edge_dev, W, H, row0, rows, true, edge_dev != nullptr,
                              stamp, (hipStream_t)stream));
     return 0;

@@ -61,27 +61,56 @@ __device__ __forceinline__ void tile_origin_2d(uint32_t& bx, uint32_t& by, uint3
 
 // ---- SSAO ------------------------------------------------------------------------------------------------
 // Re-lays the D24 depth plane as decoded {d(x, y), d(x, y+1)} entries with a BORDER guard band (ssao_core.hpp "depth pairs"):
-// one lane per two horizontally adjacent entries (a 16-byte store), rows y = -2 .. H, entries x = -2 .. W+1.
-// By-product: the coarse geometry map of the sky shortcut (ssao_core.hpp).  A wave covers texel columns
-// [128 blockIdx.x - 2, 128 blockIdx.x + 126) of row y = py - 2 (through the .x / .z components of its entries); if any of them
-// lies below the clear depth it stamps the cell (blockIdx.x, y / 32) with this frame's stamp -- a plain store: every writer of
-// a cell stores the same value, and a stale or uninitialised word can only read as "geometry" (no shortcut), never as "sky".
+// one lane per two horizontally adjacent entries (a 16-byte store), rows y = -2 .. H, entries x = -2 .. W+1; a workgroup
+// covers 8 rows (two per wave) x 128 entries = 16 blocks of 8 x 8 padded texels.
+// By-products: the coarse geometry map of the sky shortcut and the nearest-depth map of the tap culling (ssao_core.hpp).
+// A wave covers texel columns [128 blockIdx.x - 2, 128 blockIdx.x + 126) of its rows (through the .x / .z components of its
+// entries); if any texel of a row lies below the clear depth it stamps the cell (blockIdx.x, y / 32) with this frame's stamp --
+// a plain store: every writer of a cell stores the same value, and a stale or uninitialised word can only read as "geometry"
+// (no shortcut), never as "sky".  The block minima go through a 4-lane shuffle and LDS; positions outside the padded plane
+// count as the clear depth, which is what a footprint reaching them reads.
 __global__ __launch_bounds__(256) void depth_pairs_kernel(const uint32_t* __restrict__ depth, f4a* __restrict__ pairs, uint32_t* __restrict__ geo,
-                                                          uint32_t stamp, uint32_t W, uint32_t H)
+                                                          float* __restrict__ zmin, uint32_t stamp, uint32_t W, uint32_t H, CullParams cull)
 {
+    __shared__ float s_min[4][16];
     const uint32_t halfPitch = depth_pairs_pitch(W) / 2u;
-    const uint32_t px2 = blockIdx.x * 64u + (threadIdx.x & 63u);
-    const uint32_t py = blockIdx.y * 4u + (threadIdx.x >> 6);
-    if (py >= H + 3u) return;                                   // wave-uniform
-    bool geometry = false;
-    if (px2 < halfPitch) {
-        const f4a e = depth_pairs_entry2(depth, W, H, 2 * (int)px2 - 2, (int)py - 2);
-        pairs[py * halfPitch + px2] = e;
-        geometry = (e.x != 1.0f) | (e.z != 1.0f);              // texels (x, y), (x + 1, y): BORDER and clear-depth texels decode to 1.0
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t px2 = blockIdx.x * 64u + lane;
+    float m = 1.0f;
+#pragma unroll
+    for (uint32_t r = 0; r < 2u; ++r) {
+        const uint32_t py = blockIdx.y * 8u + wave * 2u + r;
+        bool geometry = false;
+        if (py < H + 3u && px2 < halfPitch) {
+            const f4a e = depth_pairs_entry2(depth, W, H, 2 * (int)px2 - 2, (int)py - 2);
+            pairs[py * halfPitch + px2] = e;
+            geometry = (e.x != 1.0f) | (e.z != 1.0f);              // texels (x, y), (x + 1, y): BORDER and clear-depth texels decode to 1.0
+            m = __builtin_fminf(m, __builtin_fminf(e.x, e.z));
+        }
+        const uint32_t y = py - 2u;
+        if (__builtin_amdgcn_ballot_w64(geometry) != 0 && lane == 0 && y < H)
+            geo[(y >> 5) * geo_map_cols(W) + blockIdx.x] = stamp;
     }
-    const uint32_t y = py - 2u;
-    if (__builtin_amdgcn_ballot_w64(geometry) != 0 && (threadIdx.x & 63u) == 0 && y < H)
-        geo[(y >> 5) * geo_map_cols(W) + blockIdx.x] = stamp;
+    // 8 padded texel columns = 4 lanes
+    m = __builtin_fminf(m, __shfl_xor(m, 1));
+    m = __builtin_fminf(m, __shfl_xor(m, 2));
+    if ((lane & 3u) == 0) s_min[wave][lane >> 2] = m;
+    __syncthreads();
+    if (threadIdx.x < 16u) {
+        const uint32_t cx = blockIdx.x * 16u + threadIdx.x;
+        if (cx < zmin_map_cols(W) && blockIdx.y < zmin_map_rows(H)) {
+            const float mm = __builtin_fminf(__builtin_fminf(s_min[0][threadIdx.x], s_min[1][threadIdx.x]),
+                                             __builtin_fminf(s_min[2][threadIdx.x], s_min[3][threadIdx.x]));
+            zmin[blockIdx.y * zmin_map_cols(W) + cx] = zmin_cell_value(cull.A, cull.B, mm);
+        }
+    }
+}
+
+// The lookup map of the tap culling: per block position the smallest of the 2 x 2 block values starting there.
+__global__ __launch_bounds__(256) void zmin_combine_kernel(const float* __restrict__ zmin, float* __restrict__ zcull, uint32_t cols, uint32_t rows)
+{
+    const uint32_t cx = blockIdx.x * 64u + (threadIdx.x & 63u), cy = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (cx < cols && cy < rows) zcull[cy * cols + cx] = zmin_combine(zmin, cols, rows, cx, cy);
 }
 
 // Shaders/Ssao.hlsl:117-199 over half-res rows [row0, row1).  EMIT_AO = false builds only the edge workspace.
@@ -92,7 +121,7 @@ __global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, co
                                                    const uint32_t* __restrict__ randvec,
                                                    uint16_t* __restrict__ ambient, EdgePlane edge, uint32_t W,
                                                    uint32_t H, uint32_t row0, uint32_t row1, uint32_t SX, uint32_t SY, int sparseProjTex,
-                                                   SkyReach sky, uint32_t stamp)
+                                                   SkyReach sky, uint32_t stamp, int cullEnabled)
 {
     const uint32_t w2 = W / 2;
     uint32_t bx, by;
@@ -128,7 +157,10 @@ __global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, co
         }
     }
     if (EMIT_AO) {
-        const uint32_t v = PAIRS ? ssao_pixel(cb, c, dp, randvec, W, H, x, y, sparseProjTex != 0) : ssao_pixel(cb, c, dd, randvec, W, H, x, y, sparseProjTex != 0);
+        uint32_t v;
+        if (PAIRS && cullEnabled) v = ssao_pixel(cb, c, dp, randvec, W, H, x, y, sparseProjTex != 0, ZminMap{ edge.zcull, zmin_map_cols(W) });
+        else if (PAIRS) v = ssao_pixel(cb, c, dp, randvec, W, H, x, y, sparseProjTex != 0);
+        else v = ssao_pixel(cb, c, dd, randvec, W, H, x, y, sparseProjTex != 0);
         ambient[y * w2 + x] = (uint16_t)v;
         // unoccluded-wavefront map (ssao_core.hpp "unoccluded tiles"): lane 0 is live whenever the wave is (x = 64 bx < w2)
         if (PAIRS && stamp != 0u && __builtin_amdgcn_ballot_w64(v != 0xFFFFu) == 0 && (threadIdx.x & 63u) == 0)
@@ -485,11 +517,18 @@ static inline dim3 grid_for(uint32_t width, uint32_t rows, uint32_t rows_per_blo
     return dim3((width + 63u) / 64u, (rows + rows_per_block - 1u) / rows_per_block, 1);
 }
 
-hipError_t launch_depth_pairs(const uint32_t* depth, void* edge_base, uint32_t W, uint32_t H, uint32_t stamp, hipStream_t stream)
+hipError_t launch_depth_pairs(const crychic_ssao_constants& cb, const uint32_t* depth, void* edge_base, uint32_t W, uint32_t H, uint32_t stamp,
+                              hipStream_t stream)
 {
     const EdgePlane e = edge_plane_carve(edge_base, W, H);
-    const dim3 grid((depth_pairs_pitch(W) / 2u + 63u) / 64u, (H + 3u + 3u) / 4u, 1);      // grid.x == geo_map_cols(W)
-    hipLaunchKernelGGL(depth_pairs_kernel, grid, dim3(256), 0, stream, depth, (f4a*)const_cast<void*>(e.pairs), e.geo, stamp, W, H);
+    // grid.x == geo_map_cols(W); 16 cells of the nearest-depth map per workgroup in x, one cell row in y
+    const dim3 grid((depth_pairs_pitch(W) / 2u + 63u) / 64u, zmin_map_rows(H), 1);
+    const CullParams cull = ssao_cull_params(cb);
+    hipLaunchKernelGGL(depth_pairs_kernel, grid, dim3(256), 0, stream, depth, (f4a*)const_cast<void*>(e.pairs), e.geo, e.zmin, stamp, W, H, cull);
+    if (cull.enabled) {
+        const uint32_t cols = zmin_map_cols(W), rows = zmin_map_rows(H);
+        hipLaunchKernelGGL(zmin_combine_kernel, dim3((cols + 63u) / 64u, (rows + 3u) / 4u, 1), dim3(256), 0, stream, e.zmin, e.zcull, cols, rows);
+    }
     return hipGetLastError();
 }
 
@@ -514,7 +553,8 @@ hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, con
     const int sparse = ssao_projtex_is_sparse(cb) ? 1 : 0;
     SkyReach sky = ssao_sky_reach(cb, W, H);
     if (!use_pairs || stamp == 0u) sky.enabled = 0;      // stamp 0: the caller did not build the geometry map
-#define CRY_LAUNCH_SSAO(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, cb, (const u2*)normal, depth, (const uint32_t*)randvec, ambient, e, W, H, row0, row0 + rows, SX, SY, sparse, sky, stamp)
+    const int cull = (use_pairs && stamp != 0u && ssao_cull_params(cb).enabled) ? 1 : 0;    // the nearest-depth map comes with the pairs plane
+#define CRY_LAUNCH_SSAO(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, cb, (const u2*)normal, depth, (const uint32_t*)randvec, ambient, e, W, H, row0, row0 + rows, SX, SY, sparse, sky, stamp, cull)
     if (emit_ao && use_pairs) CRY_LAUNCH_SSAO((ssao_kernel<true, true>));
     else if (emit_ao) CRY_LAUNCH_SSAO((ssao_kernel<true, false>));
     else CRY_LAUNCH_SSAO((ssao_kernel<false, false>));

@@ -31,6 +31,8 @@ struct EdgePlane {
     const void* pairs; // DepthPairs plane (below), depth_pairs_bytes(W, H)
     uint32_t* geo;     // coarse geometry map (below "sky shortcut"), geo_map_bytes(W, H)
     uint32_t* ones;    // unoccluded-wavefront map (below "unoccluded tiles"), ones_map_bytes(W, H)
+    float* zmin;       // nearest-depth map per 8 x 8 block (below "tap culling"), zmin_map_bytes(W, H)
+    float* zcull;      // the same per 2 x 2 blocks: what a tap looks up, zmin_map_bytes(W, H)
 };
 
 // ---- depth pairs -----------------------------------------------------------------------------------------------------
@@ -60,7 +62,14 @@ CRY_HD size_t edge_plane_geo_offset(uint32_t W, uint32_t H) { return (edge_plane
 CRY_HD uint32_t ones_map_cols(uint32_t W) { return (W / 2u + 63u) / 64u; }
 CRY_HD size_t ones_map_bytes(uint32_t W, uint32_t H) { return (size_t)ones_map_cols(W) * (H / 2u) * 4u; }
 CRY_HD size_t edge_plane_ones_offset(uint32_t W, uint32_t H) { return (edge_plane_geo_offset(W, H) + geo_map_bytes(W, H) + 15) & ~(size_t)15; }
-CRY_HD size_t edge_plane_bytes(uint32_t W, uint32_t H) { return edge_plane_ones_offset(W, H) + ones_map_bytes(W, H); }
+// Coarse nearest-depth map ("tap culling" below): one float per block of 8 x 8 texels of the padded depth plane (padded texel
+// (ex, ey) = texel (ex - 2, ey - 2): the coordinates of the pairs plane, BORDER band included).
+CRY_HD uint32_t zmin_map_cols(uint32_t W) { return (W + 4u + 7u) / 8u; }
+CRY_HD uint32_t zmin_map_rows(uint32_t H) { return (H + 4u + 7u) / 8u; }
+CRY_HD size_t zmin_map_bytes(uint32_t W, uint32_t H) { return (size_t)zmin_map_cols(W) * zmin_map_rows(H) * 4u; }
+CRY_HD size_t edge_plane_zmin_offset(uint32_t W, uint32_t H) { return (edge_plane_ones_offset(W, H) + ones_map_bytes(W, H) + 15) & ~(size_t)15; }
+CRY_HD size_t edge_plane_zcull_offset(uint32_t W, uint32_t H) { return (edge_plane_zmin_offset(W, H) + zmin_map_bytes(W, H) + 15) & ~(size_t)15; }
+CRY_HD size_t edge_plane_bytes(uint32_t W, uint32_t H) { return edge_plane_zcull_offset(W, H) + zmin_map_bytes(W, H); }
 // Entries (x, y) and (x + 1, y) of the pairs plane from the D24 plane; x even (so the two texels of a row are one 8-byte load).
 CRY_HD f4a depth_pairs_entry2(const uint32_t* __restrict__ depth, uint32_t W, uint32_t H, int x, int y)
 {
@@ -88,6 +97,8 @@ CRY_HD EdgePlane edge_plane_carve(void* base, uint32_t W, uint32_t H)
     e.pairs = b + edge_plane_pairs_offset(W, H);
     e.geo = (uint32_t*)(b + edge_plane_geo_offset(W, H));
     e.ones = (uint32_t*)(b + edge_plane_ones_offset(W, H));
+    e.zmin = (float*)(b + edge_plane_zmin_offset(W, H));
+    e.zcull = (float*)(b + edge_plane_zcull_offset(W, H));
     return e;
 }
 
@@ -286,6 +297,65 @@ CRY_HD GeoCells ssao_sky_cells(const SkyReach& r, uint32_t W, uint32_t H, uint32
     return g;
 }
 
+// ---- tap culling ---------------------------------------------------------------------------------------------------------
+// A tap adds dp * occlusion to the sum, and occlusion is 0 whenever distZ = p.z - r.z <= SurfaceEpsilon (Ssao.hlsl:76-108): the
+// surface under the tap is not in front of the pixel by more than epsilon.  On open ground that is nine taps out of ten, and the
+// depth gather -- the whole cost of the pass -- only confirms it.  depth_pairs_kernel therefore also leaves, per block of 8 x 8
+// padded depth texels, a LOWER BOUND of the view depth any footprint inside the block can return:
+//     cell = ndc_to_view(min over the block of the decoded texels - 2^-21) * 0.999998.
+// A footprint with top-left padded texel (ex, ey) lies inside the 2 x 2 blocks starting at (ex >> 3, ey >> 3); a second small
+// pass stores the smallest of those four cells per block position (zmin_combine), and if that value is >= p.z - epsilon the
+// tap is skipped: gather, reconstruction, normalisation and all.  Why that is exact:
+//   * bilinear filtering returns >= min(texels) - 2^-22 in binary32 (three lerps, each a mad on values in [0, 1]);
+//   * ndc_to_view is B * rcp(z - A) with B < 0 < 1 < A (checked on the host: ssao_cull_params): every step is monotone, so the
+//     cell bounds the tap's rz from below; r.z = (rz * rcp(q.z)) * q.z is rz within 3 ulp -- covered by the factor 0.999998;
+//   * hence p.z - r.z <= epsilon in real numbers, and rounding is monotone: distZ <= epsilon, occlusion = 0;
+//   * dp is finite -- the pixel's normal and p are finite and |p| < 1e15 (checked per pixel), q.z >= 1e-3 (checked per tap) -- so
+//     the term is +0 and the sum does not change.
+// The lookup is one 4-byte load from a 0.5 MB map (L1 / L2 resident) in place of a 16-byte gather that misses L1; the parity
+// and fuzz tests run the kernel bodies with culling against an oracle that has none.
+struct CullParams { int enabled; float A, B; };
+CRY_HD CullParams ssao_cull_params(const crychic_ssao_constants& cb)
+{
+    CullParams c{ 0, cb.Proj[4 * 2 + 2], cb.Proj[4 * 2 + 3] };
+    const float eps = cb.SurfaceEpsilon;
+    // z - A < 0 for every filtered z <= 1 + 2^-21, B < 0: view depth positive and increasing in z; far plane finite
+    const bool ok = c.A > 1.000002f && c.A < 1.0e6f && c.B < 0.0f && c.B > -1.0e12f && eps == eps && __builtin_fabsf(eps) < 1.0e30f;
+    c.enabled = ok ? 1 : 0;
+    return c;
+}
+CRY_HD float zmin_cell_value(float A, float B, float blockMinNdc)
+{
+    return divf(B, (blockMinNdc - 4.76837158203125e-7f) - A) * 0.999998f;       // ndc_to_view(min - 2^-21), scaled down
+}
+// per pixel: p.z - epsilon when the pixel may cull at all, NaN (no comparison succeeds) otherwise
+CRY_HD float ssao_cull_threshold(f3 nRaw, f3 p, float eps)
+{
+    const float big = 1.0e15f;
+    const bool ok = (__builtin_fabsf(nRaw.x) < 3.0e38f) & (__builtin_fabsf(nRaw.y) < 3.0e38f) & (__builtin_fabsf(nRaw.z) < 3.0e38f) &
+                    (__builtin_fabsf(p.x) < big) & (__builtin_fabsf(p.y) < big) & (__builtin_fabsf(p.z) < big);
+    return ok ? p.z - eps : u2f(0x7FC00000u);
+}
+struct NoCull {
+    static constexpr bool active = false;
+    CRY_HD bool operator()(int, int, float) const { return false; }
+};
+// cell (cx, cy) of the lookup map: the smallest block value of blocks (cx .. cx+1, cy .. cy+1), the map's edge repeated
+CRY_HD float zmin_combine(const float* __restrict__ zmin, uint32_t cols, uint32_t rows, uint32_t cx, uint32_t cy)
+{
+    const uint32_t cx1 = cx + 1u < cols ? cx + 1u : cx, cy1 = cy + 1u < rows ? cy + 1u : cy;
+    return __builtin_fminf(__builtin_fminf(zmin[cy * cols + cx], zmin[cy * cols + cx1]), __builtin_fminf(zmin[cy1 * cols + cx], zmin[cy1 * cols + cx1]));
+}
+struct ZminMap {
+    static constexpr bool active = true;
+    const float* cells; uint32_t pitch;                            // EdgePlane::zcull, zmin_map_cols(W)
+    CRY_HD bool operator()(int i0, int j0, float pzEps) const     // (i0, j0): top-left texel of the footprint, already in [-2, dim]
+    {
+        const uint32_t cx = (uint32_t)(i0 + 2) >> 3, cy = (uint32_t)(j0 + 2) >> 3;      // inside the map for every clamped index
+        return load_at<float>(cells, (mul24(cy, pitch) + cx) * 4u) >= pzEps;          // NaN on either side: not culled
+    }
+};
+
 struct SsaoCentre {
     u2 nrm_bits;  // raw fp16 normal texel
     float vz;        // linear view depth at the pixel centre
@@ -315,10 +385,10 @@ CRY_HD SsaoCentre ssao_centre(const crychic_ssao_constants& cb, const u2* __rest
 }
 
 // Ssao.hlsl:117-199 for half-res pixel (x, y); returns the R16_UNORM ambient value.  `sparseProjTex` = ssao_projtex_is_sparse(cb).
-template <class Depth>
+template <class Depth, class Cull = NoCull>
 CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c,
                            const Depth depth, const uint32_t* __restrict__ randvec, uint32_t W,
-                           uint32_t H, uint32_t x, uint32_t y, bool sparseProjTex)
+                           uint32_t H, uint32_t x, uint32_t y, bool sparseProjTex, const Cull cull = Cull(), uint32_t* culledTaps = nullptr)
 {
     const uint32_t w2 = W / 2, h2 = H / 2;
     const float u = divf((float)x + 0.5f, (float)w2);
@@ -333,10 +403,12 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
     const float rphw = rcp(phw);
     const f3 PosV{ phx * rphw, phy * rphw, phz * rphw };
 
-    const f3 n = normalize3(unpack_normal(c.nrm_bits));   // :125
+    const f3 nRaw = unpack_normal(c.nrm_bits);
+    const f3 n = normalize3(nRaw);                        // :125
     const float pz = c.vz;                                // :126-127
     const float t = divf(pz, PosV.z);                     // :135
     const f3 p{ t * PosV.x, t * PosV.y, t * PosV.z };
+    const float pzEps = Cull::active ? ssao_cull_threshold(nRaw, p, cb.SurfaceEpsilon) : 0.0f;   // "tap culling"
 
     const f3 rv = randvec_linear_wrap(randvec, 4.0f * u, 4.0f * v);  // :138
     const f3 randVec{ fma(2.0f, rv.x, -1.0f), fma(2.0f, rv.y, -1.0f), fma(2.0f, rv.z, -1.0f) };
@@ -392,9 +464,20 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
         const v2f fy = v2f{ __builtin_fmaxf(ty.x - fly.x, 0.0f), __builtin_fmaxf(ty.y - fly.y, 0.0f) };
         const int i0a = texel_index(flx.x, W), j0a = texel_index(fly.x, H);
         const int i0b = texel_index(flx.y, W), j0b = texel_index(fly.y, H);
-        float a00, a10, a01, a11, b00, b10, b01, b11;
-        depth.footprint(i0a, j0a, a00, a10, a01, a11);
-        depth.footprint(i0b, j0b, b00, b10, b01, b11);
+        // tap culling: a tap whose footprint cannot return a surface in front of the pixel adds exactly +0
+        const bool ca = Cull::active && (q.z.x >= 1.0e-3f) && cull(i0a, j0a, pzEps);
+        const bool cb2 = Cull::active && (q.z.y >= 1.0e-3f) && cull(i0b, j0b, pzEps);
+        if (Cull::active) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (__builtin_amdgcn_ballot_w64(!(ca & cb2)) == 0) continue;      // the whole wavefront skips both taps
+#else
+            if (culledTaps) *culledTaps += (ca ? 1u : 0u) + (cb2 ? 1u : 0u);
+            if (ca & cb2) continue;
+#endif
+        }
+        float a00 = 1.0f, a10 = 1.0f, a01 = 1.0f, a11 = 1.0f, b00 = 1.0f, b10 = 1.0f, b01 = 1.0f, b11 = 1.0f;
+        if (!ca) depth.footprint(i0a, j0a, a00, a10, a01, a11);
+        if (!cb2) depth.footprint(i0b, j0b, b00, b10, b01, b11);
         const v2f t00{ a00, b00 }, t10{ a10, b10 }, t01{ a01, b01 }, t11{ a11, b11 };
         const v2f zndc = lerp2(lerp2(t00, t10, fx), lerp2(t01, t11, fx), fy);
         const v2f rz = B * rcp2(zndc - A);                                        // :164-165
@@ -407,8 +490,10 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
         const v2f dp = max0_2(dot3x2(n2, dn));                                    // :186
         const v2f fade = saturate2((fadeEnd - distZ) * rFadeLength);              // :76-108
         const v2f occ = select2(distZ > eps, fade, splat(0.0f));
-        occlusionSum = fma(dp.x, occ.x, occlusionSum);                            // :188-190, tap i then tap i+1
-        occlusionSum = fma(dp.y, occ.y, occlusionSum);
+        // a culled tap of a lane whose wavefront went on: its term is the +0 the argument above promises (the placeholder
+        // footprint is never looked at)
+        occlusionSum = fma(ca ? 0.0f : dp.x, ca ? 0.0f : occ.x, occlusionSum);      // :188-190, tap i then tap i+1
+        occlusionSum = fma(cb2 ? 0.0f : dp.y, cb2 ? 0.0f : occ.y, occlusionSum);
     }
     };
     if (sparse) taps(SparseTag<true>{}); else taps(SparseTag<false>{});

@@ -45,6 +45,8 @@ void hs_eval_array(int kind, size_t n, const float* in, const float* in2, float*
 
 static uint32_t g_sky_waves = 0;     // wavefronts the last hs_ssao_path call resolved through the sky shortcut
 uint32_t hs_last_sky_waves(void) { return g_sky_waves; }
+static uint32_t g_culled_taps = 0;   // taps the last hs_ssao_path call skipped through the nearest-depth map
+uint32_t hs_last_culled_taps(void) { return g_culled_taps; }
 
 // use_pairs != 0: the product's default path -- build the decoded depth-pairs plane in the edge workspace (the body of
 // depth_pairs_kernel) and let the taps gather from it; 0: taps on the raw D24 plane (what runs without a workspace).
@@ -81,8 +83,28 @@ void hs_ssao_path(const crychic_ssao_constants* cb, const void* normal, const ui
                 if (v.x != 1.0f || v.z != 1.0f) e.geo[((py - 2u) >> 5) * gpitch + px2 / 64u] = stamp;
             }
     }
+    // the nearest-depth map as depth_pairs_kernel fills it: per block of 8 x 8 padded texels (padded (ex, ey) = texel (ex - 2, ey - 2),
+    // anything outside the plane reads as the clear depth), and the whole map as the culling window
+    const CullParams cp = ssao_cull_params(*cb);
+    const bool culling = pairs && cp.enabled && use_pairs != 2;         // use_pairs == 2: pairs plane without tap culling
+    const ZminMap win{ e.zcull, zmin_map_cols(W) };
+    if (pairs) {
+        for (uint32_t cy = 0; cy < zmin_map_rows(H); ++cy)
+            for (uint32_t cx = 0; cx < zmin_map_cols(W); ++cx) {
+                float m = 1.0f;
+                for (uint32_t ey = 8u * cy; ey < 8u * cy + 8u; ++ey)
+                    for (uint32_t ex = 8u * cx; ex < 8u * cx + 8u; ++ex) {
+                        const int tx = (int)ex - 2, ty = (int)ey - 2;
+                        if ((uint32_t)tx < W && (uint32_t)ty < H) m = __builtin_fminf(m, d24_to_float(depth[(uint32_t)ty * W + (uint32_t)tx]));
+                    }
+                e.zmin[cy * zmin_map_cols(W) + cx] = zmin_cell_value(cp.A, cp.B, m);
+            }
+        for (uint32_t cy = 0; cy < zmin_map_rows(H); ++cy)      // zmin_combine_kernel
+            for (uint32_t cx = 0; cx < zmin_map_cols(W); ++cx) e.zcull[cy * zmin_map_cols(W) + cx] = zmin_combine(e.zmin, zmin_map_cols(W), zmin_map_rows(H), cx, cy);
+    }
     std::vector<SsaoCentre> row(w2);
     g_sky_waves = 0;
+    g_culled_taps = 0;
     for (uint32_t y = row0; y < row0 + rows; ++y) {
         for (uint32_t x = 0; x < w2; ++x) {
             const SsaoCentre c = pairs ? ssao_centre(*cb, nrm, dp, W, H, (int)x, (int)y) : ssao_centre(*cb, nrm, depth, W, H, (int)x, (int)y);
@@ -108,8 +130,9 @@ void hs_ssao_path(const crychic_ssao_constants* cb, const void* normal, const ui
             bool allOnes = true;
             for (uint32_t x = x0; x < x0 + n; ++x) {
                 ambient[y * w2 + x] = skip ? (uint16_t)0xFFFFu
-                                           : (uint16_t)(pairs ? ssao_pixel(*cb, row[x], dp, (const uint32_t*)randvec, W, H, x, y, sparse)
-                                                              : ssao_pixel(*cb, row[x], dd, (const uint32_t*)randvec, W, H, x, y, sparse));
+                                           : (uint16_t)(culling ? ssao_pixel(*cb, row[x], dp, (const uint32_t*)randvec, W, H, x, y, sparse, win, &g_culled_taps)
+                                                        : pairs ? ssao_pixel(*cb, row[x], dp, (const uint32_t*)randvec, W, H, x, y, sparse)
+                                                                : ssao_pixel(*cb, row[x], dd, (const uint32_t*)randvec, W, H, x, y, sparse));
                 allOnes = allOnes && ambient[y * w2 + x] == 0xFFFFu;
             }
             if (pairs && allOnes) e.ones[y * ones_map_cols(W) + x0 / 64u] = stamp;      // the unoccluded-wavefront map, as ssao_kernel writes it

@@ -54,6 +54,7 @@ class HostSim:
         L.hs_ssao.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, u32, u32]
         L.hs_ssao_path.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, i]
         L.hs_last_sky_waves.restype = u32
+        L.hs_last_culled_taps.restype = u32
         L.hs_blur.argtypes = [vp, vp, vp, vp, u32, u32, i, u32, u32]
         L.hs_blur_mode.argtypes = [vp, vp, vp, vp, u32, u32, i, i, u32, u32, i]
         L.hs_last_ones_tiles.restype = u32
@@ -67,16 +68,16 @@ class HostSim:
         self.lib.hs_eval_array(kind, a.size, a.ctypes.data, b.ctypes.data, out.ctypes.data)
         return out
 
-    def ssao(self, cb, normal_f16, depth_u32, randvec_u8, edge_bytes, row0=0, rows=None, emit=True, pairs=True):
-        """pairs=True: the taps gather from the decoded depth-pairs plane (the product's path when it has a workspace);
-        pairs=False: from the raw D24 plane."""
+    def ssao(self, cb, normal_f16, depth_u32, randvec_u8, edge_bytes, row0=0, rows=None, emit=True, pairs=True, cull=True):
+        """pairs=True: the taps gather from the decoded depth-pairs plane (the product's path when it has a workspace), and with
+        cull=True skip the ones the nearest-depth map proves to add nothing; pairs=False: from the raw D24 plane."""
         H, W = depth_u32.shape
         rows = H // 2 - row0 if rows is None else rows
         out = np.zeros((H // 2, W // 2), dtype=np.uint16)
         edge = np.zeros((edge_bytes,), dtype=np.uint8)
         n = np.ascontiguousarray(normal_f16.view(np.uint16)); d = np.ascontiguousarray(depth_u32); r = np.ascontiguousarray(randvec_u8)
         self.lib.hs_ssao_path(C.addressof(cb), n.ctypes.data, d.ctypes.data, r.ctypes.data, out.ctypes.data if emit else None,
-                              edge.ctypes.data, W, H, row0, rows, 1 if pairs else 0)
+                              edge.ctypes.data, W, H, row0, rows, (1 if cull else 2) if pairs else 0)
         return out, edge
 
     def blur(self, cb, edge, ambient_in, W, H, horizontal, row0=0, rows=None):
