@@ -471,7 +471,7 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
 #if defined(__HIP_DEVICE_COMPILE__)
             if (__builtin_amdgcn_ballot_w64(!(ca & cb2)) == 0) continue;      // the whole wavefront skips both taps
 #else
-            if (culledTaps) *culledTaps += (ca ? 1u : 0u) + (cb2 ? 1u : 0u);
+            if (culledTaps) { culledTaps[0] += (ca ? 1u : 0u) + (cb2 ? 1u : 0u); culledTaps[1] |= ((ca ? 1u : 0u) << i) | ((cb2 ? 1u : 0u) << (i + 1)); }
             if (ca & cb2) continue;
 #endif
         }

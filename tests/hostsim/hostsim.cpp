@@ -47,6 +47,8 @@ static uint32_t g_sky_waves = 0;     // wavefronts the last hs_ssao_path call re
 uint32_t hs_last_sky_waves(void) { return g_sky_waves; }
 static uint32_t g_culled_taps = 0;   // taps the last hs_ssao_path call skipped through the nearest-depth map
 uint32_t hs_last_culled_taps(void) { return g_culled_taps; }
+static uint16_t* g_cull_masks = nullptr;      // optional: per half-res pixel, bit i = tap i culled (analysis only)
+void hs_set_cull_mask_plane(uint16_t* plane) { g_cull_masks = plane; }
 
 // use_pairs != 0: the product's default path -- build the decoded depth-pairs plane in the edge workspace (the body of
 // depth_pairs_kernel) and let the taps gather from it; 0: taps on the raw D24 plane (what runs without a workspace).
@@ -130,7 +132,11 @@ void hs_ssao_path(const crychic_ssao_constants* cb, const void* normal, const ui
             bool allOnes = true;
             for (uint32_t x = x0; x < x0 + n; ++x) {
                 ambient[y * w2 + x] = skip ? (uint16_t)0xFFFFu
-                                           : (uint16_t)(culling ? ssao_pixel(*cb, row[x], dp, (const uint32_t*)randvec, W, H, x, y, sparse, win, &g_culled_taps)
+                                           : (uint16_t)(culling ? [&] { uint32_t acc[2] = { 0u, 0u };
+                                                                         const uint32_t v = ssao_pixel(*cb, row[x], dp, (const uint32_t*)randvec, W, H, x, y, sparse, win, acc);
+                                                                         g_culled_taps += acc[0];
+                                                                         if (g_cull_masks) g_cull_masks[y * w2 + x] = (uint16_t)(acc[1] | 0x8000u);
+                                                                         return v; }()
                                                         : pairs ? ssao_pixel(*cb, row[x], dp, (const uint32_t*)randvec, W, H, x, y, sparse)
                                                                 : ssao_pixel(*cb, row[x], dd, (const uint32_t*)randvec, W, H, x, y, sparse));
                 allOnes = allOnes && ambient[y * w2 + x] == 0xFFFFu;
