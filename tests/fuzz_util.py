@@ -118,3 +118,31 @@ def sky_probe_case(seed):
     if seed >= 12:
         randvec = (rng.integers(0, 2, size=(256, 256, 4), dtype=np.uint8) * 255).astype(np.uint8)      # |randVec| = sqrt(3): the longest reflected offsets
     return W, H, c, scb, depth, normal, randvec
+
+
+def cull_probe_case(seed, W=256, H=160):
+    """Frames for the SSAO tap culling (ssao_core.hpp): the reference scene -- open ground, where most taps are culled -- with what
+    the nearest-depth bound must not miss: single near texels (spikes a fraction of a block wide), texels just in front of their
+    surroundings (around SurfaceEpsilon in view space), holes to the far plane, depth 0, a few small patches, NaN normals, and one
+    of several SurfaceEpsilon values.  Returns (W, H, constants, depth, normal, randvec)."""
+    import scene_util
+    pl = scene_util.cpu_scene(W, H, 64, 8)
+    p = scene_util.np_planes(pl)
+    c = pl["consts"]
+    rng = np.random.default_rng(1234 + seed)
+    depth, normal = p["depth"].copy(), p["normal"].copy()
+    if seed > 0:
+        n = 60
+        ys, xs = rng.integers(0, H, n), rng.integers(0, W, n)
+        kind = rng.integers(0, 4, n)
+        base = depth[ys, xs] & 0xFFFFFF
+        spike = np.where(kind == 0, rng.integers(0, 1 << 22, n),
+                np.where(kind == 1, base - rng.integers(0, 200, n).clip(max=base),
+                np.where(kind == 2, 0xFFFFFF, 0))).astype(np.uint32)
+        depth[ys, xs] = spike
+        for _ in range(6):
+            y0, x0 = int(rng.integers(0, H - 4)), int(rng.integers(0, W - 4))
+            depth[y0:y0 + int(rng.integers(1, 5)), x0:x0 + int(rng.integers(1, 5))] = int(rng.integers(0, 1 << 24))
+        normal[rng.integers(0, H, 40), rng.integers(0, W, 40), 0] = np.nan
+        c.ssao_cb.SurfaceEpsilon = float([0.05, 0.0, 0.5, 0.05, 1e-4, 0.05][seed % 6])
+    return W, H, c, depth, normal, p["randvec"]

@@ -98,6 +98,32 @@ def test_ssao_bit_exact(ctx, built_lib, oracle, W, H):
     assert np.array_equal(dev_u16(c.a0), ref)
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3, 4, 5])
+def test_tap_culling_on_device(ctx, built_lib, oracle, seed):
+    """SSAO tap culling on the device (nearest-depth map built by depth_pairs_kernel + zmin_combine_kernel, per-lane skipped
+    gathers, wave-level skipped tap pairs) against the oracle, on the probe frames of
+    tests/test_hostsim_parity.py::test_tap_culling_is_exact_and_bites; then the whole ComputeSsao chain on the same workspace."""
+    import fuzz_util
+    import oracle_lib
+    W, H, c, depth, normal, randvec = fuzz_util.cull_probe_case(seed, 384, 224)
+    scb = oracle_lib.as_oracle_cb(c.ssao_cb, oracle_lib.OrSsaoConstants)
+    lib, check = built_lib.lib, built_lib.check
+    dev = ctx.device
+    d = torch.from_numpy(depth.view(np.int32)).to(dev); n = torch.from_numpy(normal).to(dev); r = torch.from_numpy(randvec).to(dev)
+    a0 = torch.zeros((H // 2, W // 2), dtype=torch.int16, device=dev)
+    a1 = torch.zeros_like(a0)
+    edge = torch.zeros((int(lib.crychic_edge_plane_bytes(W, H)),), dtype=torch.uint8, device=dev)
+    ref = oracle.ssao(scb, normal, depth, randvec)
+    check(lib.crychic_ssao(ctx.handle, C.byref(c.ssao_cb), ptr(n), ptr(d), ptr(r), ptr(a0), ptr(edge), W, H, 0, H // 2, stream(ctx)))
+    torch.cuda.synchronize()
+    got = dev_u16(a0)
+    assert np.array_equal(got, ref), int((got != ref).sum())
+    assert (ref < 65535).sum() > 50
+    check(lib.crychic_ssao_compute(ctx.handle, C.byref(c.ssao_cb), ptr(n), ptr(d), ptr(r), ptr(a0), ptr(a1), ptr(edge), W, H, 3, 0, H // 2, stream(ctx)))
+    torch.cuda.synchronize()
+    assert np.array_equal(dev_u16(a0), oracle.compute_ssao(scb, normal, depth, randvec, 3))
+
+
 @pytest.mark.parametrize("W,H", SIZES)
 def test_blur_sweeps_bit_exact(ctx, built_lib, oracle, W, H):
     c = get_case(ctx, built_lib, W, H)

@@ -157,27 +157,11 @@ def test_tap_culling_is_exact_and_bites(built_lib, oracle, hostsim, seed):
     bound must not miss: single near texels (spikes a fraction of a block wide), texels just inside / outside SurfaceEpsilon of
     their surroundings, holes to the far plane, depth 0; with three SurfaceEpsilon values.  Kernel bodies with culling == oracle
     without it, with and without the depth-pairs plane, and the cull fires on a large share of the taps."""
-    W, H = 256, 160
-    p, c, scb, pcb, eb = setup(W, H, built_lib)
-    rng = np.random.default_rng(1234 + seed)
-    depth = p["depth"].copy()
-    normal = p["normal"].copy()
-    if seed > 0:
-        n = 60
-        ys, xs = rng.integers(0, H, n), rng.integers(0, W, n)
-        kind = rng.integers(0, 4, n)
-        base = depth[ys, xs] & 0xFFFFFF
-        spike = np.where(kind == 0, rng.integers(0, 1 << 22, n),                                   # far in front
-                np.where(kind == 1, base - rng.integers(0, 200, n).clip(max=base),                  # just in front (around epsilon in view space)
-                np.where(kind == 2, 0xFFFFFF, 0))).astype(np.uint32)                               # a hole to the far plane / depth 0
-        depth[ys, xs] = spike
-        # a few small patches as well (several texels: whole footprints inside them)
-        for _ in range(6):
-            y0, x0 = int(rng.integers(0, H - 4)), int(rng.integers(0, W - 4))
-            depth[y0:y0 + int(rng.integers(1, 5)), x0:x0 + int(rng.integers(1, 5))] = int(rng.integers(0, 1 << 24))
-        normal[rng.integers(0, H, 40), rng.integers(0, W, 40), 0] = np.nan                          # pixels that must not cull at all
-        c.ssao_cb.SurfaceEpsilon = float([0.05, 0.0, 0.5, 0.05, 1e-4, 0.05][seed])
-        scb = oracle_lib.as_oracle_cb(c.ssao_cb, oracle_lib.OrSsaoConstants)
+    import fuzz_util
+    W, H, c, depth, normal, randvec = fuzz_util.cull_probe_case(seed)
+    p = {"randvec": randvec}
+    eb = int(built_lib.lib.crychic_edge_plane_bytes(W, H))
+    scb = oracle_lib.as_oracle_cb(c.ssao_cb, oracle_lib.OrSsaoConstants)
     ref = oracle.ssao(scb, normal, depth, p["randvec"])
     got, _ = hostsim.ssao(c.ssao_cb, normal, depth, p["randvec"], eb)
     culled = int(hostsim.lib.hs_last_culled_taps())
@@ -196,7 +180,7 @@ def test_tap_culling_is_exact_and_bites(built_lib, oracle, hostsim, seed):
         assert int(hostsim.lib.hs_last_culled_taps()) == 0
         assert np.array_equal(got, oracle.ssao(scb, normal, depth, p["randvec"]))
     finally:
-        c.ssao_cb.Proj[4 * 2 + 3], c.ssao_cb.SurfaceEpsilon = keep[0], 0.05        # setup() hands out a shared constants object
+        c.ssao_cb.Proj[4 * 2 + 3], c.ssao_cb.SurfaceEpsilon = keep
 
 
 @pytest.mark.parametrize("seed", [0, 1, 5, 12, 14])
