@@ -4,7 +4,7 @@ profiles/r02_pmc_counters.json, the file bench.py's `roofline` object reads hard
 
     tools/make_pmc_profile.py <pmc dir with pmc_table.json> <kernel_stats.csv of the same workload> [out.json]
 
-Per pass (ssao = depth_pairs_kernel + ssao_kernel, blur = all sweeps, light) and per launch of the 4K bench frame:
+Per pass (ssao = depth_pairs_kernel + zmin_combine_kernel + ssao_kernel, blur = all sweeps, light) and per launch of the 4K bench frame:
   hbm_bytes_per_launch  (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950
                         (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact
   valu_issue_frac       SQ_ACTIVE_INST_VALU * 4 cycles / (1024 SIMDs * kernel cycles at 2.4 GHz)
@@ -51,7 +51,7 @@ def main():
     import bench
     args = type("A", (), {})()
     wl = {"width": 3840, "height": 2160, "blur_count": 4, "lights": 3, "pcf": "literal", "shadow_dim": 4096, "camera": "reference"}
-    passes = {"ssao": [("depth_pairs_kernel", 1), ("ssao_kernel<true, true>", 1)],
+    passes = {"ssao": [("depth_pairs_kernel", 1), ("zmin_combine_kernel", 1), ("ssao_kernel<true, true>", 1)],
               "blur": [("blur_kernel<true, true>", 1), ("blur_kernel<false, true>", 1), ("blur_replay_pair_kernel", wl["blur_count"] - 1)],
               "light": [("light_kernel<true, false>", 1)]}
     kernels = {}
