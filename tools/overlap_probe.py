@@ -2,10 +2,11 @@
 
 Modes, each over the bench's 4K workload:
   whole F     F frame pipelines, every frame one crychic_draw_hot_path call on its own stream (bench.py --frames-in-flight F)
-  split F     every frame = crychic_ssao_compute on a HIGH-priority stream, then crychic_deferred_light on a LOW-priority
-              stream behind an event: the latency-bound SSAO / blur kernels get wave slots first, the VALU-bound
-              lighting pass fills whatever they leave idle
-Prints ms per frame for each.  Usage: python tools/overlap_probe.py [--steps 200]
+  pipeline    every SSAO + blur chain on ONE stream, every lighting pass on ANOTHER, events between them: lighting(n) runs
+              beside chain(n + 1)
+  split F     (--priorities) every frame = crychic_ssao_compute on a HIGH-priority stream, then crychic_deferred_light on a
+              LOW-priority stream behind an event, and the reverse
+Prints ms per frame for each (records: profiles/r02_overlap_probe.txt).  Usage: python tools/overlap_probe.py [--steps 200]
 """
 import argparse
 import ctypes as C
@@ -22,6 +23,7 @@ def main():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--skip-whole", action="store_true")
+    ap.add_argument("--priorities", action="store_true", help="also run the split-stream modes with stream priorities")
     args = ap.parse_args()
     import torch
     from crychic_renderer_amd import build
@@ -97,7 +99,8 @@ def main():
         run("two-stage pipeline, %d slots" % slots, pipe, args.steps)
         for a in apps:
             assert torch.equal(a.mBackBuffer, ref.mBackBuffer), "pipeline differs"
-    return
+    if not args.priorities:
+        return
 
     lo, hi = torch.cuda.Stream.priority_range() if hasattr(torch.cuda.Stream, "priority_range") else (0, -1)
     shadow_ptrs = (C.c_void_p * 4)(*[planes["shadow"][i].data_ptr() for i in range(4)])
@@ -127,10 +130,6 @@ def main():
             run("split F=%d %s" % (F, tag), split, args.steps)
             for a in apps:
                 assert torch.equal(a.mBackBuffer, ref.mBackBuffer), "split pipeline differs"
-
-
-def _unused():
-    pass
 
 
 if __name__ == "__main__":
