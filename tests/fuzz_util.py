@@ -18,6 +18,18 @@ def random_case(seed, built_lib):
     depth = rng.integers(0, 1 << 24, size=(H, W), dtype=np.uint32)
     depth[rng.random((H, W)) < 0.25] = 0xFFFFFF                         # uncovered
     depth[rng.random((H, W)) < 0.05] = 0
+    if rng.random() < 0.35:
+        # a smooth depth field (tilted plane + a little noise) with spikes, holes and sky patches: the SSAO tap culling gets
+        # blocks it can cull and blocks a single texel spoils
+        yy, xx = np.mgrid[0:H, 0:W]
+        lo, hi = sorted(rng.integers(1 << 20, (1 << 24) - 1, 2).tolist())
+        ramp = lo + (hi - lo) * ((yy * float(rng.random()) + xx * float(rng.random())) / float(H + W))
+        depth = (ramp + rng.integers(-40, 41, size=(H, W))).clip(0, 0xFFFFFE).astype(np.uint32)
+        k = int(rng.integers(5, 60))
+        depth[rng.integers(0, H, k), rng.integers(0, W, k)] = rng.integers(0, 1 << 24, k).astype(np.uint32)
+        for _ in range(int(rng.integers(0, 5))):
+            y0, x0 = int(rng.integers(0, H - 8)), int(rng.integers(0, W - 8))
+            depth[y0:y0 + int(rng.integers(1, 9)), x0:x0 + int(rng.integers(1, 9))] = 0xFFFFFF
     depth |= rng.integers(0, 256, size=(H, W), dtype=np.uint32) << 24      # stencil byte must be ignored
     nrm = rng.standard_normal((H, W, 4)).astype(np.float16)
     sel = rng.random((H, W))
