@@ -385,6 +385,8 @@ CRY_HD SsaoCentre ssao_centre(const crychic_ssao_constants& cb, const u2* __rest
 }
 
 // Ssao.hlsl:117-199 for half-res pixel (x, y); returns the R16_UNORM ambient value.  `sparseProjTex` = ssao_projtex_is_sparse(cb).
+// `cull`: NoCull, or the ZminMap of the tap culling.  `culledTaps` (host builds only, may be null): two words -- [0] += the number
+// of taps culled, [1] |= bit i for every culled tap i -- for the tests that check that the culling bites.
 template <class Depth, class Cull = NoCull>
 CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c,
                            const Depth depth, const uint32_t* __restrict__ randvec, uint32_t W,
