@@ -57,8 +57,12 @@ CRY_HD ShadowFetch shadow_fetch(const uint32_t* __restrict__ s, uint32_t dim, fl
 CRY_HD float shadow_resolve(const ShadowFetch& f, uint32_t dim, float ref)
 {
     const Bilin& b = f.b;
-    const bool xa = (uint32_t)b.i0 < dim, xb = (uint32_t)(b.i0 + 1) < dim;
-    const bool y0 = (uint32_t)b.j0 < dim, y1 = (uint32_t)(b.j0 + 1) < dim;
+    bool xa = (uint32_t)b.i0 < dim, xb = (uint32_t)(b.i0 + 1) < dim;
+    bool y0 = (uint32_t)b.j0 < dim, y1 = (uint32_t)(b.j0 + 1) < dim;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // a wavefront whose footprints all lie inside the map (everything but the rim of a cascade) drops the four BORDER selects
+    if (__builtin_amdgcn_ballot_w64(!(xa & xb & y0 & y1)) == 0) xa = xb = y0 = y1 = true;
+#endif
     // the BORDER colour 0 is D24 0: select on the integer texel, then decode unconditionally
     const float t00 = d24_to_float((xa && y0) ? f.p0.a : 0u);
     const float t10 = d24_to_float((xb && y0) ? f.p0.b : 0u);
@@ -262,6 +266,11 @@ CRY_HD AmbientFetch ambient_fetch(const uint16_t* __restrict__ a, uint32_t w2, u
 }
 CRY_HD float ambient_resolve(const AmbientFetch& f)
 {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // a wavefront over unoccluded ground (most of them): four texels of 65535 decode to 1.0 and lerp(1, 1, t) = mad(t, 0, 1) = 1
+    // for the finite weights bilinear_setup returns
+    if (__builtin_amdgcn_ballot_w64((f.t00 & f.t10 & f.t01 & f.t11) != 0xFFFFu) == 0) return 1.0f;
+#endif
     return bilerp(unorm16_to_float(f.t00), unorm16_to_float(f.t10), unorm16_to_float(f.t01), unorm16_to_float(f.t11), f.fx, f.fy);
 }
 CRY_HD float ambient_linear_clamp(const uint16_t* __restrict__ a, uint32_t w2, uint32_t h2, float u, float v)
