@@ -54,14 +54,16 @@ CRY_HD ShadowFetch shadow_fetch(const uint32_t* __restrict__ s, uint32_t dim, fl
     f.p1 = pair_at(s, r1, dim, f.b.i0);
     return f;
 }
+// WAVE_CHECK: let a wavefront whose footprints all lie inside the map (everything but the rim of a cascade) drop the four
+// BORDER selects -- for callers with one lookup at a time; inside the 16-tap loop the branch would separate the taps' loads.
+template <bool WAVE_CHECK = false>
 CRY_HD float shadow_resolve(const ShadowFetch& f, uint32_t dim, float ref)
 {
     const Bilin& b = f.b;
     bool xa = (uint32_t)b.i0 < dim, xb = (uint32_t)(b.i0 + 1) < dim;
     bool y0 = (uint32_t)b.j0 < dim, y1 = (uint32_t)(b.j0 + 1) < dim;
 #if defined(__HIP_DEVICE_COMPILE__)
-    // a wavefront whose footprints all lie inside the map (everything but the rim of a cascade) drops the four BORDER selects
-    if (__builtin_amdgcn_ballot_w64(!(xa & xb & y0 & y1)) == 0) xa = xb = y0 = y1 = true;
+    if (WAVE_CHECK && __builtin_amdgcn_ballot_w64(!(xa & xb & y0 & y1)) == 0) xa = xb = y0 = y1 = true;
 #endif
     // the BORDER colour 0 is D24 0: select on the integer texel, then decode unconditionally
     const float t00 = d24_to_float((xa && y0) ? f.p0.a : 0u);
@@ -359,8 +361,8 @@ CRY_HD bool cascade_fetch_uniform(const LightParams& P, f3 posW, float distance,
 }
 CRY_HD float cascade_resolve_uniform(const LightParams& P, const CascadePair& c)
 {
-    const float a = pcf_zero_radius(shadow_resolve(c.f0, P.shadowDim, c.z0));
-    const float b = pcf_zero_radius(shadow_resolve(c.f1, P.shadowDim, c.z1));
+    const float a = pcf_zero_radius(shadow_resolve<true>(c.f0, P.shadowDim, c.z0));
+    const float b = pcf_zero_radius(shadow_resolve<true>(c.f1, P.shadowDim, c.z1));
     return 0.5f * (a + b);                                      // :66
 }
 
