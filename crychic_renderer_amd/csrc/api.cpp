@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
 #include <utility>
 #include <new>
@@ -12,6 +13,7 @@
 #include "kernels.hpp"
 #include "light_core.hpp"
 #include "ssao_core.hpp"
+#include "blur_tiles.hpp"
 #include "raster_core.hpp"
 #include "internal.hpp"
 
@@ -61,22 +63,19 @@ int bind(crychic_ctx* ctx)
     return 0;
 }
 
-uint32_t next_stamp(crychic_ctx* ctx)
+// Frame stamps mark what the SSAO pass of one frame wrote into the (caller-owned) edge workspace.  They come from one
+// process-wide counter, so two contexts -- or a context re-created over recycled memory -- never issue the same value.
+std::atomic<uint32_t> g_frameStamp{ 0x5EED0000u };
+uint32_t next_stamp()
 {
-    ctx->frameStamp = ctx->frameStamp + 1u ? ctx->frameStamp + 1u : 1u;      // never 0
-    return ctx->frameStamp;
+    uint32_t s;
+    do { s = g_frameStamp.fetch_add(1u, std::memory_order_relaxed) + 1u; } while (s == 0u);      // never 0
+    return s;
 }
 
-void clamp_rows(uint32_t limit, int64_t lo, int64_t hi, uint32_t* row0, uint32_t* rows)
-{
-    if (lo < 0) lo = 0;
-    if (hi > (int64_t)limit) hi = limit;
-    if (hi < lo) hi = lo;
-    *row0 = (uint32_t)lo;
-    *rows = (uint32_t)(hi - lo);
-}
+using cry::clamp_rows;
 
-int ssao_compute_impl(crychic_ctx* ctx, const crychic_ssao_constants* cb, const void* normal, const uint32_t* depth,
+int ssao_compute_impl(const crychic_ssao_constants* cb, const void* normal, const uint32_t* depth,
                       const uint8_t* randvec, uint16_t* ambient0, uint16_t* ambient1, void* edge, uint32_t W,
                       uint32_t H, int blurCount, uint32_t row0, uint32_t rows, hipStream_t stream, hipEvent_t afterSsao)
 {
@@ -84,41 +83,23 @@ int ssao_compute_impl(crychic_ctx* ctx, const crychic_ssao_constants* cb, const 
     if (row0 > h2 || rows > h2 - row0) return fail(CRYCHIC_E_INVALID_ARG, "rows [%u,+%u) outside the %u-row ambient map", row0, rows, h2);
     if (blurCount < 0) return fail(CRYCHIC_E_INVALID_ARG, "blurCount %d < 0", blurCount);
     if (blurCount > 0 && (!ambient1 || !edge)) return fail(CRYCHIC_E_INVALID_ARG, "blurCount > 0 needs ambient1 and the edge workspace");
-    // Vertical sweeps reach 5 rows (gBlurRadius, SsaoBlur.hlsl:48): recompute a halo instead of exchanging it.
+    // rows, planes and launches: blur_tiles.hpp "the launch plan"
     uint32_t r0, rn;
-    clamp_rows(h2, (int64_t)row0 - 5 * blurCount, (int64_t)row0 + rows + 5 * blurCount, &r0, &rn);
+    cry::blur_chain_ssao_rows(blurCount, row0, rows, h2, &r0, &rn);
+    uint16_t* planes[2] = { ambient0, ambient1 };
     // With a workspace at hand the depth plane is re-laid once per frame as decoded pairs (whole plane: the taps of any row
     // reach far up and down the frame) and the taps gather from that; its cost is part of the SSAO pass.
-    const uint32_t stamp = next_stamp(ctx);
+    const uint32_t stamp = next_stamp();
     if (edge) CRY_HIP(cry::launch_depth_pairs(*cb, depth, edge, W, H, stamp, stream));
-    CRY_HIP(cry::launch_ssao(*cb, normal, depth, randvec, ambient0, edge, W, H, r0, rn, true, edge != nullptr, stamp, stream));
+    CRY_HIP(cry::launch_ssao(*cb, normal, depth, randvec, planes[cry::blur_chain_ssao_plane(blurCount)], edge, W, H, r0, rn, true, edge != nullptr,
+                             stamp, stream));
     if (afterSsao) CRY_HIP(hipEventRecord(afterSsao, stream));
-    // Iteration 0 records each direction's tap decisions; iterations 1.. replay them (same geometry, same rows or fewer).
-    // Replay iterations run as one fused H+V launch each (in -> out, out != in).  The result has to end in ambient0
-    // (Ssao.cpp:75-78): an even number of them ping-pongs ambient0 <-> ambient1; an odd number >= 3 routes its last three
-    // steps through the spare plane of the edge workspace (0 -> 1 -> spare -> 0); a single one runs as two sweeps (0 -> 1 -> 0).
-    const int replayIters = blurCount > 1 ? blurCount - 1 : 0;
-    uint16_t* spare = edge ? cry::edge_plane_carve(edge, W, H).spare : nullptr;
-    uint16_t* cur = ambient0;
-    for (int i = 0; i < blurCount; ++i) {
-        uint32_t v0, vn;
-        clamp_rows(h2, (int64_t)row0 - 5 * (blurCount - 1 - i), (int64_t)row0 + rows + 5 * (blurCount - 1 - i), &v0, &vn);
-        if (i >= 1 && replayIters >= 2) {
-            const int left = blurCount - i;                      // fused steps still to run, this one included
-            uint16_t* dst;
-            if (replayIters % 2 == 0 || left > 3) dst = (cur == ambient0) ? ambient1 : ambient0;
-            else dst = left == 3 ? ambient1 : (left == 2 ? spare : ambient0);   // cur is ambient0, ambient1, spare in turn
-            CRY_HIP(cry::launch_blur_replay_pair(*cb, edge, cur, dst, W, H, v0, vn, stream));
-            cur = dst;
-            continue;
-        }
-        clamp_rows(h2, (int64_t)row0 - 5 * (blurCount - i), (int64_t)row0 + rows + 5 * (blurCount - i), &r0, &rn);
-        const cry::BlurMode mode = blurCount == 1 ? cry::BlurMode::Plain : (i == 0 ? cry::BlurMode::Record : cry::BlurMode::Replay);
-        // unoccluded-tile exit of the record sweeps: a pixel's value after the frame's sweeps depends on inputs within 5 pixels
-        // per iteration along each axis
-        const int margin = 5 * blurCount + 2;
-        CRY_HIP(cry::launch_blur(*cb, edge, ambient0, ambient1, W, H, true, mode, r0, rn, stamp, margin, stream));    // Ssao.cpp:240
-        CRY_HIP(cry::launch_blur(*cb, edge, ambient1, ambient0, W, H, false, mode, v0, vn, stamp, margin, stream));   // Ssao.cpp:241
+    for (int i = 0; i < cry::blur_chain_launches(blurCount); ++i) {
+        const cry::BlurStep s = cry::blur_chain_step(blurCount, row0, rows, h2, i);
+        if (s.iterations == 0)      // a pixel's value after the frame's sweeps depends on inputs within 5 pixels per iteration
+            CRY_HIP(cry::launch_blur_pair(*cb, edge, planes[s.in], planes[s.out], W, H, s.row0, s.rows, blurCount > 1, stamp, 5 * blurCount, r0, rn, stream));
+        else
+            CRY_HIP(cry::launch_blur_replay_fused(*cb, edge, planes[s.in], planes[s.out], W, H, s.row0, s.rows, s.iterations, stamp, stream));
     }
     return 0;
 }
@@ -183,7 +164,6 @@ int crychic_ctx_create(int device_ordinal, crychic_ctx** out)
     snprintf(ctx->name, sizeof ctx->name, "%s %s", prop.gcnArchName, prop.name);
     ctx->profiling = false;
     ctx->times_valid = false;
-    ctx->frameStamp = 0x5EED0000u;
     ctx->rasterStatus = nullptr;
     for (auto& ev : ctx->ev) {
         hipError_t ee = hipEventCreate(&ev);
@@ -213,7 +193,7 @@ int crychic_ssao(crychic_ctx* ctx, const crychic_ssao_constants* cb, const void*
     if (int rc = check_dims(W, H)) return rc;
     if (!cb || !normal_dev || !depth_dev || !randvec_dev || !ambient_out_dev) return fail(CRYCHIC_E_INVALID_ARG, "null argument");
     if (row0 > H / 2 || rows > H / 2 - row0) return fail(CRYCHIC_E_INVALID_ARG, "rows [%u,+%u) outside the %u-row ambient map", row0, rows, H / 2);
-    const uint32_t stamp = next_stamp(ctx);
+    const uint32_t stamp = next_stamp();
     if (edge_dev) CRY_HIP(cry::launch_depth_pairs(*cb, depth_dev, edge_dev, W, H, stamp, (hipStream_t)stream));
     CRY_HIP(cry::launch_ssao(*cb, normal_dev, depth_dev, randvec_dev, ambient_out_dev, edge_dev, W, H, row0, rows, true, edge_dev != nullptr,
                              stamp, (hipStream_t)stream));
@@ -241,8 +221,7 @@ int crychic_ssao_blur(crychic_ctx* ctx, const crychic_ssao_constants* cb, const 
     if (!cb || !edge_dev || !ambient_in_dev || !ambient_out_dev) return fail(CRYCHIC_E_INVALID_ARG, "null argument");
     if (ambient_in_dev == ambient_out_dev) return fail(CRYCHIC_E_INVALID_ARG, "blur cannot run in place (the reference ping-pongs, Ssao.cpp:253-266)");
     if (row0 > H / 2 || rows > H / 2 - row0) return fail(CRYCHIC_E_INVALID_ARG, "rows [%u,+%u) outside the %u-row ambient map", row0, rows, H / 2);
-    CRY_HIP(cry::launch_blur(*cb, edge_dev, ambient_in_dev, ambient_out_dev, W, H, horizontal != 0, cry::BlurMode::Plain, row0, rows, 0u, 0,
-                             (hipStream_t)stream));
+    CRY_HIP(cry::launch_blur(*cb, edge_dev, ambient_in_dev, ambient_out_dev, W, H, horizontal != 0, row0, rows, (hipStream_t)stream));
     return 0;
 }
 
@@ -254,7 +233,7 @@ int crychic_ssao_compute(crychic_ctx* ctx, const crychic_ssao_constants* cb, con
     if (int rc = bind(ctx)) return rc;
     if (int rc = check_dims(W, H)) return rc;
     if (!cb || !normal_dev || !depth_dev || !randvec_dev || !ambient0_dev) return fail(CRYCHIC_E_INVALID_ARG, "null argument");
-    return ssao_compute_impl(ctx, cb, normal_dev, depth_dev, randvec_dev, ambient0_dev, ambient1_dev, edge_dev, W, H,
+    return ssao_compute_impl(cb, normal_dev, depth_dev, randvec_dev, ambient0_dev, ambient1_dev, edge_dev, W, H,
                              blurCount, row0, rows, (hipStream_t)stream, nullptr);
 }
 
@@ -328,7 +307,7 @@ int crychic_draw_hot_path(crychic_ctx* ctx, const crychic_ssao_constants* ssaoCB
         // (DeferredShading.hlsl:40-42): rows row0/2 - 1 .. (row0+rows)/2; keep one more row of slack.
         uint32_t a0, an;
         clamp_rows(H / 2, (int64_t)(f->row0 / 2) - 2, (int64_t)((f->row0 + f->rows + 1) / 2) + 2, &a0, &an);
-        if (int rc = ssao_compute_impl(ctx, ssaoCB, f->normal_dev, f->depth_dev, f->randvec_dev, f->ambient0_dev,
+        if (int rc = ssao_compute_impl(ssaoCB, f->normal_dev, f->depth_dev, f->randvec_dev, f->ambient0_dev,
                                        f->ambient1_dev, f->edge_dev, W, H, f->blurCount, a0, an, stream,
                                        prof ? ctx->ev[1] : nullptr)) return rc;
     } else if (prof) {

@@ -10,7 +10,6 @@ struct crychic_ctx {
     bool times_valid;
     hipEvent_t ev[4];  // start, after ssao, after blur, after light
     const uint32_t* rasterStatus;   // device status word of the most recent producer pass (crychic_raster_status)
-    uint32_t frameStamp;   // stamps the coarse geometry map of the SSAO pass: a new value per depth-pairs build, never 0
 };
 
 namespace cry {

@@ -6,6 +6,7 @@
 #include <hip/hip_runtime.h>
 #include "kernels.hpp"
 #include "ssao_core.hpp"
+#include "blur_tiles.hpp"
 #include "light_core.hpp"
 
 namespace cry {
@@ -60,57 +61,83 @@ __device__ __forceinline__ void tile_origin_2d(uint32_t& bx, uint32_t& by, uint3
 }
 
 // ---- SSAO ------------------------------------------------------------------------------------------------
-// Re-lays the D24 depth plane as decoded {d(x, y), d(x, y+1)} entries with a BORDER guard band (ssao_core.hpp "depth pairs"):
-// one lane per two horizontally adjacent entries (a 16-byte store), rows y = -2 .. H, entries x = -2 .. W+1; a workgroup
-// covers 8 rows (two per wave) x 128 entries = 16 blocks of 8 x 8 padded texels.
-// By-products: the coarse geometry map of the sky shortcut and the nearest-depth map of the tap culling (ssao_core.hpp).
-// A wave covers texel columns [128 blockIdx.x - 2, 128 blockIdx.x + 126) of its rows (through the .x / .z components of its
-// entries); if any texel of a row lies below the clear depth it stamps the cell (blockIdx.x, y / 32) with this frame's stamp --
-// a plain store: every writer of a cell stores the same value, and a stale or uninitialised word can only read as "geometry"
-// (no shortcut), never as "sky".  The block minima go through a 4-lane shuffle and LDS; positions outside the padded plane
-// count as the clear depth, which is what a footprint reaching them reads.
+// Re-lays the D24 depth plane as decoded {d(x, y), d(x, y+1)} entries with a BORDER guard band (ssao_core.hpp "depth pairs").
+// One wavefront per 8 entry rows x 128 entry columns: a lane owns two horizontally adjacent entries of each of the 8 rows (one
+// 16-byte store per row) and reads the 9 texel rows they are built from once (one 8-byte load per row).  Entry rows are
+// py = 8 cy .. 8 cy + 7 of cell row cy (texel rows py - 2 .. py - 1), entry columns 128 seg .. 128 seg + 127 of segment seg.
+// By-products, both without LDS or barriers:
+//   * the nearest-depth map of the tap culling: cell (cx, cy) = smallest decoded texel of padded texels [8 cx, 8 cx + 8] x
+//     [8 cy, 8 cy + 8] -- the 9 rows a lane holds, over the 4 lanes of the cell plus the first column of the next lane (the last
+//     cell of a wavefront takes that column from one extra load); positions outside the plane count as the clear depth, which
+//     is what a footprint reaching them reads;
+//   * the coarse geometry map of the sky shortcut: a wavefront covers texel columns [128 seg - 2, 128 seg + 126) of its rows; if
+//     any texel of rows belonging to cell row c lies below the clear depth it stamps cell (seg, c) with this frame's stamp -- a
+//     plain store: every writer of a cell stores the same value, and a stale or uninitialised word can only read as "geometry"
+//     (no shortcut), never as "sky".
 __global__ __launch_bounds__(256) void depth_pairs_kernel(const uint32_t* __restrict__ depth, f4a* __restrict__ pairs, uint32_t* __restrict__ geo,
-                                                          float* __restrict__ zmin, uint32_t stamp, uint32_t W, uint32_t H, CullParams cull)
+                                                          float* __restrict__ zcull, uint32_t stamp, uint32_t W, uint32_t H, CullParams cull,
+                                                          uint32_t cellRow0)
 {
-    __shared__ float s_min[4][16];
     const uint32_t halfPitch = depth_pairs_pitch(W) / 2u;
-    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint32_t px2 = blockIdx.x * 64u + lane;
-    float m = 1.0f;
+    const uint32_t lane = threadIdx.x & 63u, seg = blockIdx.x * 4u + (threadIdx.x >> 6);
+    if (seg * 64u >= halfPitch) return;                          // wave-uniform
+    const uint32_t px2 = seg * 64u + lane, cy = cellRow0 + blockIdx.y;
+    const int x = 2 * (int)px2 - 2, y0 = 8 * (int)cy - 2;         // first texel column of the lane, first texel row of the wave
+    const bool inx = (uint32_t)x < W;                             // W even, x even: x + 1 < W as well
+    const uint32_t cx = inx ? (uint32_t)x : 0u;
+    float r0[9], r1[9];
 #pragma unroll
-    for (uint32_t r = 0; r < 2u; ++r) {
-        const uint32_t py = blockIdx.y * 8u + wave * 2u + r;
-        bool geometry = false;
-        if (py < H + 3u && px2 < halfPitch) {
-            const f4a e = depth_pairs_entry2(depth, W, H, 2 * (int)px2 - 2, (int)py - 2);
-            pairs[py * halfPitch + px2] = e;
-            geometry = (e.x != 1.0f) | (e.z != 1.0f);              // texels (x, y), (x + 1, y): BORDER and clear-depth texels decode to 1.0
-            m = __builtin_fminf(m, __builtin_fminf(e.x, e.z));
-        }
-        const uint32_t y = py - 2u;
-        if (__builtin_amdgcn_ballot_w64(geometry) != 0 && lane == 0 && y < H)
-            geo[(y >> 5) * geo_map_cols(W) + blockIdx.x] = stamp;
+    for (int k = 0; k < 9; ++k) {
+        const int y = y0 + k;
+        RawPair t{ 0x00FFFFFFu, 0x00FFFFFFu };
+        if (inx && (uint32_t)y < H) t = load_at<RawPair>(depth, (mul24((uint32_t)y, W) + cx) * 4u);
+        r0[k] = d24_to_float(t.lo);
+        r1[k] = d24_to_float(t.hi);
     }
-    // 8 padded texel columns = 4 lanes
+    const bool live = px2 < halfPitch;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t py = 8u * cy + (uint32_t)k;
+        if (live && py < H + 3u) pairs[py * halfPitch + px2] = f4a{ r0[k], r0[k + 1], r1[k], r1[k + 1] };
+    }
+    // coarse geometry map: rows y0 .. y0 + 7 (row y0 + 8 is the next cell row's first) fall into at most two 32-row cells
+    const int yFirst = y0 < 0 ? 0 : y0;
+    const uint32_t c0 = (uint32_t)yFirst >> 5;
+    bool geoA = false, geoB = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const int y = y0 + k;
+        const bool g = (r0[k] != 1.0f) | (r1[k] != 1.0f);          // BORDER and clear-depth texels decode to 1.0
+        if ((uint32_t)y < H) { if (((uint32_t)y >> 5) == c0) geoA |= g; else geoB |= g; }
+    }
+    const bool anyA = __builtin_amdgcn_ballot_w64(geoA) != 0, anyB = __builtin_amdgcn_ballot_w64(geoB) != 0;
+    if (lane == 0) {
+        if (anyA) geo[c0 * geo_map_cols(W) + seg] = stamp;
+        if (anyB) geo[(c0 + 1u) * geo_map_cols(W) + seg] = stamp;
+    }
+    // nearest-depth map
+    float mFirst = r0[0], mSecond = r1[0];
+#pragma unroll
+    for (int k = 1; k < 9; ++k) { mFirst = __builtin_fminf(mFirst, r0[k]); mSecond = __builtin_fminf(mSecond, r1[k]); }
+    float m = __builtin_fminf(mFirst, mSecond);
     m = __builtin_fminf(m, __shfl_xor(m, 1));
-    m = __builtin_fminf(m, __shfl_xor(m, 2));
-    if ((lane & 3u) == 0) s_min[wave][lane >> 2] = m;
-    __syncthreads();
-    if (threadIdx.x < 16u) {
-        const uint32_t cx = blockIdx.x * 16u + threadIdx.x;
-        if (cx < zmin_map_cols(W) && blockIdx.y < zmin_map_rows(H)) {
-            const float mm = __builtin_fminf(__builtin_fminf(s_min[0][threadIdx.x], s_min[1][threadIdx.x]),
-                                             __builtin_fminf(s_min[2][threadIdx.x], s_min[3][threadIdx.x]));
-            zmin[blockIdx.y * zmin_map_cols(W) + cx] = zmin_cell_value(cull.A, cull.B, mm);
-        }
+    m = __builtin_fminf(m, __shfl_xor(m, 2));                       // the cell's own 8 columns
+    float next = __shfl(mFirst, (int)((lane | 3u) + 1u) & 63);      // first column of the next cell (lanes 60..63: replaced below)
+    {
+        // column 128 seg + 126 (texel), rows y0 .. y0 + 8: lanes 0 .. 8 load one texel each
+        const int xe = 128 * (int)seg + 126, ye = y0 + (int)lane;
+        float v = 1.0f;
+        if (lane < 9u && (uint32_t)xe < W && (uint32_t)ye < H) v = d24_to_float(load_at<uint32_t>(depth, (mul24((uint32_t)ye, W) + (uint32_t)xe) * 4u));
+        v = __builtin_fminf(v, __shfl_xor(v, 1));
+        v = __builtin_fminf(v, __shfl_xor(v, 2));
+        v = __builtin_fminf(v, __shfl_xor(v, 4));
+        v = __builtin_fminf(v, __shfl_xor(v, 8));
+        v = __shfl(v, 0);
+        if (lane >= 60u) next = v;
     }
-}
-
-// The lookup map of the tap culling: per block position the smallest of the 2 x 2 block values starting there.
-__global__ __launch_bounds__(256) void zmin_combine_kernel(const float* __restrict__ zmin, float* __restrict__ zcull, uint32_t cols, uint32_t rows)
-{
-    const uint32_t cx = blockIdx.x * 64u + (threadIdx.x & 63u), cy = blockIdx.y * 4u + (threadIdx.x >> 6);
-    if (cx < cols && cy < rows) zcull[cy * cols + cx] = zmin_combine(zmin, cols, rows, cx, cy);
+    m = __builtin_fminf(m, next);
+    const uint32_t cellX = seg * 16u + (lane >> 2);
+    if ((lane & 3u) == 0 && cellX < zmin_map_cols(W)) zcull[cy * zmin_map_cols(W) + cellX] = zmin_cell_value(cull.A, cull.B, m);
 }
 
 // Shaders/Ssao.hlsl:117-199 over half-res rows [row0, row1).  EMIT_AO = false builds only the edge workspace.
@@ -162,22 +189,26 @@ __global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, co
         else if (PAIRS) v = ssao_pixel(cb, c, dp, randvec, W, H, x, y, sparseProjTex != 0);
         else v = ssao_pixel(cb, c, dd, randvec, W, H, x, y, sparseProjTex != 0);
         ambient[y * w2 + x] = (uint16_t)v;
-        // unoccluded-wavefront map (ssao_core.hpp "unoccluded tiles"): lane 0 is live whenever the wave is (x = 64 bx < w2)
-        if (PAIRS && stamp != 0u && __builtin_amdgcn_ballot_w64(v != 0xFFFFu) == 0 && (threadIdx.x & 63u) == 0)
-            edge.ones[y * ones_map_cols(W) + bx] = stamp;
+        // unoccluded-wavefront map (ssao_core.hpp "unoccluded tiles"): lane 0 is live whenever the wave is (x = 64 bx < w2).  The
+        // word is written by EVERY wavefront that emits ambient values -- the stamp or 0 -- so no word of a row computed this
+        // frame is ever stale.
+        if (PAIRS && stamp != 0u) {
+            const bool allOnes = __builtin_amdgcn_ballot_w64(v != 0xFFFFu) == 0;
+            if ((threadIdx.x & 63u) == 0) edge.ones[y * ones_map_cols(W) + bx] = allOnes ? stamp : 0u;
+        }
     }
 }
 
 // ---- bilateral blur ------------------------------------------------------------------------------------------
-// Shaders/SsaoBlur.hlsl:85-146, one sweep.  A 64 x 16 output tile plus its 5-pixel apron along the sweep axis is
-// staged once in LDS as pre-decoded floats (normal.xyz + linear depth as one 16-byte entry, ambient as one dword), so
-// the 11-tap window of every pixel is served by one ds_read_b128 + one ds_read_b32 per tap instead of 3 global
-// fetches + 4 format conversions.  Consecutive lanes read consecutive 16-byte entries (conflict-free for both
-// directions: the horizontal window slides along a staged row, the vertical one hops whole rows).
-template <bool HORZ, bool RECORD>
+// Shaders/SsaoBlur.hlsl:85-146, one self-contained sweep (crychic_ssao_blur == Ssao::BlurAmbientMap(cmdList, bool), Ssao.cpp:245-293).
+// A 64 x 16 output tile plus its 5-pixel apron along the sweep axis is staged once in LDS as pre-decoded floats (normal.xyz +
+// linear depth as one 16-byte entry, ambient as one dword), so the 11-tap window of every pixel is served by one ds_read_b128 +
+// one ds_read_b32 per tap instead of 3 global fetches + 4 format conversions.  Consecutive lanes read consecutive 16-byte
+// entries (conflict-free for both directions: the horizontal window slides along a staged row, the vertical one hops whole rows).
+template <bool HORZ>
 __global__ __launch_bounds__(256) void blur_kernel(crychic_ssao_constants cb, EdgePlane edge,
                                                    const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
-                                                   uint32_t W, uint32_t H, uint32_t row0, uint32_t row1, uint32_t stamp, int onesMargin)
+                                                   uint32_t W, uint32_t H, uint32_t row0, uint32_t row1)
 {
     constexpr int BW = 64, BH = 16, R = 5;
     constexpr int SW = HORZ ? BW + 2 * R : BW;
@@ -189,34 +220,6 @@ __global__ __launch_bounds__(256) void blur_kernel(crychic_ssao_constants cb, Ed
     uint32_t bx, by;
     tile_origin<4>(bx, by);
     const int x0 = (int)bx * BW, y0 = (int)row0 + (int)by * BH;
-    if (RECORD && stamp != 0u) {
-        // Unoccluded tile (ssao_core.hpp): every wavefront of the SSAO pass within reach of this frame's sweeps wrote 65535
-        const OnesRegion g = blur_ones_region((uint32_t)w2, (uint32_t)h2, x0, y0, BW, BH, onesMargin);
-        const uint32_t ncol = g.c1 - g.c0 + 1u, ncell = ncol * (g.r1 - g.r0 + 1u), pitch = ones_map_cols(W);
-        bool occluded = false;
-        for (uint32_t k = threadIdx.x; k < ncell; k += 256u) {
-            const uint32_t r = k / ncol, c = k - r * ncol;
-            occluded |= edge.ones[(g.r0 + r) * pitch + g.c0 + c] != stamp;
-        }
-        if (!__syncthreads_or(occluded)) {
-            // The recorded decision is "centre tap only": a neighbouring tile that replays these pixels (the fused replay sweeps
-            // recompute their apron rows) then gets w5 * 1 * rcp(w5) -> 65535, the value every other decision would give too.
-            const int tx = (int)(threadIdx.x & 63u), tyb = (int)(threadIdx.x >> 6), x = x0 + tx;
-            uint16_t* __restrict__ mask_o = HORZ ? edge.mask_h : edge.mask_v;
-            float* __restrict__ total_o = HORZ ? edge.total_h : edge.total_v;
-#pragma unroll
-            for (int j = 0; j < BH / 4; ++j) {
-                const int y = y0 + tyb + 4 * j;
-                if (x < w2 && y < (int)row1) {
-                    const uint32_t p = (uint32_t)y * (uint32_t)w2 + (uint32_t)x;
-                    out[p] = (uint16_t)0xFFFFu;
-                    mask_o[p] = (uint16_t)(1u << 5);
-                    total_o[p] = cb.BlurWeights[1][1];      // w[5]
-                }
-            }
-            return;
-        }
-    }
     const int sx0 = HORZ ? x0 - R : x0, sy0 = HORZ ? y0 : y0 - R;
     const float borderZ = ndc_to_view(cb, 1.0f);
 
@@ -230,158 +233,76 @@ __global__ __launch_bounds__(256) void blur_kernel(crychic_ssao_constants cb, Ed
 
     const int tx = (int)(threadIdx.x & 63u), tyb = (int)(threadIdx.x >> 6);
     const int x = x0 + tx;
-    uint16_t* __restrict__ mask_out = HORZ ? edge.mask_h : edge.mask_v;
-    float* __restrict__ total_out = HORZ ? edge.total_h : edge.total_v;
 #pragma unroll
     for (int j = 0; j < BH / 4; ++j) {
         const int ty = tyb + 4 * j;
         const int y = y0 + ty;
         if (x < w2 && y < (int)row1) {
-            const BlurOut o = blur_pixel_full(&cb.BlurWeights[0][0], [&](int i) {
+            const uint32_t v = blur_pixel(&cb.BlurWeights[0][0], [&](int i) {
                 const int idx = HORZ ? ty * SW + tx + i : (ty + i) * SW + tx;
                 const f4a q = s_nz[idx];
                 return BlurTap{ f3{ q.x, q.y, q.z }, q.w, s_a[idx] };
             });
-            const uint32_t p = (uint32_t)y * (uint32_t)w2 + (uint32_t)x;
-            out[p] = (uint16_t)o.value;
-            if (RECORD) { mask_out[p] = (uint16_t)o.mask; total_out[p] = o.total; }
-        }
-    }
-}
-
-// A later sweep of the same direction: the per-tap decisions and totalWeight recorded by the RECORD sweep are
-// replayed, so only the ambient tile (+ apron) is staged and each tap costs one LDS read, one multiply-add and a
-// select.  Bit-identical to blur_kernel (same float operations in the same order).
-template <bool HORZ>
-__global__ __launch_bounds__(256) void blur_replay_kernel(crychic_ssao_constants cb, EdgePlane edge,
-                                                          const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
-                                                          uint32_t W, uint32_t H, uint32_t row0, uint32_t row1, int onesShortcut)
-{
-    constexpr int BW = 64, BH = 16, R = 5;
-    constexpr int SW = HORZ ? BW + 2 * R : BW;
-    constexpr int SH = HORZ ? BH : BH + 2 * R;
-    __shared__ float s_a[SW * SH];
-
-    const int w2 = (int)(W / 2), h2 = (int)(H / 2);
-    uint32_t bx, by;
-    tile_origin<4>(bx, by);
-    const int x0 = (int)bx * BW, y0 = (int)row0 + (int)by * BH;
-    const int sx0 = HORZ ? x0 - R : x0, sy0 = HORZ ? y0 : y0 - R;
-    const int tx = (int)(threadIdx.x & 63u), tyb = (int)(threadIdx.x >> 6);
-    const int x = x0 + tx;
-    const uint16_t* __restrict__ mask_in = HORZ ? edge.mask_h : edge.mask_v;
-    const float* __restrict__ total_in = HORZ ? edge.total_h : edge.total_v;
-    bool allOne = onesShortcut != 0;
-    for (int k = (int)threadIdx.x; k < SW * SH; k += 256) {
-        const int ly = k / SW, lx = k - ly * SW;
-        const int cx = clampi(sx0 + lx, 0, w2 - 1), cy = clampi(sy0 + ly, 0, h2 - 1);   // ambient: point / CLAMP
-        const uint32_t raw = in[(uint32_t)cy * (uint32_t)w2 + (uint32_t)cx];
-        allOne = allOne && raw == 0xFFFFu;
-        s_a[k] = unorm16_to_float(raw);
-    }
-    // A window whose ambient values are all 1.0 blurs to exactly 1.0 whatever the recorded decisions are: the colour sum adds
-    // the very weights the recorded total was built from, in the same order, so colour == total bit for bit and x / x = 1
-    // for the finite positive totals that finite positive weights give (blur_weights_positive(), checked by the launcher).
-    // Most of the frame (sky, unoccluded surfaces) is like that; the whole tile then skips masks, taps and divisions.
-    if (__syncthreads_and(allOne)) {
-#pragma unroll
-        for (int j = 0; j < BH / 4; ++j) {
-            const int y = y0 + tyb + 4 * j;
-            if (x < w2 && y < (int)row1) out[(uint32_t)y * (uint32_t)w2 + (uint32_t)x] = (uint16_t)0xFFFFu;
-        }
-        return;
-    }
-    uint32_t m[BH / 4];
-    float tot[BH / 4];
-#pragma unroll
-    for (int j = 0; j < BH / 4; ++j) {
-        const int y = y0 + tyb + 4 * j;
-        const bool live = (x < w2) && (y < (int)row1);
-        const uint32_t p = live ? (uint32_t)y * (uint32_t)w2 + (uint32_t)x : 0u;
-        m[j] = mask_in[p];
-        tot[j] = total_in[p];
-    }
-
-#pragma unroll
-    for (int j = 0; j < BH / 4; ++j) {
-        const int ty = tyb + 4 * j;
-        const int y = y0 + ty;
-        if (x < w2 && y < (int)row1) {
-            const uint32_t v = blur_pixel_replay(&cb.BlurWeights[0][0], m[j], tot[j], [&](int i) {
-                return s_a[HORZ ? ty * SW + tx + i : (ty + i) * SW + tx];
-            });
             out[(uint32_t)y * (uint32_t)w2 + (uint32_t)x] = (uint16_t)v;
         }
     }
 }
 
-// One whole replay iteration (horizontal then vertical sweep, SsaoBlur ping-pong 0 -> 1 -> 0 of Ssao.cpp:240-241) in one
-// launch: the horizontal results of the tile's rows plus a 5-row apron stay in LDS -- quantised to R16_UNORM and decoded
-// again exactly as the round trip through the ambient map does -- and feed the vertical sweep.  Bit-identical to
-// blur_replay_kernel<true> followed by blur_replay_kernel<false>; `out` must not alias `in`.
-__global__ __launch_bounds__(256) void blur_replay_pair_kernel(crychic_ssao_constants cb, EdgePlane edge,
-                                                               const uint16_t* __restrict__ in, uint16_t* __restrict__ out,
-                                                               uint32_t W, uint32_t H, uint32_t row0, uint32_t row1, int onesShortcut)
-{
-    constexpr int BW = 64, BH = 16, R = 5;
-    constexpr int SW = BW + 2 * R, SH = BH + 2 * R;
-    __shared__ float s_in[SW * SH];
-    __shared__ float s_mid[BW * SH];
+// The workgroup behind the tile bodies of blur_tiles.hpp.
+struct BlockDev {
+    __device__ int tid() const { return (int)threadIdx.x; }
+    __device__ int size() const { return (int)blockDim.x; }
+    __device__ void sync() const { __syncthreads(); }
+    __device__ bool all(bool p) const { return __syncthreads_and(p) != 0; }
+    __device__ bool any(bool p) const { return __syncthreads_or(p) != 0; }
+};
 
-    const int w2 = (int)(W / 2), h2 = (int)(H / 2);
+// Tiles of the blur launches lie on an absolute 64 x 16 grid of the half-res map (so that the flags one launch leaves per tile
+// mean the same tile to the next); a launch covers the tile rows that intersect its rows [row0, row1).
+__device__ __forceinline__ BlurTileArgs blur_tile_args(const crychic_ssao_constants& cb, const EdgePlane& edge, const uint16_t* in, uint16_t* out,
+                                                       uint32_t W, uint32_t H, uint32_t row0, uint32_t row1)
+{
     uint32_t bx, by;
     tile_origin<4>(bx, by);
-    const int x0 = (int)bx * BW, y0 = (int)row0 + (int)by * BH;
-    const int tx = (int)(threadIdx.x & 63u), tyb = (int)(threadIdx.x >> 6);
-    const int x = x0 + tx;
-    bool allOne = onesShortcut != 0;
-    for (int k = (int)threadIdx.x; k < SW * SH; k += 256) {
-        const int ly = k / SW, lx = k - ly * SW;
-        const int cx = clampi(x0 - R + lx, 0, w2 - 1), cy = clampi(y0 - R + ly, 0, h2 - 1);   // ambient: point / CLAMP
-        const uint32_t raw = in[(uint32_t)cy * (uint32_t)w2 + (uint32_t)cx];
-        allOne = allOne && raw == 0xFFFFu;
-        s_in[k] = unorm16_to_float(raw);
-    }
-    if (__syncthreads_and(allOne)) {        // all-ones window: both sweeps return exactly 1.0 (see blur_replay_kernel)
-#pragma unroll
-        for (int j = 0; j < BH / 4; ++j) {
-            const int y = y0 + tyb + 4 * j;
-            if (x < w2 && y < (int)row1) out[(uint32_t)y * (uint32_t)w2 + (uint32_t)x] = (uint16_t)0xFFFFu;
-        }
-        return;
-    }
-    // the vertical sweep's recorded decisions of this thread's four outputs
-    uint32_t m[BH / 4];
-    float tot[BH / 4];
-#pragma unroll
-    for (int j = 0; j < BH / 4; ++j) {
-        const int y = y0 + tyb + 4 * j;
-        const bool live = (x < w2) && (y < (int)row1);
-        const uint32_t p = live ? (uint32_t)y * (uint32_t)w2 + (uint32_t)x : 0u;
-        m[j] = edge.mask_v[p];
-        tot[j] = edge.total_v[p];
-    }
-    // horizontal sweep of rows y0-5 .. y0+BH+4 (CLAMPed: a vertical tap above / below the map reads the edge row's result)
-    for (int k = (int)threadIdx.x; k < BW * SH; k += 256) {
-        const int ly = k >> 6, lx = k & 63;
-        const int cy = clampi(y0 - R + ly, 0, h2 - 1), cx = x0 + lx;
-        if (cx < w2) {
-            const uint32_t p = (uint32_t)cy * (uint32_t)w2 + (uint32_t)cx;
-            const uint32_t v = blur_pixel_replay(&cb.BlurWeights[0][0], edge.mask_h[p], edge.total_h[p],
-                                                 [&](int i) { return s_in[ly * SW + lx + i]; });
-            s_mid[k] = unorm16_to_float(v);
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < BH / 4; ++j) {
-        const int ty = tyb + 4 * j;
-        const int y = y0 + ty;
-        if (x < w2 && y < (int)row1) {
-            const uint32_t v = blur_pixel_replay(&cb.BlurWeights[0][0], m[j], tot[j], [&](int i) { return s_mid[(ty + i) * BW + tx]; });
-            out[(uint32_t)y * (uint32_t)w2 + (uint32_t)x] = (uint16_t)v;
-        }
-    }
+    by += row0 / (uint32_t)kBlurTileH;
+    BlurTileArgs a;
+    a.w = &cb.BlurWeights[0][0];
+    a.e = edge;
+    a.in = in;
+    a.out = out;
+    a.w2 = (int)(W / 2);
+    a.h2 = (int)(H / 2);
+    a.x0 = (int)bx * kBlurTileW;
+    a.y0 = (int)by * kBlurTileH;
+    a.row0 = (int)row0;
+    a.row1 = (int)row1;
+    a.borderZ = ndc_to_view(cb, 1.0f);
+    a.tileIndex = by * blur_tiles_x(W) + bx;
+    return a;
+}
+
+// Iteration 0 of the blur: horizontal + vertical sweep of a tile in one launch (blur_tiles.hpp blur_pair_tile).
+template <bool RECORD>
+__global__ __launch_bounds__(256) void blur_pair_kernel(crychic_ssao_constants cb, EdgePlane edge, const uint16_t* __restrict__ in,
+                                                        uint16_t* __restrict__ out, uint32_t W, uint32_t H, uint32_t row0, uint32_t row1,
+                                                        uint32_t stamp, int onesMargin, int ssaoRow0, int ssaoRow1)
+{
+    __shared__ f4a s_nz[kBlurPairSW * kBlurPairSH];
+    __shared__ float s_a[kBlurPairSW * kBlurPairSH];
+    __shared__ float s_mid[kBlurTileW * kBlurPairSH];
+    const BlurTileArgs a = blur_tile_args(cb, edge, in, out, W, H, row0, row1);
+    blur_pair_tile<RECORD>(BlockDev{}, a, stamp, onesMargin, ssaoRow0, ssaoRow1, s_nz, s_a, s_mid);
+}
+
+// Iterations 1 .. k of the blur in one launch (blur_tiles.hpp blur_replay_fused_tile).
+__global__ __launch_bounds__(512) void blur_replay_fused_kernel(crychic_ssao_constants cb, EdgePlane edge, const uint16_t* __restrict__ in,
+                                                                uint16_t* __restrict__ out, uint32_t W, uint32_t H, uint32_t row0, uint32_t row1,
+                                                                int k, uint32_t stamp, int onesShortcut)
+{
+    __shared__ float s0[kBlurFusedMaxW * kBlurFusedMaxH];
+    __shared__ float s1[kBlurFusedMaxW * kBlurFusedMaxH];
+    const BlurTileArgs a = blur_tile_args(cb, edge, in, out, W, H, row0, row1);
+    blur_replay_fused_tile(BlockDev{}, a, k, stamp, onesShortcut != 0, s0, s1);
 }
 
 // ---- deferred lighting -----------------------------------------------------------------------------------------
@@ -503,15 +424,6 @@ __global__ __launch_bounds__(256) void light_points_kernel(LightParams P, const 
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------
-// All 11 blur weights finite and in (0, 1e30): every total the record sweep can produce is then finite and positive.
-static bool blur_weights_positive(const crychic_ssao_constants& cb)
-{
-    const float* w = &cb.BlurWeights[0][0];
-    for (int i = 0; i < 11; ++i)
-        if (!(w[i] > 0.0f && w[i] < 1.0e30f)) return false;
-    return true;
-}
-
 static inline dim3 grid_for(uint32_t width, uint32_t rows, uint32_t rows_per_block = 4u)
 {
     return dim3((width + 63u) / 64u, (rows + rows_per_block - 1u) / rows_per_block, 1);
@@ -521,14 +433,11 @@ hipError_t launch_depth_pairs(const crychic_ssao_constants& cb, const uint32_t* 
                               hipStream_t stream)
 {
     const EdgePlane e = edge_plane_carve(edge_base, W, H);
-    // grid.x == geo_map_cols(W); 16 cells of the nearest-depth map per workgroup in x, one cell row in y
-    const dim3 grid((depth_pairs_pitch(W) / 2u + 63u) / 64u, zmin_map_rows(H), 1);
-    const CullParams cull = ssao_cull_params(cb);
-    hipLaunchKernelGGL(depth_pairs_kernel, grid, dim3(256), 0, stream, depth, (f4a*)const_cast<void*>(e.pairs), e.geo, e.zmin, stamp, W, H, cull);
-    if (cull.enabled) {
-        const uint32_t cols = zmin_map_cols(W), rows = zmin_map_rows(H);
-        hipLaunchKernelGGL(zmin_combine_kernel, dim3((cols + 63u) / 64u, (rows + 3u) / 4u, 1), dim3(256), 0, stream, e.zmin, e.zcull, cols, rows);
-    }
+    // a wavefront per 128 entry columns x 8 entry rows (= one row of 16 cells of the nearest-depth map), four wavefronts per workgroup
+    const uint32_t segs = (depth_pairs_pitch(W) / 2u + 63u) / 64u;
+    const dim3 grid((segs + 3u) / 4u, zmin_map_rows(H), 1);
+    hipLaunchKernelGGL(depth_pairs_kernel, grid, dim3(256), 0, stream, depth, (f4a*)const_cast<void*>(e.pairs), e.geo, e.zcull, stamp, W, H,
+                       ssao_cull_params(cb), 0u);
     return hipGetLastError();
 }
 
@@ -563,35 +472,49 @@ hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, con
 }
 
 hipError_t launch_blur(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out,
-                       uint32_t W, uint32_t H, bool horizontal, BlurMode mode, uint32_t row0, uint32_t rows,
-                       uint32_t stamp, int onesMargin, hipStream_t stream)
+                       uint32_t W, uint32_t H, bool horizontal, uint32_t row0, uint32_t rows, hipStream_t stream)
 {
     if (rows == 0) return hipSuccess;
     const EdgePlane e = edge_plane_carve(const_cast<void*>(edge_base), W, H);
     const dim3 grid = grid_for(W / 2, rows, 16u);
-    // the unoccluded-tile exit needs finite positive weights (x * rcp(x) of a finite positive total) and the SSAO pass's map
-    if (mode != BlurMode::Record || !blur_weights_positive(cb)) stamp = 0u;
-#define CRY_LAUNCH_BLUR(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, cb, e, in, out, W, H, row0, row0 + rows, stamp, onesMargin)
-    if (mode == BlurMode::Replay) {
-        const int ones = blur_weights_positive(cb) ? 1 : 0;
-        if (horizontal) hipLaunchKernelGGL(blur_replay_kernel<true>, grid, dim3(256), 0, stream, cb, e, in, out, W, H, row0, row0 + rows, ones);
-        else hipLaunchKernelGGL(blur_replay_kernel<false>, grid, dim3(256), 0, stream, cb, e, in, out, W, H, row0, row0 + rows, ones);
-    } else if (mode == BlurMode::Record) {
-        if (horizontal) CRY_LAUNCH_BLUR((blur_kernel<true, true>)); else CRY_LAUNCH_BLUR((blur_kernel<false, true>));
-    } else {
-        if (horizontal) CRY_LAUNCH_BLUR((blur_kernel<true, false>)); else CRY_LAUNCH_BLUR((blur_kernel<false, false>));
-    }
-#undef CRY_LAUNCH_BLUR
+    if (horizontal) hipLaunchKernelGGL(blur_kernel<true>, grid, dim3(256), 0, stream, cb, e, in, out, W, H, row0, row0 + rows);
+    else hipLaunchKernelGGL(blur_kernel<false>, grid, dim3(256), 0, stream, cb, e, in, out, W, H, row0, row0 + rows);
     return hipGetLastError();
 }
 
-hipError_t launch_blur_replay_pair(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out,
-                                   uint32_t W, uint32_t H, uint32_t row0, uint32_t rows, hipStream_t stream)
+// tile rows of the absolute 64 x 16 grid that intersect half-res rows [row0, row0 + rows)
+static inline dim3 blur_tile_grid(uint32_t W, uint32_t row0, uint32_t rows)
+{
+    const uint32_t t0 = row0 / (uint32_t)kBlurTileH, t1 = (row0 + rows - 1u) / (uint32_t)kBlurTileH;
+    return dim3(blur_tiles_x(W), t1 - t0 + 1u, 1);
+}
+
+hipError_t launch_blur_pair(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out, uint32_t W, uint32_t H,
+                            uint32_t row0, uint32_t rows, bool record, uint32_t stamp, int onesMargin, uint32_t ssaoRow0, uint32_t ssaoRows,
+                            hipStream_t stream)
 {
     if (rows == 0) return hipSuccess;
     const EdgePlane e = edge_plane_carve(const_cast<void*>(edge_base), W, H);
-    hipLaunchKernelGGL(blur_replay_pair_kernel, grid_for(W / 2, rows, 16u), dim3(256), 0, stream, cb, e, in, out, W, H, row0, row0 + rows,
-                       blur_weights_positive(cb) ? 1 : 0);
+    // the unoccluded-tile exit needs finite positive weights (x * rcp(x) of a finite positive total) and the SSAO pass's map
+    if (!blur_weights_positive(cb)) stamp = 0u;
+    const dim3 grid = blur_tile_grid(W, row0, rows);
+#define CRY_LAUNCH_PAIR(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, cb, e, in, out, W, H, row0, row0 + rows, stamp, onesMargin, \
+                                              (int)ssaoRow0, (int)(ssaoRow0 + ssaoRows))
+    if (record) CRY_LAUNCH_PAIR(blur_pair_kernel<true>); else CRY_LAUNCH_PAIR(blur_pair_kernel<false>);
+#undef CRY_LAUNCH_PAIR
+    return hipGetLastError();
+}
+
+hipError_t launch_blur_replay_fused(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out, uint32_t W,
+                                    uint32_t H, uint32_t row0, uint32_t rows, int iterations, uint32_t stamp, hipStream_t stream)
+{
+    if (rows == 0 || iterations <= 0) return hipSuccess;
+    if (iterations > kBlurMaxFused) return hipErrorInvalidValue;
+    const EdgePlane e = edge_plane_carve(const_cast<void*>(edge_base), W, H);
+    const int ones = blur_weights_positive(cb) ? 1 : 0;
+    if (!ones) stamp = 0u;             // the pair launch settled no tile either
+    hipLaunchKernelGGL(blur_replay_fused_kernel, blur_tile_grid(W, row0, rows), dim3(512), 0, stream, cb, e, in, out, W, H, row0, row0 + rows,
+                       iterations, stamp, ones);
     return hipGetLastError();
 }
 

@@ -17,17 +17,20 @@ hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, con
                        const uint8_t* randvec, uint16_t* ambient, void* edge_base, uint32_t W, uint32_t H,
                        uint32_t row0, uint32_t rows, bool emit_ao, bool use_pairs, uint32_t stamp, hipStream_t stream);
 
-// Plain: a self-contained sweep.  Record: same, and stores the per-pixel tap decisions + totalWeight of this
-// direction in the edge workspace.  Replay: uses what a Record sweep of the same direction stored (same geometry).
-enum class BlurMode { Plain, Record, Replay };
-// horizontal + vertical replay sweep of one iteration in one launch (in -> out, out != in)
-hipError_t launch_blur_replay_pair(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out,
-                                   uint32_t W, uint32_t H, uint32_t row0, uint32_t rows, hipStream_t stream);
-// stamp / onesMargin (Record sweeps): the SSAO pass's frame stamp and 5 pixels per sweep of the frame still to run, for the
-// unoccluded-tile exit (ssao_core.hpp); stamp 0 = no exit.
+// One self-contained sweep of SsaoBlur.hlsl (Ssao::BlurAmbientMap(cmdList, bool), Ssao.cpp:245-293) over half-res rows [row0, row0 + rows).
 hipError_t launch_blur(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out,
-                       uint32_t W, uint32_t H, bool horizontal, BlurMode mode, uint32_t row0, uint32_t rows,
-                       uint32_t stamp, int onesMargin, hipStream_t stream);
+                       uint32_t W, uint32_t H, bool horizontal, uint32_t row0, uint32_t rows, hipStream_t stream);
+// Iteration 0 of the blur chain: horizontal + vertical sweep in one launch (in -> out, out != in); the rows are those of the
+// vertical sweep's output.  record: store both sweeps' tap decisions + totals and the per-tile flags for launch_blur_replay_fused.
+// stamp (0 = no exit) / onesMargin / ssaoRow0, ssaoRows: the unoccluded-tile exit (blur_tiles.hpp) -- the SSAO pass of this frame
+// wrote the unoccluded-wavefront map with `stamp` for half-res rows [ssaoRow0, ssaoRow0 + ssaoRows).
+hipError_t launch_blur_pair(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out, uint32_t W, uint32_t H,
+                            uint32_t row0, uint32_t rows, bool record, uint32_t stamp, int onesMargin, uint32_t ssaoRow0, uint32_t ssaoRows,
+                            hipStream_t stream);
+// `iterations` (1 .. 3) further blur iterations in one launch, replaying what launch_blur_pair(record) stored (in -> out, out != in);
+// the rows are those owed after the last of them.  stamp: the one the pair launch ran with (its settled tiles return at once).
+hipError_t launch_blur_replay_fused(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out, uint32_t W,
+                                    uint32_t H, uint32_t row0, uint32_t rows, int iterations, uint32_t stamp, hipStream_t stream);
 
 hipError_t launch_light(const LightParams& P, const float* g0, const float* g1, const float* g2,
                         const uint32_t* depth, const uint16_t* ambient, const uint8_t* cube, uint8_t* out,

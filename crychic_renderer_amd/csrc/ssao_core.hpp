@@ -27,12 +27,11 @@ struct EdgePlane {
     uint16_t* mask_v;
     float* total_h;
     float* total_v;
-    uint16_t* spare;   // a third ambient plane: lets an odd number of fused replay iterations end in ambient0 (api.cpp)
     const void* pairs; // DepthPairs plane (below), depth_pairs_bytes(W, H)
     uint32_t* geo;     // coarse geometry map (below "sky shortcut"), geo_map_bytes(W, H)
     uint32_t* ones;    // unoccluded-wavefront map (below "unoccluded tiles"), ones_map_bytes(W, H)
-    float* zmin;       // nearest-depth map per 8 x 8 block (below "tap culling"), zmin_map_bytes(W, H)
-    float* zcull;      // the same per 2 x 2 blocks: what a tap looks up, zmin_map_bytes(W, H)
+    float* zcull;      // nearest-depth map per 9 x 9 texel cell (below "tap culling"): what a tap looks up, zmin_map_bytes(W, H)
+    uint32_t* tiles;   // unoccluded-tile flags of the blur launches (blur_tiles.hpp), blur_tile_map_bytes(W, H)
 };
 
 // ---- depth pairs -----------------------------------------------------------------------------------------------------
@@ -48,7 +47,7 @@ CRY_HD size_t depth_pairs_bytes(uint32_t W, uint32_t H) { return (size_t)(W + 4u
 CRY_HD size_t edge_plane_pairs_offset(uint32_t W, uint32_t H)
 {
     size_t w2 = W / 2, h2 = H / 2;
-    return (w2 * h2 * 26 + (w2 + h2) * 8 + 15) & ~(size_t)15;
+    return (w2 * h2 * 24 + (w2 + h2) * 8 + 15) & ~(size_t)15;
 }
 // Coarse geometry map: one word per cell of 128 x 32 depth texels, holding the frame stamp of the last frame in which the
 // cell contained a texel below the clear depth.  Cell cx covers texel columns [128 cx - 2, 128 cx + 126) -- the footprint of
@@ -62,14 +61,20 @@ CRY_HD size_t edge_plane_geo_offset(uint32_t W, uint32_t H) { return (edge_plane
 CRY_HD uint32_t ones_map_cols(uint32_t W) { return (W / 2u + 63u) / 64u; }
 CRY_HD size_t ones_map_bytes(uint32_t W, uint32_t H) { return (size_t)ones_map_cols(W) * (H / 2u) * 4u; }
 CRY_HD size_t edge_plane_ones_offset(uint32_t W, uint32_t H) { return (edge_plane_geo_offset(W, H) + geo_map_bytes(W, H) + 15) & ~(size_t)15; }
-// Coarse nearest-depth map ("tap culling" below): one float per block of 8 x 8 texels of the padded depth plane (padded texel
-// (ex, ey) = texel (ex - 2, ey - 2): the coordinates of the pairs plane, BORDER band included).
+// Coarse nearest-depth map ("tap culling" below): one float per cell of 9 x 9 texels of the padded depth plane, cells 8 texels
+// apart (padded texel (ex, ey) = texel (ex - 2, ey - 2): the coordinates of the pairs plane, BORDER band included): cell (cx, cy)
+// covers padded texels [8 cx, 8 cx + 8] x [8 cy, 8 cy + 8], so the 2 x 2 footprint whose top-left padded texel is (ex, ey) lies
+// inside cell (ex >> 3, ey >> 3).
 CRY_HD uint32_t zmin_map_cols(uint32_t W) { return (W + 4u + 7u) / 8u; }
 CRY_HD uint32_t zmin_map_rows(uint32_t H) { return (H + 4u + 7u) / 8u; }
 CRY_HD size_t zmin_map_bytes(uint32_t W, uint32_t H) { return (size_t)zmin_map_cols(W) * zmin_map_rows(H) * 4u; }
-CRY_HD size_t edge_plane_zmin_offset(uint32_t W, uint32_t H) { return (edge_plane_ones_offset(W, H) + ones_map_bytes(W, H) + 15) & ~(size_t)15; }
-CRY_HD size_t edge_plane_zcull_offset(uint32_t W, uint32_t H) { return (edge_plane_zmin_offset(W, H) + zmin_map_bytes(W, H) + 15) & ~(size_t)15; }
-CRY_HD size_t edge_plane_bytes(uint32_t W, uint32_t H) { return edge_plane_zcull_offset(W, H) + zmin_map_bytes(W, H); }
+CRY_HD size_t edge_plane_zcull_offset(uint32_t W, uint32_t H) { return (edge_plane_ones_offset(W, H) + ones_map_bytes(W, H) + 15) & ~(size_t)15; }
+// Unoccluded-tile flags of the blur launches: one word per 64 x 16 half-res tile of an absolute grid (blur_tiles.hpp).
+CRY_HD uint32_t blur_tiles_x(uint32_t W) { return (W / 2u + 63u) / 64u; }
+CRY_HD uint32_t blur_tiles_y(uint32_t H) { return (H / 2u + 15u) / 16u; }
+CRY_HD size_t blur_tile_map_bytes(uint32_t W, uint32_t H) { return (size_t)blur_tiles_x(W) * blur_tiles_y(H) * 4u; }
+CRY_HD size_t edge_plane_tiles_offset(uint32_t W, uint32_t H) { return (edge_plane_zcull_offset(W, H) + zmin_map_bytes(W, H) + 15) & ~(size_t)15; }
+CRY_HD size_t edge_plane_bytes(uint32_t W, uint32_t H) { return edge_plane_tiles_offset(W, H) + blur_tile_map_bytes(W, H); }
 // Entries (x, y) and (x + 1, y) of the pairs plane from the D24 plane; x even (so the two texels of a row are one 8-byte load).
 CRY_HD f4a depth_pairs_entry2(const uint32_t* __restrict__ depth, uint32_t W, uint32_t H, int x, int y)
 {
@@ -93,12 +98,11 @@ CRY_HD EdgePlane edge_plane_carve(void* base, uint32_t W, uint32_t H)
     e.mask_v = (uint16_t*)(b + n * 22);   // n * 2
     e.gcol = (u2*)(b + n * 24);           // h2 * 8
     e.grow = e.gcol + h2;                 // w2 * 8
-    e.spare = (uint16_t*)(b + n * 24 + (w2 + h2) * 8);   // n * 2
     e.pairs = b + edge_plane_pairs_offset(W, H);
     e.geo = (uint32_t*)(b + edge_plane_geo_offset(W, H));
     e.ones = (uint32_t*)(b + edge_plane_ones_offset(W, H));
-    e.zmin = (float*)(b + edge_plane_zmin_offset(W, H));
     e.zcull = (float*)(b + edge_plane_zcull_offset(W, H));
+    e.tiles = (uint32_t*)(b + edge_plane_tiles_offset(W, H));
     return e;
 }
 
@@ -300,12 +304,12 @@ CRY_HD GeoCells ssao_sky_cells(const SkyReach& r, uint32_t W, uint32_t H, uint32
 // ---- tap culling ---------------------------------------------------------------------------------------------------------
 // A tap adds dp * occlusion to the sum, and occlusion is 0 whenever distZ = p.z - r.z <= SurfaceEpsilon (Ssao.hlsl:76-108): the
 // surface under the tap is not in front of the pixel by more than epsilon.  On open ground that is nine taps out of ten, and the
-// depth gather -- the whole cost of the pass -- only confirms it.  depth_pairs_kernel therefore also leaves, per block of 8 x 8
-// padded depth texels, a LOWER BOUND of the view depth any footprint inside the block can return:
-//     cell = ndc_to_view(min over the block of the decoded texels - 2^-21) * 0.999998.
-// A footprint with top-left padded texel (ex, ey) lies inside the 2 x 2 blocks starting at (ex >> 3, ey >> 3); a second small
-// pass stores the smallest of those four cells per block position (zmin_combine), and if that value is >= p.z - epsilon the
-// tap is skipped: gather, reconstruction, normalisation and all.  Why that is exact:
+// depth gather -- the whole cost of the pass -- only confirms it.  depth_pairs_kernel therefore also leaves, per cell of 9 x 9
+// padded depth texels (cells 8 texels apart, so that they overlap by one row and one column), a LOWER BOUND of the view depth
+// any footprint inside the cell can return:
+//     cell = ndc_to_view(min over the cell of the decoded texels - 2^-21) * 0.999998.
+// A footprint with top-left padded texel (ex, ey) lies inside cell (ex >> 3, ey >> 3); if that cell is >= p.z - epsilon the tap
+// is skipped: gather, reconstruction, normalisation and all.  Why that is exact:
 //   * bilinear filtering returns >= min(texels) - 2^-22 in binary32 (three lerps, each a mad on values in [0, 1]);
 //   * ndc_to_view is B * rcp(z - A) with B < 0 < 1 < A (checked on the host: ssao_cull_params): every step is monotone, so the
 //     cell bounds the tap's rz from below; r.z = (rz * rcp(q.z)) * q.z is rz within 3 ulp -- covered by the factor 0.999998;
@@ -340,12 +344,6 @@ struct NoCull {
     static constexpr bool active = false;
     CRY_HD bool operator()(int, int, float) const { return false; }
 };
-// cell (cx, cy) of the lookup map: the smallest block value of blocks (cx .. cx+1, cy .. cy+1), the map's edge repeated
-CRY_HD float zmin_combine(const float* __restrict__ zmin, uint32_t cols, uint32_t rows, uint32_t cx, uint32_t cy)
-{
-    const uint32_t cx1 = cx + 1u < cols ? cx + 1u : cx, cy1 = cy + 1u < rows ? cy + 1u : cy;
-    return __builtin_fminf(__builtin_fminf(zmin[cy * cols + cx], zmin[cy * cols + cx1]), __builtin_fminf(zmin[cy1 * cols + cx], zmin[cy1 * cols + cx1]));
-}
 struct ZminMap {
     static constexpr bool active = true;
     const float* cells; uint32_t pitch;                            // EdgePlane::zcull, zmin_map_cols(W)
@@ -508,10 +506,11 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
 // ---- unoccluded tiles --------------------------------------------------------------------------------------------------
 // A blur output whose 11-tap window holds only 1.0 is 1.0 whatever the edge tests decide (the accepted weights are summed into
 // colour and total alike, and x * rcp(x) quantises to 65535).  So if every ambient value within `margin` = 5 pixels per
-// remaining sweep of a tile is 65535 when the first sweep starts, the tile stays 65535 through all sweeps of the frame, the
-// replay sweeps take their all-ones exit on it and never read its recorded masks: the record sweeps may write 65535 and skip
-// staging, edge tests and mask recording for that tile.  Whether the neighbourhood is all ones is answered by the
-// unoccluded-wavefront map the SSAO pass fills (rows outside the rows it computed this frame hold no current stamp: no skip).
+// iteration of a tile is 65535 when the first sweep starts, the tile stays 65535 through all sweeps of the frame: the first blur
+// launch settles it (writes 65535, a centre-only decision and the tile's flag -- blur_tiles.hpp) and the later launch skips it.
+// Whether the neighbourhood is all ones is answered by the unoccluded-wavefront map the SSAO pass fills: one word per wavefront
+// that emitted ambient values, the frame's stamp if all 64 are 65535 and 0 otherwise.  A tile whose neighbourhood leaves the rows
+// the SSAO pass computed this frame is never settled, so no word is looked at that this frame did not write.
 // CLAMP addressing maps taps beyond the map to its edge texels, so the neighbourhood is clamped to the map, not extended.
 struct OnesRegion { uint32_t c0, c1, r0, r1; };      // inclusive cell columns (64-pixel segments) and half-res rows
 CRY_HD OnesRegion blur_ones_region(uint32_t w2, uint32_t h2, int x0, int y0, int bw, int bh, int margin)

@@ -83,7 +83,7 @@ public:
             mRenderTargetWidth, mRenderTargetHeight, blurCount, 0, mRenderTargetHeight / 2, cmdList->Stream()));
     }
 
-    // false (default): ComputeSsao is one crychic_ssao_compute call (record / replay sweeps, fused iterations, exits);
+    // false (default): ComputeSsao is one crychic_ssao_compute call (SSAO pass + two blur launches: record, fused replay, exits);
     // true: the reference's literal sequence of one SSAO pass and 2 * blurCount single sweeps.  Same bits either way
     // (tests/cpp/veneer_driver.cpp renders both).
     bool mLiteralSequence = false;
@@ -123,6 +123,8 @@ private:
         mEdgePlane = std::make_unique<ID3D12Resource>(crychic_edge_plane_bytes(mRenderTargetWidth, mRenderTargetHeight), ID3D12Resource::DEFAULT_HEAP);
         CrychicHipThrowIfFailed(hipMemset(mAmbientMap0->Data(), 0xFF, n2 * 2));  // clear value 1.0 (Ssao.cpp:333)
         CrychicHipThrowIfFailed(hipMemset(mAmbientMap1->Data(), 0xFF, n2 * 2));
+        // not required (crychic_hip.h "Contract" of the edge workspace): hygiene for tools that look at the workspace
+        CrychicHipThrowIfFailed(hipMemset(mEdgePlane->Data(), 0, crychic_edge_plane_bytes(mRenderTargetWidth, mRenderTargetHeight)));
     }
     void BuildRandomVectorTexture(ID3D12GraphicsCommandList* cmdList)  // Ssao.cpp:352-421
     {

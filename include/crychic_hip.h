@@ -145,7 +145,12 @@ int crychic_update_ssao_cb(const crychic_camera* cam, uint32_t W, uint32_t H, co
 float crychic_pcf_search_radius(uint32_t shadowMapWidth, int literal);
 
 /* ---- SSAO (Ssao.h / Ssao.cpp / Ssao.hlsl / SsaoBlur.hlsl) --------------------------------------------- */
-/* Bytes of the half-res edge workspace for a W x H frame. */
+/* Bytes of the edge workspace for a W x H frame: per-pixel centre normals / linear depths and recorded blur decisions (half
+ * res), the decoded depth-pairs plane (full res) and the coarse maps of the exact shortcuts (csrc/ssao_core.hpp).
+ * Contract: the workspace is caller-owned scratch with NO initialisation requirement and no meaning between frames -- it may
+ * be freshly allocated, recycled from another context, or shared by consecutive frames of one stream.  Every word a frame
+ * reads was written earlier in that same frame (the maps are stamped from one process-wide counter and the passes write the
+ * stamp or a non-stamp into every word they will look at), so stale contents can never be mistaken for this frame's. */
 size_t crychic_edge_plane_bytes(uint32_t W, uint32_t H);
 
 /* Ssao.hlsl:PS (Shaders/Ssao.hlsl:117-199) over half-res rows [row0, row0+rows): writes ambient_out and,

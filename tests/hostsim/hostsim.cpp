@@ -3,6 +3,7 @@
 // with the oracle before any GPU time is spent.  Nothing in the product loads this library.
 #include <cstring>
 #include "ssao_core.hpp"
+#include "blur_tiles.hpp"
 #include "light_core.hpp"
 #include "raster_core.hpp"
 #include <vector>
@@ -49,6 +50,10 @@ static uint32_t g_culled_taps = 0;   // taps the last hs_ssao_path call skipped 
 uint32_t hs_last_culled_taps(void) { return g_culled_taps; }
 static uint16_t* g_cull_masks = nullptr;      // optional: per half-res pixel, bit i = tap i culled (analysis only)
 void hs_set_cull_mask_plane(uint16_t* plane) { g_cull_masks = plane; }
+// The frame stamp the next hs_ssao_path / hs_blur_chain calls run with (api.cpp draws a fresh one per frame from a process-wide
+// counter).  Like the device, nothing here clears the workspace: whatever the caller left in it is what a recycled allocation holds.
+static uint32_t g_stamp = 1u;
+void hs_set_stamp(uint32_t stamp) { g_stamp = stamp; }
 
 // use_pairs != 0: the product's default path -- build the decoded depth-pairs plane in the edge workspace (the body of
 // depth_pairs_kernel) and let the taps gather from it; 0: taps on the raw D24 plane (what runs without a workspace).
@@ -69,14 +74,12 @@ void hs_ssao_path(const crychic_ssao_constants* cb, const void* normal, const ui
     const DepthPairs dp{ e.pairs, depth_pairs_pitch(W) };
     const DepthD24 dd{ depth, W, H };
     const bool sparse = ssao_projtex_is_sparse(*cb);
-    // the coarse geometry map as depth_pairs_kernel fills it (stamp 1 on a zeroed map), and the sky shortcut per "wavefront"
-    // of 64 consecutive pixels of a row, exactly as ssao_kernel takes it
+    // the coarse geometry map as depth_pairs_kernel fills it (cells with geometry get the stamp, the others are left alone), and
+    // the sky shortcut per "wavefront" of 64 consecutive pixels of a row, exactly as ssao_kernel takes it
     SkyReach sky = ssao_sky_reach(*cb, W, H);
     if (!pairs) sky.enabled = 0;
-    const uint32_t stamp = 1u, gpitch = geo_map_cols(W);
+    const uint32_t stamp = g_stamp, gpitch = geo_map_cols(W);
     if (pairs) {
-        std::memset(e.geo, 0, geo_map_bytes(W, H));
-        std::memset(e.ones, 0, ones_map_bytes(W, H));
         const uint32_t halfPitch = depth_pairs_pitch(W) / 2u;
         const f4a* pp = (const f4a*)e.pairs;
         for (uint32_t py = 2; py < H + 2u; ++py)
@@ -85,8 +88,8 @@ void hs_ssao_path(const crychic_ssao_constants* cb, const void* normal, const ui
                 if (v.x != 1.0f || v.z != 1.0f) e.geo[((py - 2u) >> 5) * gpitch + px2 / 64u] = stamp;
             }
     }
-    // the nearest-depth map as depth_pairs_kernel fills it: per block of 8 x 8 padded texels (padded (ex, ey) = texel (ex - 2, ey - 2),
-    // anything outside the plane reads as the clear depth), and the whole map as the culling window
+    // the nearest-depth map as depth_pairs_kernel fills it: per cell of 9 x 9 padded texels, cells 8 apart (padded (ex, ey) = texel
+    // (ex - 2, ey - 2), anything outside the plane reads as the clear depth)
     const CullParams cp = ssao_cull_params(*cb);
     const bool culling = pairs && cp.enabled && use_pairs != 2;         // use_pairs == 2: pairs plane without tap culling
     const ZminMap win{ e.zcull, zmin_map_cols(W) };
@@ -94,15 +97,13 @@ void hs_ssao_path(const crychic_ssao_constants* cb, const void* normal, const ui
         for (uint32_t cy = 0; cy < zmin_map_rows(H); ++cy)
             for (uint32_t cx = 0; cx < zmin_map_cols(W); ++cx) {
                 float m = 1.0f;
-                for (uint32_t ey = 8u * cy; ey < 8u * cy + 8u; ++ey)
-                    for (uint32_t ex = 8u * cx; ex < 8u * cx + 8u; ++ex) {
+                for (uint32_t ey = 8u * cy; ey <= 8u * cy + 8u; ++ey)
+                    for (uint32_t ex = 8u * cx; ex <= 8u * cx + 8u; ++ex) {
                         const int tx = (int)ex - 2, ty = (int)ey - 2;
                         if ((uint32_t)tx < W && (uint32_t)ty < H) m = __builtin_fminf(m, d24_to_float(depth[(uint32_t)ty * W + (uint32_t)tx]));
                     }
-                e.zmin[cy * zmin_map_cols(W) + cx] = zmin_cell_value(cp.A, cp.B, m);
+                e.zcull[cy * zmin_map_cols(W) + cx] = zmin_cell_value(cp.A, cp.B, m);
             }
-        for (uint32_t cy = 0; cy < zmin_map_rows(H); ++cy)      // zmin_combine_kernel
-            for (uint32_t cx = 0; cx < zmin_map_cols(W); ++cx) e.zcull[cy * zmin_map_cols(W) + cx] = zmin_combine(e.zmin, zmin_map_cols(W), zmin_map_rows(H), cx, cy);
     }
     std::vector<SsaoCentre> row(w2);
     g_sky_waves = 0;
@@ -141,7 +142,7 @@ void hs_ssao_path(const crychic_ssao_constants* cb, const void* normal, const ui
                                                                 : ssao_pixel(*cb, row[x], dd, (const uint32_t*)randvec, W, H, x, y, sparse));
                 allOnes = allOnes && ambient[y * w2 + x] == 0xFFFFu;
             }
-            if (pairs && allOnes) e.ones[y * ones_map_cols(W) + x0 / 64u] = stamp;      // the unoccluded-wavefront map, as ssao_kernel writes it
+            if (pairs) e.ones[y * ones_map_cols(W) + x0 / 64u] = allOnes ? stamp : 0u;      // the unoccluded-wavefront map, as ssao_kernel writes it
         }
     }
 }
@@ -165,49 +166,50 @@ void hs_blur(const crychic_ssao_constants* cb, void* edge_base, const uint16_t* 
         }
 }
 
-// record = 1: full sweep that also stores masks/totals; record = 2: replay sweep using them.
-// onesMargin >= 0 (record sweeps): take the unoccluded-tile exit of blur_kernel<.., RECORD> per 64 x 16 tile, against the
-// unoccluded-wavefront map hs_ssao_path left in the workspace (stamp 1).
-static uint32_t g_ones_tiles = 0;
-uint32_t hs_last_ones_tiles(void) { return g_ones_tiles; }
-void hs_blur_mode(const crychic_ssao_constants* cb, void* edge_base, const uint16_t* in, uint16_t* out, uint32_t W,
-                  uint32_t H, int horizontal, int mode, uint32_t row0, uint32_t rows, int onesMargin)
+// The blur chain of Ssao::ComputeSsao as api.cpp issues it: the launch plan of blur_tiles.hpp, every launch's tiles run one after
+// the other through the very tile bodies the kernels instantiate (one sequential "thread" per tile).  planes[0] / planes[1] =
+// ambient0 / ambient1; the SSAO output is expected in planes[blur_chain_ssao_plane(blurCount)] for rows blur_chain_ssao_rows(..)
+// (hs_ssao_path with the same stamp wrote the unoccluded-wavefront map); the result is in planes[0], rows [row0, row0 + rows).
+// use_exit == 0: no unoccluded-tile exit (stamp 0), every tile takes the general path.
+static uint32_t g_settled_tiles = 0;          // tiles the last hs_blur_chain settled through the unoccluded-tile exit
+uint32_t hs_last_settled_tiles(void) { return g_settled_tiles; }
+void hs_blur_chain(const crychic_ssao_constants* cb, void* edge_base, uint16_t* plane0, uint16_t* plane1, uint32_t W, uint32_t H, int blurCount,
+                   uint32_t row0, uint32_t rows, int use_exit, int onesMargin)
 {
-    const int w2 = (int)(W / 2), h2 = (int)(H / 2);
+    const uint32_t h2 = H / 2;
     const EdgePlane e = edge_plane_carve(edge_base, W, H);
-    const float borderZ = ndc_to_view(*cb, 1.0f);
-    uint16_t* mask = horizontal ? e.mask_h : e.mask_v;
-    float* total = horizontal ? e.total_h : e.total_v;
-    const uint32_t stamp = 1u, pitch = ones_map_cols(W);
-    g_ones_tiles = 0;
-    for (int y0 = (int)row0; y0 < (int)(row0 + rows); y0 += 16)
-        for (int x0 = 0; x0 < w2; x0 += 64) {
-            bool skip = mode == 1 && onesMargin >= 0;
-            if (skip) {
-                const OnesRegion g = blur_ones_region((uint32_t)w2, (uint32_t)h2, x0, y0, 64, 16, onesMargin);
-                for (uint32_t r = g.r0; r <= g.r1 && skip; ++r)
-                    for (uint32_t c = g.c0; c <= g.c1 && skip; ++c) skip = e.ones[r * pitch + c] == stamp;
-            }
-            g_ones_tiles += skip ? 1u : 0u;
-            for (int y = y0; y < y0 + 16 && y < (int)(row0 + rows); ++y)
-                for (int x = x0; x < x0 + 64 && x < w2; ++x) {
-                    const uint32_t p = (uint32_t)y * w2 + x;
-                    if (skip) {
-                        out[p] = 0xFFFFu; mask[p] = (uint16_t)(1u << 5); total[p] = cb->BlurWeights[1][1];
-                    } else if (mode == 2) {
-                        out[p] = (uint16_t)blur_pixel_replay(&cb->BlurWeights[0][0], mask[p], total[p], [&](int i) {
-                            const int xi = clampi(horizontal ? x + i - 5 : x, 0, w2 - 1), yi = clampi(horizontal ? y : y + i - 5, 0, h2 - 1);
-                            return unorm16_to_float(in[(uint32_t)yi * w2 + xi]);
-                        });
-                    } else {
-                        const BlurOut o = blur_pixel_full(&cb->BlurWeights[0][0], [&](int i) {
-                            return blur_fetch(e, in, borderZ, w2, h2, horizontal ? x + i - 5 : x, horizontal ? y : y + i - 5);
-                        });
-                        out[p] = (uint16_t)o.value; mask[p] = (uint16_t)o.mask; total[p] = o.total;
-                    }
+    uint16_t* planes[2] = { plane0, plane1 };
+    uint32_t sr0, srn;
+    blur_chain_ssao_rows(blurCount, row0, rows, h2, &sr0, &srn);
+    const bool positive = blur_weights_positive(*cb);        // as the launchers decide
+    const uint32_t stamp = (use_exit && positive) ? g_stamp : 0u;
+    std::vector<f4a> s_nz(kBlurPairSW * kBlurPairSH);
+    std::vector<float> s_a(kBlurPairSW * kBlurPairSH), s_mid(kBlurTileW * kBlurPairSH), s0(kBlurFusedMaxW * kBlurFusedMaxH), s1(kBlurFusedMaxW * kBlurFusedMaxH);
+    g_settled_tiles = 0;
+    for (int i = 0; i < blur_chain_launches(blurCount); ++i) {
+        const BlurStep st = blur_chain_step(blurCount, row0, rows, h2, i);
+        if (st.rows == 0) continue;
+        const uint32_t t0 = st.row0 / (uint32_t)kBlurTileH, t1 = (st.row0 + st.rows - 1u) / (uint32_t)kBlurTileH;
+        for (uint32_t ty = t0; ty <= t1; ++ty)
+            for (uint32_t tx = 0; tx < blur_tiles_x(W); ++tx) {
+                BlurTileArgs a;
+                a.w = &cb->BlurWeights[0][0]; a.e = e; a.in = planes[st.in]; a.out = planes[st.out];
+                a.w2 = (int)(W / 2); a.h2 = (int)h2; a.x0 = (int)tx * kBlurTileW; a.y0 = (int)ty * kBlurTileH;
+                a.row0 = (int)st.row0; a.row1 = (int)(st.row0 + st.rows);
+                a.borderZ = ndc_to_view(*cb, 1.0f);
+                a.tileIndex = ty * blur_tiles_x(W) + tx;
+                if (st.iterations == 0) {
+                    if (blurCount > 1) blur_pair_tile<true>(BlockSeq{}, a, stamp, onesMargin, (int)sr0, (int)(sr0 + srn), s_nz.data(), s_a.data(), s_mid.data());
+                    else blur_pair_tile<false>(BlockSeq{}, a, stamp, onesMargin, (int)sr0, (int)(sr0 + srn), s_nz.data(), s_a.data(), s_mid.data());
+                    if (blurCount > 1 && stamp != 0u && e.tiles[a.tileIndex] == stamp) ++g_settled_tiles;
+                } else {
+                    blur_replay_fused_tile(BlockSeq{}, a, st.iterations, stamp, positive, s0.data(), s1.data());
                 }
-        }
+            }
+    }
 }
+int hs_blur_chain_ssao_plane(int blurCount) { return blur_chain_ssao_plane(blurCount); }
+void hs_blur_chain_ssao_rows(int blurCount, uint32_t row0, uint32_t rows, uint32_t h2, uint32_t* r0, uint32_t* rn) { blur_chain_ssao_rows(blurCount, row0, rows, h2, r0, rn); }
 
 void hs_light(const crychic_pass_constants* cb, const float* g0, const float* g1, const float* g2,
               const uint32_t* depth, const uint16_t* ambient, const uint32_t* const shadow[4], uint32_t shadowDim,

@@ -32,7 +32,7 @@ def build_sanitized(name, sources, extra=()):
 def build():
     if SANITIZE:
         return build_sanitized("libhostsim.so", [SRC])
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("devmath.hpp", "ssao_core.hpp", "light_core.hpp", "raster_core.hpp")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("devmath.hpp", "ssao_core.hpp", "blur_tiles.hpp", "light_core.hpp", "raster_core.hpp")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         subprocess.run([CLANG, "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-mfma",
                         "-I", os.path.join(ROOT, "include"), "-I", CSRC, SRC, "-o", LIB], check=True)
@@ -56,8 +56,11 @@ class HostSim:
         L.hs_last_sky_waves.restype = u32
         L.hs_last_culled_taps.restype = u32
         L.hs_blur.argtypes = [vp, vp, vp, vp, u32, u32, i, u32, u32]
-        L.hs_blur_mode.argtypes = [vp, vp, vp, vp, u32, u32, i, i, u32, u32, i]
-        L.hs_last_ones_tiles.restype = u32
+        L.hs_blur_chain.argtypes = [vp, vp, vp, vp, u32, u32, i, u32, u32, i, i]
+        L.hs_last_settled_tiles.restype = u32
+        L.hs_blur_chain_ssao_plane.restype = i; L.hs_blur_chain_ssao_plane.argtypes = [i]
+        L.hs_blur_chain_ssao_rows.argtypes = [i, u32, u32, u32, vp, vp]
+        L.hs_set_stamp.argtypes = [u32]
         L.hs_rasterize.restype = i
         L.hs_rasterize.argtypes = [i, vp, vp, vp, u32, vp, u32, vp, u32, u32, u32, i, f, vp, vp, vp, vp, vp]
         L.hs_light.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp, u32, vp, vp, u32, u32, u32, u32, i, f, u32, vp, u32]
@@ -68,14 +71,17 @@ class HostSim:
         self.lib.hs_eval_array(kind, a.size, a.ctypes.data, b.ctypes.data, out.ctypes.data)
         return out
 
-    def ssao(self, cb, normal_f16, depth_u32, randvec_u8, edge_bytes, row0=0, rows=None, emit=True, pairs=True, cull=True):
+    def ssao(self, cb, normal_f16, depth_u32, randvec_u8, edge_bytes, row0=0, rows=None, emit=True, pairs=True, cull=True, edge=None, stamp=1):
         """pairs=True: the taps gather from the decoded depth-pairs plane (the product's path when it has a workspace), and with
-        cull=True skip the ones the nearest-depth map proves to add nothing; pairs=False: from the raw D24 plane."""
+        cull=True skip the ones the nearest-depth map proves to add nothing; pairs=False: from the raw D24 plane.
+        edge: a workspace to (re)use as it is -- like the device, nothing clears it; stamp: the frame stamp of this call."""
         H, W = depth_u32.shape
         rows = H // 2 - row0 if rows is None else rows
         out = np.zeros((H // 2, W // 2), dtype=np.uint16)
-        edge = np.zeros((edge_bytes,), dtype=np.uint8)
+        if edge is None:
+            edge = np.zeros((edge_bytes,), dtype=np.uint8)
         n = np.ascontiguousarray(normal_f16.view(np.uint16)); d = np.ascontiguousarray(depth_u32); r = np.ascontiguousarray(randvec_u8)
+        self.lib.hs_set_stamp(int(stamp))
         self.lib.hs_ssao_path(C.addressof(cb), n.ctypes.data, d.ctypes.data, r.ctypes.data, out.ctypes.data if emit else None,
                               edge.ctypes.data, W, H, row0, rows, (1 if cull else 2) if pairs else 0)
         return out, edge
@@ -87,13 +93,32 @@ class HostSim:
         self.lib.hs_blur(C.addressof(cb), edge.ctypes.data, a.ctypes.data, out.ctypes.data, W, H, 1 if horizontal else 0, row0, rows)
         return out
 
-    def blur_mode(self, cb, edge, ambient_in, W, H, horizontal, mode, ones_margin=-1):
-        """mode 1 = record sweep, 2 = replay sweep; ones_margin >= 0 lets record sweeps take the unoccluded-tile exit."""
-        out = np.zeros((H // 2, W // 2), dtype=np.uint16)
-        a = np.ascontiguousarray(ambient_in)
-        self.lib.hs_blur_mode(C.addressof(cb), edge.ctypes.data, a.ctypes.data, out.ctypes.data, W, H, 1 if horizontal else 0, mode, 0, H // 2,
-                              int(ones_margin))
-        return out
+    def compute_ssao(self, cb, normal_f16, depth_u32, randvec_u8, edge_bytes, blur_count, row0=0, rows=None, use_exit=True, ones_margin=None,
+                     edge=None, stamp=1):
+        """Ssao::ComputeSsao as api.cpp sequences it (SSAO pass, then the two-launch blur chain of blur_tiles.hpp through the
+        kernels' own tile bodies).  Returns (ambient0, edge); rows [row0, row0 + rows) of ambient0 are the result.
+        ones_margin: the reach the unoccluded-tile exit assumes (default: what api.cpp passes, 5 per iteration)."""
+        H, W = depth_u32.shape
+        h2 = H // 2
+        rows = h2 - row0 if rows is None else rows
+        r0, rn = C.c_uint32(), C.c_uint32()
+        self.lib.hs_blur_chain_ssao_rows(blur_count, row0, rows, h2, C.addressof(r0), C.addressof(rn))
+        out, edge = self.ssao(cb, normal_f16, depth_u32, randvec_u8, edge_bytes, r0.value, rn.value, edge=edge, stamp=stamp)
+        planes = [np.full((h2, W // 2), 0xABCD, dtype=np.uint16), np.full((h2, W // 2), 0xABCD, dtype=np.uint16)]     # junk where nothing writes
+        sp = self.lib.hs_blur_chain_ssao_plane(blur_count)
+        planes[sp][r0.value:r0.value + rn.value] = out[r0.value:r0.value + rn.value]
+        self.lib.hs_blur_chain(C.addressof(cb), edge.ctypes.data, planes[0].ctypes.data, planes[1].ctypes.data, W, H, blur_count, row0, rows,
+                               1 if use_exit else 0, 5 * blur_count if ones_margin is None else int(ones_margin))
+        return planes[0], edge
+
+    def blur_chain(self, cb, edge, ambient_in, W, H, blur_count, use_exit=False):
+        """The blur chain alone on a caller-made ambient map (whole frame, no exit unless the workspace's map belongs to it)."""
+        h2 = H // 2
+        planes = [np.full((h2, W // 2), 0xABCD, dtype=np.uint16), np.full((h2, W // 2), 0xABCD, dtype=np.uint16)]
+        planes[self.lib.hs_blur_chain_ssao_plane(blur_count)][:] = ambient_in
+        self.lib.hs_blur_chain(C.addressof(cb), edge.ctypes.data, planes[0].ctypes.data, planes[1].ctypes.data, W, H, blur_count, 0, h2,
+                               1 if use_exit else 0, 5 * blur_count)
+        return planes[0]
 
     def rasterize(self, mode, view_t, viewproj_t, items, materials, textures, W, H, depth_bias=0, slope_bias=0.0):
         from crychic_renderer_amd._lib import DrawItem, Texture

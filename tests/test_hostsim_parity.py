@@ -30,8 +30,8 @@ def test_ssao_and_blur_chain(built_lib, oracle, hostsim, W, H):
     # the taps on the raw D24 plane (no workspace) and on the decoded depth-pairs plane (default) are the same bits
     raw, edge_raw = hostsim.ssao(c.ssao_cb, p["normal"], p["depth"], p["randvec"], eb, pairs=False)
     assert np.array_equal(raw, ref)
-    n26 = (W // 2) * (H // 2) * 26 + (W // 2 + H // 2) * 8
-    assert np.array_equal(edge[:n26], edge_raw[:n26])      # centre normals / depths identical either way
+    n24 = (W // 2) * (H // 2) * 24 + (W // 2 + H // 2) * 8
+    assert np.array_equal(edge[:n24], edge_raw[:n24])      # centre normals / depths identical either way
     # blur on the SSAO output and on noise (noise exercises every accept/reject combination)
     rng = np.random.default_rng(W * 7 + H)
     for start in (ref, rng.integers(0, 65536, size=ref.shape, dtype=np.uint16)):
@@ -43,17 +43,39 @@ def test_ssao_and_blur_chain(built_lib, oracle, hostsim, W, H):
             cur = r
 
 
-@pytest.mark.parametrize("W,H", [(64, 64), (130, 34)])
-def test_blur_record_replay_matches_oracle(built_lib, oracle, hostsim, W, H):
-    """Iterations 2.. of the blur replay the tap decisions recorded by iteration 1 (same geometry): same bits."""
+def oracle_chain(oracle, scb, normal, depth, start, blur_count):
+    cur = start
+    for _ in range(blur_count):
+        cur = oracle.blur(scb, normal, depth, cur, True)
+        cur = oracle.blur(scb, normal, depth, cur, False)
+    return cur
+
+
+@pytest.mark.parametrize("W,H", [(64, 64), (130, 34), (256, 256), (300, 100)])
+@pytest.mark.parametrize("blur_count", [1, 2, 3, 4, 5, 8])
+def test_blur_chain_matches_oracle(built_lib, oracle, hostsim, W, H, blur_count):
+    """The two-launch blur chain (blur_tiles.hpp: iteration 0 as one H + V launch, the others fused and replayed, tile by tile
+    with recomputed aprons) equals the oracle's 2 * blurCount separate sweeps -- on the SSAO output and on noise (noise exercises
+    every accept / reject combination, and map edges on every side of ragged tile grids)."""
     p, c, scb, pcb, eb = setup(W, H, built_lib)
     ref, edge = hostsim.ssao(c.ssao_cb, p["normal"], p["depth"], p["randvec"], eb)
-    cur_ref = cur = ref
-    for it in range(4):
-        for horz in (True, False):
-            cur_ref = oracle.blur(scb, p["normal"], p["depth"], cur_ref, horz)
-            cur = hostsim.blur_mode(c.ssao_cb, edge, cur, W, H, horz, 1 if it == 0 else 2)
-            assert np.array_equal(cur, cur_ref), (it, horz, int((cur != cur_ref).sum()))
+    rng = np.random.default_rng(W * 7 + H + blur_count)
+    for start in (ref, rng.integers(0, 65536, size=ref.shape, dtype=np.uint16)):
+        want = oracle_chain(oracle, scb, p["normal"], p["depth"], start, blur_count)
+        got = hostsim.blur_chain(c.ssao_cb, edge, start, W, H, blur_count)
+        assert np.array_equal(got, want), (blur_count, int((got != want).sum()))
+
+
+@pytest.mark.parametrize("blur_count", [1, 3, 4, 7])
+def test_compute_ssao_row_strips(built_lib, oracle, hostsim, blur_count):
+    """A strip of the final map (what one rank of N computes): the halo rows every stage recomputes, the tile grid anchored at
+    absolute rows, tiles cut by the strip's edges."""
+    W, H = 130, 200
+    p, c, scb, pcb, eb = setup(W, H, built_lib)
+    want = oracle.compute_ssao(scb, p["normal"], p["depth"], p["randvec"], blur_count)
+    for row0, rows in ((0, 100), (37, 21), (50, 50), (83, 17)):
+        got, _ = hostsim.compute_ssao(c.ssao_cb, p["normal"], p["depth"], p["randvec"], eb, blur_count, row0, rows)
+        assert np.array_equal(got[row0:row0 + rows], want[row0:row0 + rows]), (row0, rows)
 
 
 def test_row_ranges_match_full(built_lib, oracle, hostsim):
@@ -184,23 +206,57 @@ def test_tap_culling_is_exact_and_bites(built_lib, oracle, hostsim, seed):
 
 
 @pytest.mark.parametrize("seed", [0, 1, 5, 12, 14])
-@pytest.mark.parametrize("blur_count", [2, 4])
+@pytest.mark.parametrize("blur_count", [1, 2, 4, 5])
 def test_unoccluded_tile_exit_is_exact(built_lib, oracle, hostsim, seed, blur_count):
-    """Record sweeps skip tiles whose whole neighbourhood (5 pixels per iteration) came out of the SSAO pass as 65535
-    (ssao_core.hpp "unoccluded tiles") and leave a centre-only decision behind; the chain record -> replay ... must still equal
-    the oracle's blurCount iterations, here on the sky-probe frames (large unoccluded areas next to occluded patches)."""
+    """The first blur launch settles tiles whose whole neighbourhood (5 pixels per iteration) came out of the SSAO pass as 65535
+    (ssao_core.hpp "unoccluded tiles"): it writes 65535, a centre-only decision and the tile's flag, and the fused replay launch
+    skips flagged tiles altogether.  The chain must still equal the oracle's blurCount iterations, here on the sky-probe frames
+    (large unoccluded areas next to occluded patches); a margin smaller than the reach of the sweeps does break it."""
     import fuzz_util
     W, H, c, scb, depth, normal, randvec = fuzz_util.sky_probe_case(seed)
     eb = int(built_lib.lib.crychic_edge_plane_bytes(W, H))
-    ref = oracle.ssao(scb, normal, depth, randvec)
-    cur, edge = hostsim.ssao(c.ssao_cb, normal, depth, randvec, eb)
-    assert np.array_equal(cur, ref)
-    margin = 5 * blur_count + 2                  # what ssao_compute_impl passes
-    skipped = 0
-    for it in range(blur_count):
-        for horz in (True, False):
-            ref = oracle.blur(scb, normal, depth, ref, horz)
-            cur = hostsim.blur_mode(c.ssao_cb, edge, cur, W, H, horz, 1 if it == 0 else 2, ones_margin=margin)
-            skipped += int(hostsim.lib.hs_last_ones_tiles())
-            assert np.array_equal(cur, ref), (it, horz, int((cur != ref).sum()))
-    assert skipped > 10
+    want = oracle.compute_ssao(scb, normal, depth, randvec, blur_count)
+    got, _ = hostsim.compute_ssao(c.ssao_cb, normal, depth, randvec, eb, blur_count)
+    settled = int(hostsim.lib.hs_last_settled_tiles())
+    assert np.array_equal(got, want), int((got != want).sum())
+    if blur_count > 1:
+        assert settled > 10
+    noexit, _ = hostsim.compute_ssao(c.ssao_cb, normal, depth, randvec, eb, blur_count, use_exit=False)
+    assert np.array_equal(noexit, want)
+
+
+def test_unoccluded_tile_exit_margin_bites(built_lib, oracle, hostsim):
+    """The exit's margin is not slack: with less than 5 pixels per iteration some settled tile is wrong on some probe frame."""
+    import fuzz_util
+    wrong = 0
+    for seed in (0, 1, 5, 12, 14):
+        W, H, c, scb, depth, normal, randvec = fuzz_util.sky_probe_case(seed)
+        eb = int(built_lib.lib.crychic_edge_plane_bytes(W, H))
+        want = oracle.compute_ssao(scb, normal, depth, randvec, 4)
+        got, _ = hostsim.compute_ssao(c.ssao_cb, normal, depth, randvec, eb, 4, ones_margin=4)
+        wrong += int((got != want).sum())
+    assert wrong > 0
+
+
+@pytest.mark.parametrize("blur_count", [2, 4])
+def test_recycled_workspace_cannot_settle_a_tile(built_lib, oracle, hostsim, blur_count):
+    """The edge workspace is caller-owned and nothing clears it.  Render frame A, then a DIFFERENT frame B over the same,
+    uncleared workspace -- with a fresh stamp, as api.cpp draws one per frame, and, the worst case, with the very stamp frame A
+    ran with (a recycled allocation that served another context): every word of the unoccluded-wavefront map and every tile flag
+    a frame looks at was written by that frame, so frame B equals the oracle either way."""
+    import fuzz_util
+    W, H, c, scb, depth_a, normal, randvec = fuzz_util.sky_probe_case(0)
+    depth_b, normal_b = np.ascontiguousarray(depth_a[::-1, ::-1]), np.ascontiguousarray(normal[::-1, ::-1])     # the patches elsewhere
+    assert not np.array_equal(depth_a, depth_b)
+    eb = int(built_lib.lib.crychic_edge_plane_bytes(W, H))
+    want_b = oracle.compute_ssao(scb, normal_b, depth_b, randvec, blur_count)
+    for stamp_b in (8, 7):
+        _, edge = hostsim.compute_ssao(c.ssao_cb, normal, depth_a, randvec, eb, blur_count, stamp=7)
+        assert int(hostsim.lib.hs_last_settled_tiles()) > 10
+        got, _ = hostsim.compute_ssao(c.ssao_cb, normal_b, depth_b, randvec, eb, blur_count, edge=edge, stamp=stamp_b)
+        assert np.array_equal(got, want_b), (stamp_b, int((got != want_b).sum()))
+    # and a workspace pre-filled with the upcoming stamp in every word of both maps
+    edge = np.zeros((eb,), dtype=np.uint8)
+    edge.view(np.uint32)[:] = 9
+    got, _ = hostsim.compute_ssao(c.ssao_cb, normal_b, depth_b, randvec, eb, blur_count, edge=edge, stamp=9)
+    assert np.array_equal(got, want_b)

@@ -88,7 +88,7 @@ def test_c5_8k_point_lights_properties(built_lib, oracle):
     band of rows; the 8-GPU all-gather itself is covered by tests/test_sharding_gloo.py."""
     import torch
     from crychic_renderer_amd import Context, Crychic, scene
-    W, H, SD = 7680, 4320, 1024
+    W, H, SD = 7680, 4320, 4096          # the cascade size BASELINE and bench.py use
     ctx = Context(0)
     pl = scene.make_scene(W, H, shadow_dim=SD, cube_dim=256, device=str(ctx.device))
     c = pl["consts"]
