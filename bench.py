@@ -13,9 +13,12 @@ crychic_allgather_frame -- RCCL over xGMI behind the C ABI (csrc/comm.cpp), enqu
 the strip; torch.distributed (gloo) carries only control traffic (rendezvous id, barriers, the max over ranks).
 Workload = BASELINE.json configs[2]: 3840x2160, 3 directional lights, blurCount 4, cascade PCF.  The PCF radius
 follows the reference shader as written (Common.hlsl:305 unsigned division => 16 coincident taps); --pcf intended
-benches the 2.5-texel variant instead.  At N = 1 three independent frames are in flight on three streams, as the reference
-keeps them (gNumFrameResources = 3); the K frames are then also timed one at a time (config.one_frame_at_a_time) and the
-per-pass list is measured that way.  --frames-in-flight 1 makes one-at-a-time the timed region itself.
+benches the 2.5-texel variant instead.  Frames run ONE AT A TIME on one stream -- the reference submits every frame to
+one direct queue over one G-buffer / ambient-map set (Common/d3dApp.cpp:484-486), and SURVEY.md 8(d) defines the metric
+on the wall time of one frame -- so `value` = K frames / the wall time of the K-frame region.  In the same run (N = 1)
+the line also carries, all labelled and none of them `value`: the median of per-frame HIP-event times; a throughput leg
+with three frames in flight on three streams, each pipeline on its OWN copy of every input plane; the same frame with
+the evidently intended 16-tap PCF; and a camera pitched down until every pixel is covered (no sky).
 
 Rank 0 prints ONE JSON line: metric/value/... plus "roofline" (frame level per SURVEY.md 8d, with a per-kernel
 break-down measured by HIP events on the launch stream) and "cpu_baseline" (the CPU oracle on a band of the frame).
@@ -39,7 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r02_pmc_counters.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc_counters.json")
 
 
 def parse():
@@ -58,11 +61,11 @@ def parse():
                     help="covered: the camera pitched down until no pixel is sky (informational: every G-buffer texel is read)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-producers", action="store_true", help="skip the informational timing of the producer passes")
-    ap.add_argument("--frames-in-flight", type=int, default=0,
-                    help="independent frame pipelines (own stream + own ambient / edge workspace) alternating frames: the head and "
-                         "tail of one frame's kernels overlap the other's.  0 = auto: 3 at N = 1 (the reference's own "
-                         "gNumFrameResources, FrameResource.h / CRYCHIC.h), 4 for the strips of N > 1.  At N = 1 the same K frames "
-                         "are also timed one at a time (config.one_frame_at_a_time) and the per-pass list is measured that way")
+    ap.add_argument("--frames-in-flight", type=int, default=1,
+                    help="independent frame pipelines (own stream, own ambient / edge workspace and, at N = 1, own copies of every "
+                         "input plane) taking the K frames in turn.  1 (default) = one frame at a time, the metric's definition; "
+                         "more = a throughput experiment (at N = 1 the default run reports one as config.throughput_3_in_flight)")
+    ap.add_argument("--no-legs", action="store_true", help="skip the informational legs of the N = 1 line (throughput, intended PCF, covered camera)")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the strip exchange even with one rank: exercises the N > 1 code path on a 1-GPU box")
     ap.add_argument("--exchange", choices=["abi", "torch"], default="abi",
@@ -287,7 +290,7 @@ def kernel_source_hash():
     """Identifies the hot-path kernels a committed counter profile was taken on: sha256 over their sources + the build flags."""
     from crychic_renderer_amd import build
     h = hashlib.sha256()
-    for name in ("devmath.hpp", "kernels.hip", "kernels.hpp", "light_core.hpp", "ssao_core.hpp"):
+    for name in ("blur_tiles.hpp", "devmath.hpp", "kernels.hip", "kernels.hpp", "light_core.hpp", "ssao_core.hpp"):
         with open(os.path.join(build.CSRC, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
     h.update(" ".join(build.FLAGS).encode())
@@ -441,10 +444,15 @@ def main():
                               consts=scene.Constants(W, H, args.shadow_dim, cam=bench_camera(args)))
     pcf_radius = lib.crychic_pcf_search_radius(args.shadow_dim, 1 if args.pcf == "literal" else 0)
 
-    def new_app():
-        a = Crychic(ctx, W, H, planes["randvec"], planes["cube"], shadow_dim=args.shadow_dim)
-        a.load_scene(planes)
-        a.blurCount, a.numDirLights, a.pcfSearchRadius = args.blur_count, args.lights, pcf_radius
+    def new_app(scene_planes=None, own_inputs=False, radius=None):
+        """A renderer over `scene_planes` (default: the benchmark scene).  own_inputs: on private copies of every input plane,
+        so that pipelines running side by side cannot share cache fills of the same addresses."""
+        pl = planes if scene_planes is None else scene_planes
+        if own_inputs:
+            pl = {k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in pl.items()}
+        a = Crychic(ctx, W, H, pl["randvec"], pl["cube"], shadow_dim=args.shadow_dim)
+        a.load_scene(pl)
+        a.blurCount, a.numDirLights, a.pcfSearchRadius = args.blur_count, args.lights, pcf_radius if radius is None else radius
         if args.point_lights:
             a.set_point_lights(scene.point_light_grid(args.point_lights))
         return a
@@ -514,21 +522,23 @@ def main():
         else:
             bounds = None
             args.partition = "equal (fallback: no balanced plan)"
-    row0, rows = bounds[rank] if bounds and not args.strip else sharding.strip_rows(H, world, rank)
+    # The exchange always starts on the plain plan -- H/N rows per rank, one in-place ncclAllGather -- and moves to the balanced
+    # plan (ragged strips, one group of in-place ncclBroadcasts) only after the equal-strip frame has passed its check in this
+    # same run; the balanced plan then has to pass the same check or the run goes back to equal strips.
+    plan, bounds = bounds, None
+    row0, rows = sharding.strip_rows(H, world, rank)
     if args.strip:
         sn, sr = (int(v) for v in args.strip.split(":"))
-        row0, rows = bounds[sr] if bounds else sharding.strip_rows(H, sn, sr)
+        row0, rows = plan[sr] if plan else sharding.strip_rows(H, sn, sr)
+        bounds = plan
 
-    # Frames in flight: consecutive frames are independent, so further pipelines (own stream, own ambient / edge workspace,
-    # same read-only input planes) let the short kernels of one strip fill the dispatch gaps of the others.
-    # auto: three at N = 1 -- what the reference keeps in flight itself (gNumFrameResources = 3: three FrameResources cycled by
-    # CRYCHIC::Update / Draw) -- so the memory-pipe-bound SSAO / blur passes of one frame run under the VALU-bound lighting
-    # pass of another; four for the short strips of N > 1.  The per-pass list of the roofline object and
-    # config.one_frame_at_a_time are measured with one frame at a time (kernel durations not stretched by a co-running frame).
-    nflight = max(1, min(args.frames_in_flight or (4 if rows < H else 3), 4))
+    # Frames in flight: 1 by default -- one frame at a time on one stream, the metric's definition (the reference's
+    # frames go through one direct queue over one set of targets).  More is a labelled throughput experiment: further pipelines
+    # with their own stream, ambient maps, workspace and (N = 1) their own copies of the input planes.
+    nflight = max(1, min(args.frames_in_flight, 4))
     apps, streams = [app], [torch.cuda.current_stream(dev)]
     for _ in range(nflight - 1):
-        apps.append(new_app())
+        apps.append(new_app(own_inputs=(world == 1)))
         streams.append(torch.cuda.Stream(device=dev))
 
     # ---- the exchange ------------------------------------------------------------------------------------------------------
@@ -558,16 +568,15 @@ def main():
                     print("bench.py rank %d: crychic_allgather_frame unavailable (%s)" % (rank, e), file=sys.stderr, flush=True)
                     ok = False
                 if all_ranks_ok(ok):
-                    exchange_kind = "crychic_allgather_frame (C ABI, RCCL): " + ("one group of in-place ncclBroadcasts" if bounds else "in-place ncclAllGather")
+                    exchange_kind = "crychic_allgather_frame (C ABI, RCCL)"
                 else:
                     if exchange is not None:
                         exchange.abort()
                     exchange = None
         if exchange is None:
-            if bounds is not None:
-                bounds = None
-                row0, rows = sharding.strip_rows(H, world, rank)
-                args.partition = "equal (fallback)"
+            if plan is not None:
+                plan = None
+                args.partition = "equal (fallback: no RCCL communicator behind the C ABI)"
             nccl = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=min(args.timeout, 300.0)))
             exchange = sharding.FrameGather(W, H, world, rank, dev, group=nccl)
             exchange_kind = "torch.distributed nccl all_gather_into_tensor (fallback)" if args.exchange == "abi" else "torch.distributed nccl all_gather_into_tensor"
@@ -622,26 +631,37 @@ def main():
         app.Draw(0, H)
         torch.cuda.synchronize()
         exchange_ok = all(int(c) == chk for c in allchk) and bool(torch.equal(f, planes["out"]))
-        if args.fail_first_check:
-            args.fail_first_check, exchange_ok = False, False
         return exchange_ok, allchk
 
     exchange_ok = None
     if exchange is not None and args.warmup > 0:
-        exchange_ok, allchk = warm_and_check()
-        if not all_ranks_ok(exchange_ok) and abi and bounds is not None:
-            # the ragged plan failed its check on some rank: every rank switches to equal strips (same communicator, one
-            # in-place ncclAllGather) and the check runs again
-            print("bench.py rank %d: balanced strips failed the frame check (checksums %s); falling back to equal strips"
-                  % (rank, [int(c) for c in allchk]), file=sys.stderr, flush=True)
-            bounds = None
-            exchange.set_bounds(None)
-            row0, rows = sharding.strip_rows(H, world, rank)
-            args.partition = "equal (fallback: the balanced plan failed the frame check)"
-            exchange_ok, allchk = warm_and_check()
+        exchange_ok, allchk = warm_and_check()              # equal strips, in-place ncclAllGather
         if not all_ranks_ok(exchange_ok):
             raise SystemExit("bench.py rank %d: the gathered frame differs between ranks or from the single-GPU frame (checksums %s)"
                              % (rank, [int(c) for c in allchk]))
+        if plan is not None and abi:
+            # the equal-strip frame is right on every rank: now the balanced plan, under the same check
+            bounds = plan
+            exchange.set_bounds(bounds)
+            row0, rows = bounds[rank]
+            ok2, allchk = warm_and_check()
+            if args.fail_first_check:
+                args.fail_first_check, ok2 = False, False
+            if not all_ranks_ok(ok2):
+                print("bench.py rank %d: balanced strips failed the frame check (checksums %s); falling back to equal strips"
+                      % (rank, [int(c) for c in allchk]), file=sys.stderr, flush=True)
+                bounds = None
+                exchange.set_bounds(None)
+                row0, rows = sharding.strip_rows(H, world, rank)
+                args.partition = "equal (fallback: the balanced plan failed the frame check)"
+                exchange_ok, allchk = warm_and_check()
+                if not all_ranks_ok(exchange_ok):
+                    raise SystemExit("bench.py rank %d: the gathered frame differs between ranks or from the single-GPU frame (checksums %s)"
+                                     % (rank, [int(c) for c in allchk]))
+        elif plan is not None:
+            args.partition = "equal (the torch.distributed exchange gathers equal strips only)"
+        if abi:
+            exchange_kind += ": " + ("one group of in-place ncclBroadcasts" if bounds else "in-place ncclAllGather")
     elif args.warmup > 0:
         for i in range(args.warmup):
             step(i)
@@ -658,21 +678,86 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax)
 
-    # ---- N = 1: the same K frames one at a time on one stream (latency view; not `value` unless --frames-in-flight 1) ----
-    serial = None
-    if world == 1 and not args.strip and nflight > 1 and exchange is None:
-        app.mBackBuffer = planes["out"]
-        for phase in range(2):
-            torch.cuda.synchronize()
-            t1 = time.perf_counter()
-            for _ in range(args.steps if phase else 10):
-                app.Draw(row0, rows)
-            torch.cuda.synchronize()
-            t_serial = time.perf_counter() - t1
-        if not torch.equal(outs[1], planes["out"]):
-            raise SystemExit("bench.py: the frame pipelines disagree")
-        serial = {"ms_per_frame": round(t_serial / args.steps * 1e3, 4), "Mpixels_per_s": round(W * H * args.steps / t_serial / 1e6, 1),
-                  "hbm_roofline_frac": round((59 + 14 * max(args.blur_count, 0)) * W * H / (t_serial / args.steps) / 1e9 / HBM_PEAK_GBS, 4)}
+    def frame_stats(a, row0_, rows_, n):
+        """n frames one at a time on the current stream: (wall ms per frame over the region, median of per-frame HIP-event ms)."""
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for _ in range(5):
+            a.Draw(row0_, rows_)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for e0, e1 in evs:
+            e0.record()
+            a.Draw(row0_, rows_)
+            e1.record()
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - t1) / n * 1e3
+        per = sorted(e0.elapsed_time(e1) for e0, e1 in evs)
+        return wall, per[len(per) // 2]
+
+    def leg(ms, npx_):
+        return {"ms_per_frame": round(ms, 4), "Mpixels_per_s": round(npx_ / ms / 1e3, 1),
+                "hbm_roofline_frac": round((59 + 14 * max(args.blur_count, 0)) * npx_ / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+
+    # ---- per-frame HIP-event times of the same workload (SURVEY.md 8d: median of >= 50 frames) ----
+    app.mBackBuffer = planes["out"]
+    nev = max(50, min(args.steps, 200))
+    _, frame_ms_median = frame_stats(app, row0, rows, nev)
+
+    # ---- N = 1 informational legs (labelled; none of them is `value`) ----
+    legs = {}
+    if world == 1 and not args.strip and exchange is None and not args.no_legs and not args.point_lights:
+        nleg = max(20, min(args.steps, 100))
+        # (a) throughput: three frames in flight on three streams, every pipeline on its own copy of every input plane
+        if nflight == 1:
+            pipes = [app] + [new_app(own_inputs=True) for _ in range(2)]
+            pstreams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(2)]
+            pouts = [planes["out"]] + [torch.zeros_like(planes["out"]) for _ in range(2)]
+            for phase in range(2):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(nleg * 3 if phase else 9):
+                    with torch.cuda.stream(pstreams[i % 3]):
+                        pipes[i % 3].mBackBuffer = pouts[i % 3]
+                        pipes[i % 3].Draw(row0, rows)
+                torch.cuda.synchronize()
+                t_thr = (time.perf_counter() - t1) / (nleg * 3) * 1e3
+            if not (torch.equal(pouts[0], pouts[1]) and torch.equal(pouts[0], pouts[2])):
+                raise SystemExit("bench.py: the frame pipelines disagree")      # same inputs, same kernels: must be the same bytes
+            legs["throughput_3_in_flight"] = dict(leg(t_thr, W * H), note="three pipelines on three streams, each with private copies of all input planes")
+            del pipes, pouts
+        # (b) the evidently intended PCF: 2.5-texel rotated Poisson disc, 16 distinct taps per cascade (Common.hlsl:305 with float division)
+        if args.pcf == "literal":
+            a2 = new_app(radius=lib.crychic_pcf_search_radius(args.shadow_dim, 0))
+            a2.mBackBuffer = torch.zeros_like(planes["out"])
+            wall, med = frame_stats(a2, row0, rows, nleg)
+            a2.set_profiling(True)
+            a2.Draw(row0, rows)
+            lt = a2.last_pass_times()["light_ms"]
+            a2.set_profiling(False)
+            legs["pcf_intended"] = dict(leg(wall, W * H), frame_ms_median_hipevent=round(med, 4), light_ms=round(lt, 4))
+            del a2
+        # (c) a camera pitched down until every pixel is covered: no sky, every G-buffer texel is read
+        if args.camera == "reference":
+            args.camera = "covered"
+            cplanes = scene.make_scene(W, H, shadow_dim=args.shadow_dim, cube_dim=args.cube_dim, device=str(dev),
+                                       consts=scene.Constants(W, H, args.shadow_dim, cam=bench_camera(args)))
+            args.camera = "reference"
+            a3 = new_app(scene_planes=cplanes)
+            a3.mBackBuffer = torch.zeros_like(planes["out"])
+            wall, med = frame_stats(a3, row0, rows, nleg)
+            a3.set_profiling(True)
+            acc3 = {"ssao_ms": 0.0, "blur_ms": 0.0, "light_ms": 0.0}
+            for _ in range(10):
+                a3.Draw(row0, rows)
+                t = a3.last_pass_times()
+                for k in acc3:
+                    acc3[k] += t[k] / 10
+            a3.set_profiling(False)
+            ccov = float(((cplanes["depth"].to(torch.int64) & 0xFFFFFF) != 0xFFFFFF).float().mean())
+            legs["camera_covered"] = dict(leg(wall, W * H), frame_ms_median_hipevent=round(med, 4), covered_pixel_fraction=round(ccov, 4),
+                                          pass_ms={k: round(v, 4) for k, v in acc3.items()},
+                                          light_hbm_frac=round(52.5 * W * H / (acc3["light_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
+            del a3, cplanes
 
     # ---- per-pass timing of the same workload (HIP events recorded by the library on the launch stream) ----
     app.set_profiling(True)
@@ -714,12 +799,22 @@ def main():
                             "bound": c.get("bound")})
             return row
 
-        kernels = [kernel_row("ssao_kernel", acc["ssao_ms"], 6.5, "ssao"),
-                   kernel_row("blur sweeps x%d" % (2 * bc), acc["blur_ms"], 7.0 * 2 * bc, "blur"),
+        kernels = [kernel_row("SSAO pass (depth_pairs_kernel + ssao_kernel)", acc["ssao_ms"], 6.5, "ssao"),
+                   kernel_row("blur, %d sweeps (blur_pair_kernel + blur_replay_fused_kernel)" % (2 * bc), acc["blur_ms"], 7.0 * 2 * bc, "blur"),
                    kernel_row("light_kernel", acc["light_ms"], 52.5, "light")]
         traffic = None
         if pmc and all(k in pmc for k in ("ssao", "blur", "light")):
             traffic = int(sum(pmc[k]["hbm_bytes_per_launch"] for k in ("ssao", "blur", "light")))
+        # The dominant kernel, two ways: by the formula's letter (52.5 B for every pixel of the launch) and on the bytes the launch
+        # really needs (a sky pixel reads its 4-byte depth texel and writes 4 bytes, nothing of the G-buffer).
+        strip_cov = float(((planes["depth"][row0:row0 + rows].to(torch.int64) & 0xFFFFFF) != 0xFFFFFF).float().mean())
+        light_s = acc["light_ms"] * 1e-3
+        needed = (strip_cov * 52.5 + (1.0 - strip_cov) * 8.0) * strip_px
+        dominant = {"kernel": "light_kernel", "ms": round(acc["light_ms"], 4), "algorithmic_MB": round(52.5 * strip_px / 1e6, 1),
+                    "frac": round(52.5 * strip_px / light_s / 1e9 / HBM_PEAK_GBS, 4),
+                    "needed_MB_on_shaded_pixels": round(needed / 1e6, 1),
+                    "frac_on_shaded_pixels": round(needed / light_s / 1e9 / HBM_PEAK_GBS, 4)}
+        frame_s = dt / args.steps
         out = {
             "metric": "Mpixels/s for G-buffer->SSAO+blur->deferred PBR lighting at 4K",
             "value": round(npx * args.steps / dt / 1e6, 2),
@@ -738,23 +833,33 @@ def main():
                        "launcher": os.environ.get("CRYCHIC_BENCH_LAUNCHER", "external (torch.distributed.run)" if world > 1 else "direct"),
                        "sharding": ("%s row strips x%d" % (args.partition, world)) if world > 1 else "single GPU",
                        "partition": args.partition if use_dist else None,
-                       "exchange": exchange_kind, "exchange_verified": exchange_ok, "frames_in_flight": nflight,
-                       "one_frame_at_a_time": serial,
+                       "exchange": exchange_kind, "exchange_verified": exchange_ok,
+                       "frames_in_flight": nflight,          # 1: `value` is K frames one at a time on one stream
+                       "frame_ms_median_hipevent": round(frame_ms_median, 4),      # median of per-frame HIP-event times, same workload
                        "strip_rows": rows, "strip_plan": [b[1] for b in bounds] if bounds and world > 1 else None,
                        "strip_only": args.strip or None,
                        "point_lights": args.point_lights * args.point_lights,
                        "covered_pixel_fraction": round(covered, 4),
                        "frame_algorithmic_MB": round(frame_bytes / 1e6, 1),
-                       "pass_ms": {k: round(v, 4) for k, v in acc.items()},      # one frame at a time on one stream (latency view)
+                       "pass_ms": {k: round(v, 4) for k, v in acc.items()},      # HIP events recorded by the library around each pass
+                       # informational legs measured in this same run (N = 1); none of them is `value`
+                       "throughput_3_in_flight": legs.get("throughput_3_in_flight"),
+                       "pcf_intended": legs.get("pcf_intended"),
+                       "camera_covered": legs.get("camera_covered"),
                        "producer_passes_ms": producer_ms,
                        # what one rank spends on a frame end to end: its producers (shadow cascades whole, G-buffer for its strip) + the step
                        "frame_ms_incl_producers_rank0": (round(dt / args.steps * 1e3 + producer_ms["shadow_4x%d" % args.shadow_dim]
                                                                + producer_ms["normals_depth+gbuffer"], 3) if producer_ms else None)},
             # Frame level per SURVEY.md 8d: algorithmic bytes of the whole frame / measured frame time (N = 1: this GPU's HBM;
-            # N > 1: the aggregate over N GPUs against N x peak).  `traffic`: HBM bytes per frame from the committed PMC passes
-            # (2*FETCH_SIZE + WRITE_SIZE, gfx950 correction), null unless they were taken on exactly these kernel sources.
+            # N > 1: the aggregate over N GPUs against N x peak).  `traffic`: HBM bytes per frame (2*FETCH_SIZE + WRITE_SIZE, gfx950
+            # correction) from the COMMITTED rocprofv3 PMC passes named by traffic_source -- counters cannot be collected inside this
+            # process -- null unless they were taken on exactly these kernel sources and this workload; frac_by_traffic prices the
+            # frame on those bytes instead of the algorithmic ones.
             "roofline": {"scope": "frame", "bound": "hbm", "achieved": round(frame_gbs, 1), "peak": HBM_PEAK_GBS * world,
                          "unit": "GB/s", "frac": round(frame_gbs / (HBM_PEAK_GBS * world), 4), "traffic": traffic,
+                         "traffic_source": ("committed profile %s (kernel sources %s)" % (os.path.relpath(PMC_PROFILE, ROOT), kernel_source_hash())) if traffic else None,
+                         "frac_by_traffic": round(traffic / frame_s / 1e9 / (HBM_PEAK_GBS * world), 4) if traffic else None,
+                         "dominant_kernel": dominant,
                          "kernels": kernels},
         }
         if world == 1 and not args.no_cpu_baseline:

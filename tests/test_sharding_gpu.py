@@ -132,11 +132,16 @@ def test_bench_json_contract(built_lib):
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0 and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
     assert "traffic" in rf and rf["achieved"] > 0 and rf["scope"] == "frame"
     assert rf["traffic"] is None                      # not the workload the committed PMC passes were taken on
-    assert [k["kernel"].split()[0] for k in rf["kernels"]] == ["ssao_kernel", "blur", "light_kernel"]
-    # N = 1 default: three frames in flight (the reference's gNumFrameResources), with the same K frames timed one at a time beside it
-    assert out["config"]["frames_in_flight"] == 3
-    serial = out["config"]["one_frame_at_a_time"]
-    assert serial["ms_per_frame"] > 0 and serial["Mpixels_per_s"] > 0 and 0 < serial["hbm_roofline_frac"] < 1
+    assert [k["kernel"].split()[0].rstrip(",") for k in rf["kernels"]] == ["SSAO", "blur", "light_kernel"]
+    assert rf["traffic_source"] is None and rf["frac_by_traffic"] is None
+    dk = rf["dominant_kernel"]
+    assert dk["kernel"] == "light_kernel" and 0 < dk["frac_on_shaded_pixels"] <= dk["frac"] < 1
+    # N = 1 default: one frame at a time, with the labelled legs of the same run beside it
+    cfg = out["config"]
+    assert cfg["frames_in_flight"] == 1 and cfg["frame_ms_median_hipevent"] > 0
+    for name in ("throughput_3_in_flight", "pcf_intended", "camera_covered"):
+        assert cfg[name]["ms_per_frame"] > 0 and cfg[name]["Mpixels_per_s"] > 0 and 0 < cfg[name]["hbm_roofline_frac"] < 1, name
+    assert cfg["camera_covered"]["covered_pixel_fraction"] > 0.999 and cfg["pcf_intended"]["light_ms"] > 0
     assert all(k["ms"] > 0 and k["achieved_GBs"] > 0 for k in rf["kernels"])
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Mpixels/s" and isinstance(cb["sample"], str)
