@@ -531,6 +531,9 @@ def main():
         sn, sr = (int(v) for v in args.strip.split(":"))
         row0, rows = plan[sr] if plan else sharding.strip_rows(H, sn, sr)
         bounds = plan
+    elif args.plan_rehearsal and plan:        # no exchange to verify: the measured plan is what the ranks render
+        bounds = plan
+        row0, rows = plan[rank]
 
     # Frames in flight: 1 by default -- one frame at a time on one stream, the metric's definition (the reference's
     # frames go through one direct queue over one set of targets).  More is a labelled throughput experiment: further pipelines

@@ -96,10 +96,10 @@ int ssao_compute_impl(const crychic_ssao_constants* cb, const void* normal, cons
     if (afterSsao) CRY_HIP(hipEventRecord(afterSsao, stream));
     for (int i = 0; i < cry::blur_chain_launches(blurCount); ++i) {
         const cry::BlurStep s = cry::blur_chain_step(blurCount, row0, rows, h2, i);
-        if (s.iterations == 0)      // a pixel's value after the frame's sweeps depends on inputs within 5 pixels per iteration
+        if (i == 0)      // a pixel's value after the frame's sweeps depends on inputs within 5 pixels per iteration
             CRY_HIP(cry::launch_blur_pair(*cb, edge, planes[s.in], planes[s.out], W, H, s.row0, s.rows, blurCount > 1, stamp, 5 * blurCount, r0, rn, stream));
         else
-            CRY_HIP(cry::launch_blur_replay_fused(*cb, edge, planes[s.in], planes[s.out], W, H, s.row0, s.rows, s.iterations, stamp, stream));
+            CRY_HIP(cry::launch_blur_replay(*cb, edge, planes[s.in], planes[s.out], W, H, s.row0, s.rows, stamp, stream));
     }
     return 0;
 }

@@ -1,22 +1,20 @@
-// blur_tiles.hpp -- workgroup-level bodies of the two blur launches of Ssao::ComputeSsao (Ssao.cpp:231-293 issues
-// 2 * blurCount draws of Shaders/SsaoBlur.hlsl:85-146; here the whole chain is two launches):
+// blur_tiles.hpp -- workgroup-level bodies of the blur launches of Ssao::ComputeSsao (Ssao.cpp:231-293 issues
+// 2 * blurCount draws of Shaders/SsaoBlur.hlsl:85-146; here one launch per iteration):
 //
-//   blur_pair_tile          iteration 0: the horizontal AND the vertical sweep of one 64 x 16 tile.  The horizontal results of
-//                           the tile's rows plus a 5-row apron stay in LDS (quantised to R16_UNORM and decoded again exactly as
-//                           the round trip through the ambient map does) and feed the vertical sweep; both sweeps record their
-//                           tap decisions (ssao_core.hpp EdgePlane::mask_* / total_*).
-//   blur_replay_fused_tile  iterations 1 .. k (k <= 3) of one tile in one go: the tile plus an apron of 5 k pixels is staged
-//                           once, every iteration replays the recorded decisions on a region that shrinks by 5 pixels per side,
-//                           and only the tile itself is written back.  Redundant apron work buys the absence of any exchange
-//                           between tiles, hence of launches between iterations.
+//   blur_pair_tile    iteration 0: the horizontal AND the vertical sweep of one 64 x 16 tile.  The horizontal results of the
+//                     tile's rows plus a 5-row apron stay in LDS (quantised to R16_UNORM and decoded again exactly as the round
+//                     trip through the ambient map does) and feed the vertical sweep; both sweeps record their tap decisions
+//                     (ssao_core.hpp EdgePlane::mask_*).
+//   blur_replay_tile  a later iteration of one tile, both sweeps, replaying the recorded decisions: ambient values and masks of
+//                     the tile + apron are staged in one burst of loads, the sweeps touch only LDS, and rows whose whole window
+//                     is 1.0 skip their taps.
 //
 // Tiles whose whole neighbourhood came out of the SSAO pass as 65535 ("unoccluded tiles", ssao_core.hpp) are settled by the first
-// launch (it writes 65535 and a per-tile flag) and cost the second launch one scalar load.  In the benchmark frame that is three
-// tiles out of four.
+// launch (it writes 65535 and a per-tile flag) and cost the later launches one scalar load.
 //
-// The bodies are host+device text over a `Block` (thread id, block size, barrier, block-wide vote): the kernels instantiate
-// them with the real workgroup (kernels.hip BlockDev), tests/hostsim runs the very same text with one sequential "thread"
-// (BlockSeq) against the oracle's sweep-by-sweep chain.  Every output bit equals the per-sweep kernels': same per-pixel
+// The bodies are host+device text over a `Block` (thread id, block size, barrier, block-wide vote, wavefronts): the kernels
+// instantiate them with the real workgroup (kernels.hip BlockDev), tests/hostsim runs the very same text with one sequential
+// "thread" (BlockSeq) against the oracle's sweep-by-sweep chain.  Every output bit equals the per-sweep kernels': same per-pixel
 // functions (blur_pixel_full / blur_pixel_replay), same operands, same order.
 #pragma once
 #include "ssao_core.hpp"
@@ -24,18 +22,15 @@
 namespace cry {
 
 constexpr int kBlurTileW = 64, kBlurTileH = 16, kBlurRadius = 5;
-constexpr int kBlurMaxFused = 3;                                        // replay iterations per launch (LDS: 2 x 94 x 46 floats)
-constexpr int kBlurPairSW = kBlurTileW + 2 * kBlurRadius;               // staged width of the pair launch: 74
+constexpr int kBlurPairSW = kBlurTileW + 2 * kBlurRadius;               // staged width: 74
 constexpr int kBlurPairSH = kBlurTileH + 2 * kBlurRadius;               // staged height: 26
-constexpr int kBlurFusedMaxW = kBlurTileW + 2 * kBlurRadius * kBlurMaxFused;    // 94
-constexpr int kBlurFusedMaxH = kBlurTileH + 2 * kBlurRadius * kBlurMaxFused;    // 46
 
 // ---- the launch plan of Ssao::ComputeSsao's blur chain (shared by api.cpp and tests/hostsim) -----------------------------------
-// Each launch reads one ambient plane and writes the other (never in place: a tile's apron is its neighbours' output):
-// iteration 0 as one H + V launch that records the tap decisions, then the remaining iterations in launches of up to
-// kBlurMaxFused, replayed.  The final map has to be ambient0 (Ssao.cpp:75-78), so the planes alternate backwards from there:
-// with an odd number of launches the SSAO pass itself writes ambient1.  Tiles the first launch settles as unoccluded hold 65535
-// in BOTH planes from then on (the SSAO pass wrote one, the first launch the other), so later launches neither read nor write them.
+// One launch per iteration, each reading one ambient plane and writing the other (never in place: a tile's apron is its
+// neighbours' output): iteration 0 records the tap decisions, the others replay them.  The final map has to be ambient0
+// (Ssao.cpp:75-78), so the planes alternate backwards from there: with an odd blurCount the SSAO pass itself writes ambient1.
+// Tiles the first launch settles as unoccluded hold 65535 in BOTH planes from then on (the SSAO pass wrote one, the first launch
+// the other), so later launches neither read nor write them.
 // Rows: the caller is owed half-res rows [row0, row0 + rows) of the final map; a vertical sweep reaches 5 rows (gBlurRadius,
 // SsaoBlur.hlsl:48), so every earlier stage is computed on 5 more rows per remaining iteration (a halo recomputed, not exchanged).
 CRY_HD void clamp_rows(uint32_t limit, int64_t lo, int64_t hi, uint32_t* row0, uint32_t* rows)
@@ -46,31 +41,18 @@ CRY_HD void clamp_rows(uint32_t limit, int64_t lo, int64_t hi, uint32_t* row0, u
     *row0 = (uint32_t)lo;
     *rows = (uint32_t)(hi - lo);
 }
-CRY_HD int blur_chain_launches(int blurCount)
-{
-    return blurCount > 0 ? 1 + (blurCount - 1 + kBlurMaxFused - 1) / kBlurMaxFused : 0;
-}
+CRY_HD int blur_chain_launches(int blurCount) { return blurCount > 0 ? blurCount : 0; }
 CRY_HD int blur_chain_ssao_plane(int blurCount) { return blur_chain_launches(blurCount) & 1; }      // 0 = ambient0, 1 = ambient1
 struct BlurStep {
-    int iterations;            // 0: the pair launch (iteration 0); k > 0: k replayed iterations
     int in, out;               // plane indices
     uint32_t row0, rows;       // rows of `out` the launch owes
 };
-CRY_HD BlurStep blur_chain_step(int blurCount, uint32_t row0, uint32_t rows, uint32_t h2, int i)
+CRY_HD BlurStep blur_chain_step(int blurCount, uint32_t row0, uint32_t rows, uint32_t h2, int i)      // i = iteration, 0 .. blurCount - 1
 {
     BlurStep s;
-    const int in = (blur_chain_ssao_plane(blurCount) + i) & 1;
-    s.in = in;
-    s.out = in ^ 1;
-    int itersAfter = blurCount - 1;               // blur iterations still to run after this launch
-    s.iterations = 0;
-    int left = blurCount - 1;
-    for (int l = 1; l <= i; ++l) {
-        const int launchesLeft = (left + kBlurMaxFused - 1) / kBlurMaxFused;
-        s.iterations = (left + launchesLeft - 1) / launchesLeft;        // spread evenly: 4 = 2 + 2, not 3 + 1 (apron work grows with k)
-        left -= s.iterations;
-        itersAfter = left;
-    }
+    s.in = (blur_chain_ssao_plane(blurCount) + i) & 1;
+    s.out = s.in ^ 1;
+    const int itersAfter = blurCount - 1 - i;
     clamp_rows(h2, (int64_t)row0 - 5 * itersAfter, (int64_t)row0 + rows + 5 * itersAfter, &s.row0, &s.rows);
     return s;
 }
@@ -90,13 +72,23 @@ CRY_HD bool blur_weights_positive(const crychic_ssao_constants& cb)
     return true;
 }
 
-// One sequential "thread" standing in for the workgroup (host builds: tests/hostsim).
+// One sequential "thread" standing in for the workgroup (host builds: tests/hostsim).  Besides the flat view (tid / size) a
+// block is a set of WAVEFRONTS that each take whole rows of a tile: lanes(f) runs f(l) for the wavefront's lanes l = 0 .. 63
+// (the host loops over them, accumulating into whatever f captures; a device lane runs its own), wave_all(p) is the AND of p
+// over the wavefront's lanes.
 struct BlockSeq {
+    static constexpr int kLanes = 64;         // lanes whose private values one host "thread" has to hold
     CRY_HD int tid() const { return 0; }
     CRY_HD int size() const { return 1; }
     CRY_HD void sync() const {}
     CRY_HD bool all(bool p) const { return p; }
     CRY_HD bool any(bool p) const { return p; }
+    CRY_HD int wave() const { return 0; }
+    CRY_HD int waves() const { return 1; }
+    template <class F> CRY_HD void lanes(F f) const { for (int l = 0; l < 64; ++l) f(l); }
+    CRY_HD bool wave_all(bool p) const { return p; }
+    CRY_HD bool wave_leader() const { return true; }
+    CRY_HD void wave_sync() const {}         // device: orders a wavefront's LDS writes before its other lanes' reads of them
 };
 
 struct BlurTileArgs {
@@ -129,13 +121,13 @@ CRY_HD void blur_tile_fill_ones(int tid, int n, const BlurTileArgs& a)
 }
 
 // Iteration 0 of the blur for one tile: H sweep of rows y0 - 5 .. y0 + 20 into LDS, V sweep of the tile from it.
-// RECORD: also store both sweeps' tap decisions and totals, and the tile's flag.  stamp != 0: the unoccluded-tile exit may be
+// RECORD: also store both sweeps' tap decisions and the tile's flag.  stamp != 0: the unoccluded-tile exit may be
 // taken -- the SSAO pass of THIS frame wrote the unoccluded-wavefront map for half-res rows [ssaoRow0, ssaoRow1) with that stamp
 // (a word of the map is only ever looked at inside those rows, where it was written this frame: stale contents cannot matter).
-// s_nz: kBlurPairSW * kBlurPairSH entries; s_a: the same count; s_mid: kBlurTileW * kBlurPairSH.
+// s_nz: kBlurPairSW * kBlurPairSH entries; s_a: the same count; s_mid: kBlurTileW * kBlurPairSH; s_hmask: kBlurTileW * kBlurTileH.
 template <bool RECORD, class Block>
 CRY_HD void blur_pair_tile(const Block& blk, const BlurTileArgs& a, uint32_t stamp, int onesMargin, int ssaoRow0, int ssaoRow1,
-                           f4a* s_nz, float* s_a, float* s_mid)
+                           f4a* s_nz, float* s_a, float* s_mid, uint16_t* s_hmask)
 {
     constexpr int SW = kBlurPairSW, SH = kBlurPairSH, R = kBlurRadius;
     const int tid = blk.tid(), n = blk.size();
@@ -165,10 +157,7 @@ CRY_HD void blur_pair_tile(const Block& blk, const BlurTileArgs& a, uint32_t sta
             if (x < a.w2 && y >= a.row0 && y < a.row1) {
                 const uint32_t p = (uint32_t)y * (uint32_t)a.w2 + (uint32_t)x;
                 a.out[p] = (uint16_t)0xFFFFu;
-                if (RECORD) {
-                    a.e.mask_h[p] = (uint16_t)(1u << 5); a.e.total_h[p] = a.w[5];
-                    a.e.mask_v[p] = (uint16_t)(1u << 5); a.e.total_v[p] = a.w[5];
-                }
+                if (RECORD) a.e.masks[p] = (1u << 5) | (1u << 21);
             }
         }
         return;
@@ -194,12 +183,7 @@ CRY_HD void blur_pair_tile(const Block& blk, const BlurTileArgs& a, uint32_t sta
                 return BlurTap{ f3{ q.x, q.y, q.z }, q.w, s_a[idx] };
             });
             s_mid[k] = unorm16_to_float(o.value);
-            const int y = a.y0 - R + ly;
-            if (RECORD && ly >= R && ly < R + kBlurTileH && y >= a.row0 && y < a.row1) {
-                const uint32_t p = (uint32_t)y * (uint32_t)a.w2 + (uint32_t)x;
-                a.e.mask_h[p] = (uint16_t)o.mask;
-                a.e.total_h[p] = o.total;
-            }
+            if (RECORD && ly >= R && ly < R + kBlurTileH) s_hmask[k - R * kBlurTileW] = (uint16_t)o.mask;      // joins the vertical mask below
         }
     }
     blk.sync();
@@ -225,100 +209,111 @@ CRY_HD void blur_pair_tile(const Block& blk, const BlurTileArgs& a, uint32_t sta
             });
             const uint32_t p = (uint32_t)y * (uint32_t)a.w2 + (uint32_t)x;
             a.out[p] = (uint16_t)o.value;
-            if (RECORD) { a.e.mask_v[p] = (uint16_t)o.mask; a.e.total_v[p] = o.total; }
+            if (RECORD) a.e.masks[p] = (uint32_t)s_hmask[k] | (o.mask << 16);
         }
     }
 }
 
-// Entries of rows [r0, r1) x columns [c0, c1) of a staged region that lie outside the map take the value of the map position
-// CLAMP addressing gives them (which lies inside the same ranges: the ranges always contain the tile).
-CRY_HD void blur_region_replicate(int tid, int n, float* buf, int RW, int xb, int yb, int w2, int h2, int c0, int c1, int r0, int r1)
-{
-    const int cw = c1 - c0, total = cw * (r1 - r0);
-    const float rcw = 1.0f / (float)cw;
-    for (int i = tid; i < total; i += n) {
-        int ry, rx;
-        divmod_small(i, cw, rcw, ry, rx);
-        const int lx = c0 + rx, ly = r0 + ry, xi = xb + lx, yi = yb + ly;
-        if ((uint32_t)xi >= (uint32_t)w2 || (uint32_t)yi >= (uint32_t)h2)
-            buf[ly * RW + lx] = buf[(clampi(yi, 0, h2 - 1) - yb) * RW + clampi(xi, 0, w2 - 1) - xb];
-    }
-}
-
-// Iterations 1 .. k of the blur (k <= kBlurMaxFused) for one tile, replaying the decisions blur_pair_tile<true> recorded.
-// stamp != 0: tiles flagged with it by that launch are settled (65535 in `in` and in `out` already) and return at once.
-// s0, s1: (64 + 10 k) * (16 + 10 k) floats each.
+// A later iteration of the blur for one tile (both sweeps), replaying the decisions blur_pair_tile<true> recorded.
+// stamp != 0: tiles flagged with it by that launch are settled (65535 in `in` and in `out` already) and return early.
+// A wavefront owns rows of the staged region (rows CLAMPed into the map, like blur_pair_tile): it stages them -- ambient values
+// (s_in) and both sweeps' decision masks (s_mask: horizontal | vertical << 16, as recorded) of columns x0 - 5 .. x0 + 68, every load of its
+// rows issued before the first is used -- runs their horizontal sweep into s_mid, and after the barrier the vertical sweep of its
+// share of the tile's rows.  Rows whose whole window holds 1.0 skip their taps -- exact: a window of ones blurs to exactly 65535
+// whatever the recorded decisions are (the colour sum adds the very weights the recorded total was built from, in the same order,
+// so colour == total bit for bit and x * rcp(x) quantises to 65535 for the finite positive totals that finite positive weights
+// give: onesShortcut, checked by the launcher; false: nothing skips).
+// s_in, s_mask: kBlurPairSW * kBlurPairSH words; s_mid: kBlurTileW * kBlurPairSH; s_rows: 8 words.
+constexpr int kBlurMaxWaves = 8;
 template <class Block>
-CRY_HD void blur_replay_fused_tile(const Block& blk, const BlurTileArgs& a, int k, uint32_t stamp, bool onesShortcut, float* s0, float* s1)
+CRY_HD void blur_replay_tile(const Block& blk, const BlurTileArgs& a, uint32_t stamp, bool onesShortcut, float* s_in, uint32_t* s_mask,
+                             float* s_mid, uint32_t* s_rows)
 {
-    if (stamp != 0u && a.e.tiles[a.tileIndex] == stamp) return;
-    const int tid = blk.tid(), n = blk.size();
-    const int A = kBlurRadius * k, RW = kBlurTileW + 2 * A, RH = kBlurTileH + 2 * A;
-    const int xb = a.x0 - A, yb = a.y0 - A;
-    const float rRW = 1.0f / (float)RW;
-    bool allOne = onesShortcut;
-    for (int i = tid; i < RW * RH; i += n) {
-        int ly, lx;
-        divmod_small(i, RW, rRW, ly, lx);
-        const int cx = clampi(xb + lx, 0, a.w2 - 1), cy = clampi(yb + ly, 0, a.h2 - 1);     // ambient: point / CLAMP
-        const uint32_t raw = a.in[(uint32_t)cy * (uint32_t)a.w2 + (uint32_t)cx];
-        allOne = allOne && raw == 0xFFFFu;
-        s0[i] = unorm16_to_float(raw);
-    }
-    // A window whose ambient values are all 1.0 blurs to exactly 1.0 whatever the recorded decisions are: the colour sum adds the
-    // very weights the recorded total was built from, in the same order, so colour == total bit for bit and x * rcp(x) quantises
-    // to 65535 for the finite positive totals that finite positive weights give (onesShortcut, checked by the launcher).
-    if (blk.all(allOne)) {
-        blur_tile_fill_ones(tid, n, a);
-        return;
-    }
-    const bool edge = xb < 0 || xb + RW > a.w2 || yb < 0 || yb + RH > a.h2;
-    float* cur = s0;
-    float* nxt = s1;
-    for (int j = 1; j <= k; ++j) {
-        const int ih = kBlurRadius * (j - 1), iv = kBlurRadius * j;      // insets before / after this iteration
-        const int cw = RW - 2 * iv;
-        const float rcw = 1.0f / (float)cw;
-        // horizontal sweep: columns [iv, RW - iv), rows [ih, RH - ih)     cur -> nxt
-        for (int i = tid; i < cw * (RH - 2 * ih); i += n) {
-            int ry, rx;
-            divmod_small(i, cw, rcw, ry, rx);
-            const int lx = iv + rx, ly = ih + ry, xi = xb + lx, yi = yb + ly;
-            if ((uint32_t)xi < (uint32_t)a.w2 && (uint32_t)yi < (uint32_t)a.h2) {
-                const uint32_t p = (uint32_t)yi * (uint32_t)a.w2 + (uint32_t)xi;
-                const float* row = cur + ly * RW + lx - kBlurRadius;
-                const uint32_t v = blur_pixel_replay(a.w, a.e.mask_h[p], a.e.total_h[p], [&](int t) { return row[t]; });
-                nxt[ly * RW + lx] = unorm16_to_float(v);
-            }
-        }
-        blk.sync();
-        if (edge) {
-            blur_region_replicate(tid, n, nxt, RW, xb, yb, a.w2, a.h2, iv, RW - iv, ih, RH - ih);
-            blk.sync();
-        }
-        // vertical sweep: columns [iv, RW - iv), rows [iv, RH - iv)       nxt -> cur, or -> out for the last iteration (the tile)
-        for (int i = tid; i < cw * (RH - 2 * iv); i += n) {
-            int ry, rx;
-            divmod_small(i, cw, rcw, ry, rx);
-            const int lx = iv + rx, ly = iv + ry, xi = xb + lx, yi = yb + ly;
-            if ((uint32_t)xi < (uint32_t)a.w2 && (uint32_t)yi < (uint32_t)a.h2) {
-                const uint32_t p = (uint32_t)yi * (uint32_t)a.w2 + (uint32_t)xi;
-                const float* col = nxt + (ly - kBlurRadius) * RW + lx;
-                const uint32_t v = blur_pixel_replay(a.w, a.e.mask_v[p], a.e.total_v[p], [&](int t) { return col[t * RW]; });
-                if (j == k) {
-                    if (yi >= a.row0 && yi < a.row1) a.out[p] = (uint16_t)v;
-                } else {
-                    cur[ly * RW + lx] = unorm16_to_float(v);
+    constexpr int SW = kBlurPairSW, SH = kBlurPairSH, R = kBlurRadius, MAXR = 4;       // up to 4 staged rows per wavefront (8 wavefronts)
+    const int wv = blk.wave(), nw = blk.waves();
+    if (stamp != 0u && a.e.tiles[a.tileIndex] == stamp) return;      // (fetching speculatively past this test was measured: 1.4x slower)
+    uint32_t onesRows = 0u;                 // bit ly: the horizontal result of staged row ly is all ones (this wavefront's rows)
+    for (int base = wv; base < SH; base += nw * MAXR) {
+        // stage up to MAXR rows: lanes 0 .. 63 take columns 0 .. 63, lanes 0 .. 9 also columns 64 .. 73
+        bool ones[MAXR] = { true, true, true, true };
+        uint32_t raw[MAXR][2][Block::kLanes], mk[MAXR][2][Block::kLanes];         // per lane (kLanes = 1 on the device)
+        blk.lanes([&](int l) {
+            const int s = l % Block::kLanes;
+#pragma unroll
+            for (int m = 0; m < MAXR; ++m) {
+                const int ly = base + m * nw < SH ? base + m * nw : SH - 1;
+                const int cy = clampi(a.y0 - R + ly, 0, a.h2 - 1);
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int lx = h ? 64 + (l < 10 ? l : 9) : l;
+                    const uint32_t p = (uint32_t)cy * (uint32_t)a.w2 + (uint32_t)clampi(a.x0 - R + lx, 0, a.w2 - 1);   // ambient: point / CLAMP
+                    raw[m][h][s] = a.in[p];
+                    mk[m][h][s] = a.e.masks[p];
                 }
             }
-        }
-        if (j < k) {
-            blk.sync();
-            if (edge) {
-                blur_region_replicate(tid, n, cur, RW, xb, yb, a.w2, a.h2, iv, RW - iv, iv, RH - iv);
-                blk.sync();
+        });
+        blk.lanes([&](int l) {
+            const int s = l % Block::kLanes;
+#pragma unroll
+            for (int m = 0; m < MAXR; ++m) {
+                const int ly = base + m * nw;
+                if (ly < SH) {
+                    s_in[ly * SW + l] = unorm16_to_float(raw[m][0][s]);
+                    s_mask[ly * SW + l] = mk[m][0][s];
+                    bool o = raw[m][0][s] == 0xFFFFu;
+                    if (l < 10) {
+                        s_in[ly * SW + 64 + l] = unorm16_to_float(raw[m][1][s]);
+                        s_mask[ly * SW + 64 + l] = mk[m][1][s];
+                        o = o && raw[m][1][s] == 0xFFFFu;
+                    }
+                    ones[m] = ones[m] && o;
+                }
             }
+        });
+        // horizontal sweep (gHorizontalBlur = 1, Ssao.cpp:240) of the same rows: the wavefront reads what it wrote itself
+        blk.wave_sync();
+#pragma unroll
+        for (int m = 0; m < MAXR; ++m) {
+            const int ly = base + m * nw;
+            if (ly >= SH) continue;
+            const bool skip = onesShortcut && blk.wave_all(ones[m]);
+            bool outOnes = true;
+            blk.lanes([&](int l) {
+                if (a.x0 + l < a.w2) {
+                    float v = 1.0f;
+                    if (!skip) {
+                        const uint32_t mh = s_mask[ly * SW + l + R] & 0xFFFFu;
+                        const float* row = s_in + ly * SW + l;
+                        v = unorm16_to_float(blur_pixel_replay(a.w, mh, [&](int i) { return row[i]; }));
+                    }
+                    s_mid[ly * kBlurTileW + l] = v;
+                    outOnes = outOnes && v == 1.0f;
+                }
+            });
+            if (skip || (onesShortcut && blk.wave_all(outOnes))) onesRows |= 1u << ly;
         }
+    }
+    if (blk.wave_leader() && wv < kBlurMaxWaves) s_rows[wv] = onesRows;
+    blk.sync();
+    uint32_t hOnes = 0u;
+    for (int w = 0; w < nw && w < kBlurMaxWaves; ++w) hOnes |= s_rows[w];
+    // vertical sweep (gHorizontalBlur = 0, Ssao.cpp:241) of the tile
+    for (int ty = wv; ty < kBlurTileH; ty += nw) {
+        const int y = a.y0 + ty;
+        if (y < a.row0 || y >= a.row1) continue;
+        const bool skip = ((hOnes >> ty) & 0x7FFu) == 0x7FFu;          // staged rows ty .. ty + 10 = taps y - 5 .. y + 5
+        blk.lanes([&](int l) {
+            const int x = a.x0 + l;
+            if (x < a.w2) {
+                uint32_t v = 0xFFFFu;
+                if (!skip) {
+                    const uint32_t mv = s_mask[(ty + R) * SW + l + R] >> 16;
+                    const float* col = s_mid + ty * kBlurTileW + l;
+                    v = blur_pixel_replay(a.w, mv, [&](int i) { return col[i * kBlurTileW]; });
+                }
+                a.out[(uint32_t)y * (uint32_t)a.w2 + (uint32_t)x] = (uint16_t)v;
+            }
+        });
     }
 }
 

@@ -250,11 +250,25 @@ __global__ __launch_bounds__(256) void blur_kernel(crychic_ssao_constants cb, Ed
 
 // The workgroup behind the tile bodies of blur_tiles.hpp.
 struct BlockDev {
+    static constexpr int kLanes = 1;
     __device__ int tid() const { return (int)threadIdx.x; }
     __device__ int size() const { return (int)blockDim.x; }
     __device__ void sync() const { __syncthreads(); }
     __device__ bool all(bool p) const { return __syncthreads_and(p) != 0; }
     __device__ bool any(bool p) const { return __syncthreads_or(p) != 0; }
+    __device__ int wave() const { return (int)(threadIdx.x >> 6); }
+    __device__ int waves() const { return (int)(blockDim.x >> 6); }
+    template <class F> __device__ void lanes(F f) const { f((int)(threadIdx.x & 63u)); }
+    __device__ bool wave_all(bool p) const { return __builtin_amdgcn_ballot_w64(!p) == 0; }       // over the live lanes of the wavefront
+    __device__ bool wave_leader() const { return (threadIdx.x & 63u) == 0; }
+    // LDS operations of one wavefront execute in order; what has to be stopped is the compiler moving a lane's reads of OTHER
+    // lanes' entries above its own writes (different addresses to it)
+    __device__ void wave_sync() const
+    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
 };
 
 // Tiles of the blur launches lie on an absolute 64 x 16 grid of the half-res map (so that the flags one launch leaves per tile
@@ -262,8 +276,10 @@ struct BlockDev {
 __device__ __forceinline__ BlurTileArgs blur_tile_args(const crychic_ssao_constants& cb, const EdgePlane& edge, const uint16_t* in, uint16_t* out,
                                                        uint32_t W, uint32_t H, uint32_t row0, uint32_t row1)
 {
-    uint32_t bx, by;
-    tile_origin<4>(bx, by);
+    // Natural order: consecutive tiles of a row go to different XCDs.  The blur's planes are small (they live in L2 / Infinity
+    // Cache whatever the placement), but its cost is very uneven -- settled (sky, open ground) tiles cost nothing, the others sit
+    // in the lower half of the frame -- and stripes of tile rows per XCD left one XCD with twice the work of the others.
+    uint32_t bx = blockIdx.x, by = blockIdx.y;
     by += row0 / (uint32_t)kBlurTileH;
     BlurTileArgs a;
     a.w = &cb.BlurWeights[0][0];
@@ -290,19 +306,22 @@ __global__ __launch_bounds__(256) void blur_pair_kernel(crychic_ssao_constants c
     __shared__ f4a s_nz[kBlurPairSW * kBlurPairSH];
     __shared__ float s_a[kBlurPairSW * kBlurPairSH];
     __shared__ float s_mid[kBlurTileW * kBlurPairSH];
+    __shared__ uint16_t s_hmask[kBlurTileW * kBlurTileH];
     const BlurTileArgs a = blur_tile_args(cb, edge, in, out, W, H, row0, row1);
-    blur_pair_tile<RECORD>(BlockDev{}, a, stamp, onesMargin, ssaoRow0, ssaoRow1, s_nz, s_a, s_mid);
+    blur_pair_tile<RECORD>(BlockDev{}, a, stamp, onesMargin, ssaoRow0, ssaoRow1, s_nz, s_a, s_mid, s_hmask);
 }
 
-// Iterations 1 .. k of the blur in one launch (blur_tiles.hpp blur_replay_fused_tile).
-__global__ __launch_bounds__(512) void blur_replay_fused_kernel(crychic_ssao_constants cb, EdgePlane edge, const uint16_t* __restrict__ in,
-                                                                uint16_t* __restrict__ out, uint32_t W, uint32_t H, uint32_t row0, uint32_t row1,
-                                                                int k, uint32_t stamp, int onesShortcut)
+// A later iteration of the blur, both sweeps, replayed (blur_tiles.hpp blur_replay_tile): 8 wavefronts per tile.
+__global__ __launch_bounds__(512) void blur_replay_kernel(crychic_ssao_constants cb, EdgePlane edge, const uint16_t* __restrict__ in,
+                                                          uint16_t* __restrict__ out, uint32_t W, uint32_t H, uint32_t row0, uint32_t row1,
+                                                          uint32_t stamp, int onesShortcut)
 {
-    __shared__ float s0[kBlurFusedMaxW * kBlurFusedMaxH];
-    __shared__ float s1[kBlurFusedMaxW * kBlurFusedMaxH];
+    __shared__ float s_in[kBlurPairSW * kBlurPairSH];
+    __shared__ uint32_t s_mask[kBlurPairSW * kBlurPairSH];
+    __shared__ float s_mid[kBlurTileW * kBlurPairSH];
+    __shared__ uint32_t s_rows[kBlurMaxWaves];
     const BlurTileArgs a = blur_tile_args(cb, edge, in, out, W, H, row0, row1);
-    blur_replay_fused_tile(BlockDev{}, a, k, stamp, onesShortcut != 0, s0, s1);
+    blur_replay_tile(BlockDev{}, a, stamp, onesShortcut != 0, s_in, s_mask, s_mid, s_rows);
 }
 
 // ---- deferred lighting -----------------------------------------------------------------------------------------
@@ -505,16 +524,14 @@ hipError_t launch_blur_pair(const crychic_ssao_constants& cb, const void* edge_b
     return hipGetLastError();
 }
 
-hipError_t launch_blur_replay_fused(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out, uint32_t W,
-                                    uint32_t H, uint32_t row0, uint32_t rows, int iterations, uint32_t stamp, hipStream_t stream)
+hipError_t launch_blur_replay(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out, uint32_t W, uint32_t H,
+                              uint32_t row0, uint32_t rows, uint32_t stamp, hipStream_t stream)
 {
-    if (rows == 0 || iterations <= 0) return hipSuccess;
-    if (iterations > kBlurMaxFused) return hipErrorInvalidValue;
+    if (rows == 0) return hipSuccess;
     const EdgePlane e = edge_plane_carve(const_cast<void*>(edge_base), W, H);
     const int ones = blur_weights_positive(cb) ? 1 : 0;
     if (!ones) stamp = 0u;             // the pair launch settled no tile either
-    hipLaunchKernelGGL(blur_replay_fused_kernel, blur_tile_grid(W, row0, rows), dim3(512), 0, stream, cb, e, in, out, W, H, row0, row0 + rows,
-                       iterations, stamp, ones);
+    hipLaunchKernelGGL(blur_replay_kernel, blur_tile_grid(W, row0, rows), dim3(512), 0, stream, cb, e, in, out, W, H, row0, row0 + rows, stamp, ones);
     return hipGetLastError();
 }
 

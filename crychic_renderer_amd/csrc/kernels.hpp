@@ -21,16 +21,16 @@ hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, con
 hipError_t launch_blur(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out,
                        uint32_t W, uint32_t H, bool horizontal, uint32_t row0, uint32_t rows, hipStream_t stream);
 // Iteration 0 of the blur chain: horizontal + vertical sweep in one launch (in -> out, out != in); the rows are those of the
-// vertical sweep's output.  record: store both sweeps' tap decisions + totals and the per-tile flags for launch_blur_replay_fused.
+// vertical sweep's output.  record: store both sweeps' tap decisions and the per-tile flags for launch_blur_replay.
 // stamp (0 = no exit) / onesMargin / ssaoRow0, ssaoRows: the unoccluded-tile exit (blur_tiles.hpp) -- the SSAO pass of this frame
 // wrote the unoccluded-wavefront map with `stamp` for half-res rows [ssaoRow0, ssaoRow0 + ssaoRows).
 hipError_t launch_blur_pair(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out, uint32_t W, uint32_t H,
                             uint32_t row0, uint32_t rows, bool record, uint32_t stamp, int onesMargin, uint32_t ssaoRow0, uint32_t ssaoRows,
                             hipStream_t stream);
-// `iterations` (1 .. 3) further blur iterations in one launch, replaying what launch_blur_pair(record) stored (in -> out, out != in);
-// the rows are those owed after the last of them.  stamp: the one the pair launch ran with (its settled tiles return at once).
-hipError_t launch_blur_replay_fused(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out, uint32_t W,
-                                    uint32_t H, uint32_t row0, uint32_t rows, int iterations, uint32_t stamp, hipStream_t stream);
+// A later iteration of the chain (both sweeps), replaying what launch_blur_pair(record) stored (in -> out, out != in); the rows
+// are those owed after it.  stamp: the one the pair launch ran with (its settled tiles return at once).
+hipError_t launch_blur_replay(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out, uint32_t W, uint32_t H,
+                              uint32_t row0, uint32_t rows, uint32_t stamp, hipStream_t stream);
 
 hipError_t launch_light(const LightParams& P, const float* g0, const float* g1, const float* g2,
                         const uint32_t* depth, const uint16_t* ambient, const uint8_t* cube, uint8_t* out,

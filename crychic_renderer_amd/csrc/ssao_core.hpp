@@ -11,7 +11,7 @@ namespace cry {
 // Everything a blur tap needs besides the ambient value is a function of the half-res pixel only
 // (SsaoBlur.hlsl:109-111,121-123): the point-sampled normal and the linearised bilinear depth.  The SSAO
 // kernel already computes both for its own pixel, so it stores them once per frame:
-//   nrm  [h2][w2]  8 B  (the fp16 texel (2x+1, 2y+1) verbatim)   -- plus per-direction tap masks / totals, below
+//   nrm  [h2][w2]  8 B  (the fp16 texel (2x+1, 2y+1) verbatim)   -- plus per-direction tap masks, below
 //   vz   [h2][w2]  4 B  (view-space depth, fp32)
 //   gcol [h2]      8 B  normal texel (0, 2y+1): CLAMP target of every horizontal tap with x + i < 0
 //   grow [w2]      8 B  normal texel (2x+1, 0): CLAMP target of every vertical tap with y + i < 0
@@ -22,11 +22,8 @@ struct EdgePlane {
     u2* grow;
     // The accept/reject decision of every blur tap (SsaoBlur.hlsl:131-132) depends on geometry only, so it is the
     // same in all blurCount iterations.  The first sweep of each direction records the 11 decisions of a pixel as a
-    // bit mask and the resulting totalWeight; later sweeps of that direction replay them (blur_pixel_replay).
-    uint16_t* mask_h;
-    uint16_t* mask_v;
-    float* total_h;
-    float* total_v;
+    // bit mask; later sweeps of that direction replay them (blur_pixel_replay) -- the totalWeight follows from the mask.
+    uint32_t* masks;   // horizontal decisions | vertical decisions << 16
     const void* pairs; // DepthPairs plane (below), depth_pairs_bytes(W, H)
     uint32_t* geo;     // coarse geometry map (below "sky shortcut"), geo_map_bytes(W, H)
     uint32_t* ones;    // unoccluded-wavefront map (below "unoccluded tiles"), ones_map_bytes(W, H)
@@ -47,7 +44,7 @@ CRY_HD size_t depth_pairs_bytes(uint32_t W, uint32_t H) { return (size_t)(W + 4u
 CRY_HD size_t edge_plane_pairs_offset(uint32_t W, uint32_t H)
 {
     size_t w2 = W / 2, h2 = H / 2;
-    return (w2 * h2 * 24 + (w2 + h2) * 8 + 15) & ~(size_t)15;
+    return (w2 * h2 * 16 + (w2 + h2) * 8 + 15) & ~(size_t)15;
 }
 // Coarse geometry map: one word per cell of 128 x 32 depth texels, holding the frame stamp of the last frame in which the
 // cell contained a texel below the clear depth.  Cell cx covers texel columns [128 cx - 2, 128 cx + 126) -- the footprint of
@@ -92,11 +89,8 @@ CRY_HD EdgePlane edge_plane_carve(void* base, uint32_t W, uint32_t H)
     EdgePlane e;
     e.nrm = (u2*)b;                       // n * 8
     e.vz = (float*)(b + n * 8);           // n * 4
-    e.total_h = (float*)(b + n * 12);     // n * 4
-    e.total_v = (float*)(b + n * 16);     // n * 4
-    e.mask_h = (uint16_t*)(b + n * 20);   // n * 2
-    e.mask_v = (uint16_t*)(b + n * 22);   // n * 2
-    e.gcol = (u2*)(b + n * 24);           // h2 * 8
+    e.masks = (uint32_t*)(b + n * 12);    // n * 4
+    e.gcol = (u2*)(b + n * 16);           // h2 * 8
     e.grow = e.gcol + h2;                 // w2 * 8
     e.pairs = b + edge_plane_pairs_offset(W, H);
     e.geo = (uint32_t*)(b + edge_plane_geo_offset(W, H));
@@ -581,19 +575,23 @@ CRY_HD BlurOut blur_pixel_full(const float* __restrict__ w, Fetch fetch)
 template <class Fetch>
 CRY_HD uint32_t blur_pixel(const float* __restrict__ w, Fetch fetch) { return blur_pixel_full(w, fetch).value; }
 
-// The same pixel with the decisions replayed from a previous sweep of the same direction: identical float
-// operations in identical order, minus the normal / depth tests.  amb(i) returns the ambient value of tap i.
+// The same pixel with the decisions replayed from a previous sweep of the same direction: identical float operations in
+// identical order, minus the normal / depth tests.  amb(i) returns the ambient value of tap i.  The totalWeight is rebuilt from
+// the mask by the very additions blur_pixel_full made (+ w[i] for an accepted tap, + 0 for a rejected one, in loop order).
 template <class Amb>
-CRY_HD uint32_t blur_pixel_replay(const float* __restrict__ w, uint32_t mask, float total, Amb amb)
+CRY_HD uint32_t blur_pixel_replay(const float* __restrict__ w, uint32_t mask, Amb amb)
 {
     float color = w[5] * amb(5);
+    float total = w[5];
 #pragma unroll
     for (int i = 0; i < 11; ++i) {
         if (i == 5) continue;
         // weight or +0.0 by AND-ing the weight's bits with the sign-extended mask bit (v_bfe_i32 + v_and_b32); adding 0 * a
-        // leaves the sum bit-unchanged, see blur_pixel_full
+        // leaves the colour sum bit-unchanged, see blur_pixel_full
         const uint32_t keep = (uint32_t)(((int32_t)(mask << (31 - i))) >> 31);
-        color = fma(u2f(f2u(w[i]) & keep), amb(i), color);
+        const float wk = u2f(f2u(w[i]) & keep);
+        color = fma(wk, amb(i), color);
+        total = total + wk;
     }
     return float_to_unorm16(divf(color, total));
 }

@@ -184,7 +184,9 @@ void hs_blur_chain(const crychic_ssao_constants* cb, void* edge_base, uint16_t* 
     const bool positive = blur_weights_positive(*cb);        // as the launchers decide
     const uint32_t stamp = (use_exit && positive) ? g_stamp : 0u;
     std::vector<f4a> s_nz(kBlurPairSW * kBlurPairSH);
-    std::vector<float> s_a(kBlurPairSW * kBlurPairSH), s_mid(kBlurTileW * kBlurPairSH), s0(kBlurFusedMaxW * kBlurFusedMaxH), s1(kBlurFusedMaxW * kBlurFusedMaxH);
+    std::vector<float> s_a(kBlurPairSW * kBlurPairSH), s_mid(kBlurTileW * kBlurPairSH);
+    std::vector<uint32_t> s_mask(kBlurPairSW * kBlurPairSH), s_rows(kBlurMaxWaves);
+    std::vector<uint16_t> s_hmask(kBlurTileW * kBlurTileH);
     g_settled_tiles = 0;
     for (int i = 0; i < blur_chain_launches(blurCount); ++i) {
         const BlurStep st = blur_chain_step(blurCount, row0, rows, h2, i);
@@ -198,12 +200,12 @@ void hs_blur_chain(const crychic_ssao_constants* cb, void* edge_base, uint16_t* 
                 a.row0 = (int)st.row0; a.row1 = (int)(st.row0 + st.rows);
                 a.borderZ = ndc_to_view(*cb, 1.0f);
                 a.tileIndex = ty * blur_tiles_x(W) + tx;
-                if (st.iterations == 0) {
-                    if (blurCount > 1) blur_pair_tile<true>(BlockSeq{}, a, stamp, onesMargin, (int)sr0, (int)(sr0 + srn), s_nz.data(), s_a.data(), s_mid.data());
-                    else blur_pair_tile<false>(BlockSeq{}, a, stamp, onesMargin, (int)sr0, (int)(sr0 + srn), s_nz.data(), s_a.data(), s_mid.data());
+                if (i == 0) {
+                    if (blurCount > 1) blur_pair_tile<true>(BlockSeq{}, a, stamp, onesMargin, (int)sr0, (int)(sr0 + srn), s_nz.data(), s_a.data(), s_mid.data(), s_hmask.data());
+                    else blur_pair_tile<false>(BlockSeq{}, a, stamp, onesMargin, (int)sr0, (int)(sr0 + srn), s_nz.data(), s_a.data(), s_mid.data(), s_hmask.data());
                     if (blurCount > 1 && stamp != 0u && e.tiles[a.tileIndex] == stamp) ++g_settled_tiles;
                 } else {
-                    blur_replay_fused_tile(BlockSeq{}, a, st.iterations, stamp, positive, s0.data(), s1.data());
+                    blur_replay_tile(BlockSeq{}, a, stamp, positive, s_a.data(), s_mask.data(), s_mid.data(), s_rows.data());
                 }
             }
     }
