@@ -164,13 +164,26 @@ CRY_HD void blur_pair_tile(const Block& blk, const BlurTileArgs& a, uint32_t sta
     }
     // stage normal + depth + ambient of columns x0 - 5 .. x0 + 68, rows y0 - 5 .. y0 + 20 (rows CLAMPed into the map: a vertical
     // tap above / below the map reads the edge row's horizontal result)
-    for (int k = tid; k < SW * SH; k += n) {
-        int ly, lx;
-        divmod_small(k, SW, 1.0f / (float)SW, ly, lx);
-        const int cy = clampi(a.y0 - R + ly, 0, a.h2 - 1);
-        const BlurTap t = blur_fetch(a.e, a.in, a.borderZ, a.w2, a.h2, a.x0 - R + lx, cy);
-        s_nz[k] = f4a{ t.n.x, t.n.y, t.n.z, t.z };
-        s_a[k] = t.a;
+    // -- in batches whose loads are all issued (from CLAMPed, always valid positions) before the first is decoded
+    constexpr int U = 4;
+    for (int base = tid; base < SW * SH; base += n * U) {
+        BlurTapRaw raw[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = base + u * n < SW * SH ? base + u * n : SW * SH - 1;
+            int ly, lx;
+            divmod_small(k, SW, 1.0f / (float)SW, ly, lx);
+            raw[u] = blur_fetch_raw(a.e, a.in, a.w2, a.h2, a.x0 - R + lx, clampi(a.y0 - R + ly, 0, a.h2 - 1));
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int k = base + u * n;
+            if (k < SW * SH) {
+                const BlurTap t = blur_fetch_decode(raw[u], a.borderZ);
+                s_nz[k] = f4a{ t.n.x, t.n.y, t.n.z, t.z };
+                s_a[k] = t.a;
+            }
+        }
     }
     blk.sync();
     // horizontal sweep (gHorizontalBlur = 1, Ssao.cpp:240) of all staged rows

@@ -299,7 +299,7 @@ __device__ __forceinline__ BlurTileArgs blur_tile_args(const crychic_ssao_consta
 
 // Iteration 0 of the blur: horizontal + vertical sweep of a tile in one launch (blur_tiles.hpp blur_pair_tile).
 template <bool RECORD>
-__global__ __launch_bounds__(256) void blur_pair_kernel(crychic_ssao_constants cb, EdgePlane edge, const uint16_t* __restrict__ in,
+__global__ __launch_bounds__(512) void blur_pair_kernel(crychic_ssao_constants cb, EdgePlane edge, const uint16_t* __restrict__ in,
                                                         uint16_t* __restrict__ out, uint32_t W, uint32_t H, uint32_t row0, uint32_t row1,
                                                         uint32_t stamp, int onesMargin, int ssaoRow0, int ssaoRow1)
 {
@@ -517,7 +517,7 @@ hipError_t launch_blur_pair(const crychic_ssao_constants& cb, const void* edge_b
     // the unoccluded-tile exit needs finite positive weights (x * rcp(x) of a finite positive total) and the SSAO pass's map
     if (!blur_weights_positive(cb)) stamp = 0u;
     const dim3 grid = blur_tile_grid(W, row0, rows);
-#define CRY_LAUNCH_PAIR(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, cb, e, in, out, W, H, row0, row0 + rows, stamp, onesMargin, \
+#define CRY_LAUNCH_PAIR(K) hipLaunchKernelGGL(K, grid, dim3(512), 0, stream, cb, e, in, out, W, H, row0, row0 + rows, stamp, onesMargin, \
                                               (int)ssaoRow0, (int)(ssaoRow0 + ssaoRows))
     if (record) CRY_LAUNCH_PAIR(blur_pair_kernel<true>); else CRY_LAUNCH_PAIR(blur_pair_kernel<false>);
 #undef CRY_LAUNCH_PAIR

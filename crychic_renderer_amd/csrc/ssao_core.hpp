@@ -336,15 +336,16 @@ CRY_HD float ssao_cull_threshold(f3 nRaw, f3 p, float eps)
 }
 struct NoCull {
     static constexpr bool active = false;
-    CRY_HD bool operator()(int, int, float) const { return false; }
+    CRY_HD float cell(int, int) const { return 0.0f; }
 };
 struct ZminMap {
     static constexpr bool active = true;
     const float* cells; uint32_t pitch;                            // EdgePlane::zcull, zmin_map_cols(W)
-    CRY_HD bool operator()(int i0, int j0, float pzEps) const     // (i0, j0): top-left texel of the footprint, already in [-2, dim]
+    // the cell of the footprint whose top-left texel is (i0, j0), both already in [-2, dim]: inside the map for every clamped index
+    CRY_HD float cell(int i0, int j0) const
     {
-        const uint32_t cx = (uint32_t)(i0 + 2) >> 3, cy = (uint32_t)(j0 + 2) >> 3;      // inside the map for every clamped index
-        return load_at<float>(cells, (mul24(cy, pitch) + cx) * 4u) >= pzEps;          // NaN on either side: not culled
+        const uint32_t cx = (uint32_t)(i0 + 2) >> 3, cy = (uint32_t)(j0 + 2) >> 3;
+        return load_at<float>(cells, (mul24(cy, pitch) + cx) * 4u);
     }
 };
 
@@ -458,9 +459,11 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
         const v2f fy = v2f{ __builtin_fmaxf(ty.x - fly.x, 0.0f), __builtin_fmaxf(ty.y - fly.y, 0.0f) };
         const int i0a = texel_index(flx.x, W), j0a = texel_index(fly.x, H);
         const int i0b = texel_index(flx.y, W), j0b = texel_index(fly.y, H);
-        // tap culling: a tap whose footprint cannot return a surface in front of the pixel adds exactly +0
-        const bool ca = Cull::active && (q.z.x >= 1.0e-3f) && cull(i0a, j0a, pzEps);
-        const bool cb2 = Cull::active && (q.z.y >= 1.0e-3f) && cull(i0b, j0b, pzEps);
+        // tap culling: a tap whose footprint cannot return a surface in front of the pixel adds exactly +0.  Both lookups are
+        // issued unconditionally and together (one round trip; a NaN on either side of the comparison: not culled)
+        const float cellA = cull.cell(i0a, j0a), cellB = cull.cell(i0b, j0b);
+        const bool ca = Cull::active && (q.z.x >= 1.0e-3f) && (cellA >= pzEps);
+        const bool cb2 = Cull::active && (q.z.y >= 1.0e-3f) && (cellB >= pzEps);
         if (Cull::active) {
 #if defined(__HIP_DEVICE_COMPILE__)
             if (__builtin_amdgcn_ballot_w64(!(ca & cb2)) == 0) continue;      // the whole wavefront skips both taps
@@ -469,9 +472,11 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
             if (ca & cb2) continue;
 #endif
         }
-        float a00 = 1.0f, a10 = 1.0f, a01 = 1.0f, a11 = 1.0f, b00 = 1.0f, b10 = 1.0f, b01 = 1.0f, b11 = 1.0f;
-        if (!ca) depth.footprint(i0a, j0a, a00, a10, a01, a11);
-        if (!cb2) depth.footprint(i0b, j0b, b00, b10, b01, b11);
+        // Both footprints in one round trip as well: a culled lane fetches the plane's first footprint instead of its own (every
+        // culled lane of the wavefront the same line, so the gather it is spared stays spared) and never looks at it.
+        float a00, a10, a01, a11, b00, b10, b01, b11;
+        depth.footprint(ca ? -2 : i0a, ca ? -2 : j0a, a00, a10, a01, a11);
+        depth.footprint(cb2 ? -2 : i0b, cb2 ? -2 : j0b, b00, b10, b01, b11);
         const v2f t00{ a00, b00 }, t10{ a10, b10 }, t01{ a01, b01 }, t11{ a11, b11 };
         const v2f zndc = lerp2(lerp2(t00, t10, fx), lerp2(t01, t11, fx), fy);
         const v2f rz = B * rcp2(zndc - A);                                        // :164-165
@@ -526,22 +531,34 @@ struct BlurTap {
 
 // Fetch the edge data + ambient for half-res position (xi, yi), which may lie outside the map along the
 // sweep axis: normal CLAMPs in full-res texel space, depth takes the BORDER value, ambient CLAMPs.
-CRY_HD BlurTap blur_fetch(const EdgePlane& e, const uint16_t* __restrict__ amb, float borderZ, int w2, int h2,
-                          int xi, int yi)
+// In two halves, so that a caller can issue the loads of many positions before it decodes the first (blur_tiles.hpp).
+struct BlurTapRaw { u2 nrm; float vz; uint32_t amb; bool inside; };
+CRY_HD BlurTapRaw blur_fetch_raw(const EdgePlane& e, const uint16_t* __restrict__ amb, int w2, int h2, int xi, int yi)
 {
-    BlurTap t;
     const int cx = clampi(xi, 0, w2 - 1), cy = clampi(yi, 0, h2 - 1);
     const uint32_t idx = mul24((uint32_t)cy, (uint32_t)w2) + (uint32_t)cx;
     const u2* src = e.nrm + idx;                       // one load through a selected address (no divergent branches)
     src = (yi < 0) ? e.grow + cx : src;
     src = (xi < 0) ? e.gcol + cy : src;
-    const u2 nb = *src;
-    t.n = unpack_normal(nb);
-    const bool inside = ((uint32_t)xi < (uint32_t)w2) & ((uint32_t)yi < (uint32_t)h2);
-    const float vz = e.vz[idx];
-    t.z = inside ? vz : borderZ;
-    t.a = unorm16_to_float(amb[idx]);
+    BlurTapRaw r;
+    r.nrm = *src;
+    r.vz = e.vz[idx];
+    r.amb = amb[idx];
+    r.inside = ((uint32_t)xi < (uint32_t)w2) & ((uint32_t)yi < (uint32_t)h2);
+    return r;
+}
+CRY_HD BlurTap blur_fetch_decode(const BlurTapRaw& r, float borderZ)
+{
+    BlurTap t;
+    t.n = unpack_normal(r.nrm);
+    t.z = r.inside ? r.vz : borderZ;
+    t.a = unorm16_to_float(r.amb);
     return t;
+}
+CRY_HD BlurTap blur_fetch(const EdgePlane& e, const uint16_t* __restrict__ amb, float borderZ, int w2, int h2,
+                          int xi, int yi)
+{
+    return blur_fetch_decode(blur_fetch_raw(e, amb, w2, h2, xi, yi), borderZ);
 }
 
 // One output pixel from its 11 taps; fetch(i) returns tap i (i = 5 is the centre).  Accumulation order is the
