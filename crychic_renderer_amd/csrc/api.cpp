@@ -134,6 +134,7 @@ int fill_light_params(cry::LightParams& P, const crychic_pass_constants* cb, con
     P.pointLights = nullptr;
     P.numPointLights = 0;
     P.shadowWIsOne = cry::light_shadow_w_is_one(P.ShadowTransforms) ? 1u : 0u;
+    P.darkLights = cry::light_dark_mask(P.Lights, numDirLights);
     return 0;
 }
 

@@ -26,6 +26,7 @@ struct LightParams {
     const crychic_light* pointLights;   // extension (BASELINE configs[4]): NUM_POINT_LIGHTS lights in a device buffer
     uint32_t numPointLights;
     uint32_t shadowWIsOne;     // light_shadow_w_is_one(): every cascade's ShadowTransform has the w column (0, 0, 0, 1)
+    uint32_t darkLights;       // light_dark_mask(): bit i = directional light i has Strength (0, 0, 0) and a sane direction
 };
 
 constexpr uint32_t kMaxPointLights = 1024;   // tile masks live in LDS: 32 words
@@ -280,6 +281,38 @@ CRY_HD float ambient_linear_clamp(const uint16_t* __restrict__ a, uint32_t w2, u
     return ambient_resolve(ambient_fetch(a, w2, h2, u, v));
 }
 
+// ---- dark lights -------------------------------------------------------------------------------------------------------
+// A directional light whose Strength is exactly (0, 0, 0) -- the reference's own third light is one (CRYCHIC.cpp:863-864) -- adds
+// fma(scale * brdf, 0 * nDotl, result) to each channel (PBR.hlsl:104-105): result itself whenever scale * brdf and nDotl are
+// finite (x * 0 = +-0, and r + +-0 = r; a zero r can only change the sign of its zero, which no output can see: the tone map
+// takes +0 and -0 to the same 0, DeferredShading.hlsl:89-90).  light_dark_mask() picks such lights on the host; the pixel side
+// is light_dark_guard(): inputs bounded so that no term of GetBRDF (PBR.hlsl:45-70) can overflow or become NaN --
+//   roughness in [0.03, 10]: a^2 >= 9e-4 keeps NDF_GGX's denominator (nDoth^2 (a^2 - 1) + 1)^2 away from 0 (nDoth <= 1 + ulps:
+//     both vectors are normalised), D <= 400; k = (r + 1)^2 / 8 <= 15.2 keeps GeometrySchlickGGX's denominators positive for
+//     nDotl <= 1.002, G <= 1e6;
+//   |albedo|, |metalness| <= 16: f0, F <= 512, so F * fs <= 512 * (0.25 * 400 * 1e6 * 512 * 1e6) ~ 3e19;
+//   G-buffer position and normal finite (bounded position: the normalised view vector is finite), light direction finite with
+//     length in [0.5, 1.001] (host): every dot product is finite, nDotl <= 1.002.
+// A wavefront skips a dark light only if all its pixels pass the guard; otherwise it evaluates the light like any other.
+CRY_HD uint32_t light_dark_mask(const crychic_light* L, int n)
+{
+    uint32_t m = 0;
+    for (int i = 0; i < n && i < 32; ++i) {
+        const float* s = L[i].Strength;
+        const float* d = L[i].Direction;
+        const float len2 = d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+        if (s[0] == 0.0f && s[1] == 0.0f && s[2] == 0.0f && len2 >= 0.25f && len2 <= 1.002f) m |= 1u << i;       // NaN fails every test
+    }
+    return m;
+}
+CRY_HD bool light_dark_guard(f4a G0, f4a G1, f4a G2)
+{
+    const float pmax = 1.2676506e30f;
+    return (G1.w >= 0.03f) & (G1.w <= 10.0f) & (__builtin_fabsf(G1.x) <= 16.0f) & (__builtin_fabsf(G1.y) <= 16.0f) & (__builtin_fabsf(G1.z) <= 16.0f) &
+           (__builtin_fabsf(G0.w) <= 16.0f) & (__builtin_fabsf(G0.x) < pmax) & (__builtin_fabsf(G0.y) < pmax) & (__builtin_fabsf(G0.z) < pmax) &
+           (__builtin_fabsf(G2.x) < 3.0e38f) & (__builtin_fabsf(G2.y) < 3.0e38f) & (__builtin_fabsf(G2.z) < 3.0e38f);
+}
+
 // Point-light iteration policies of light_pixels (extension).
 struct NoPointLights {
     CRY_HD void operator()(f3, f3, float, float, f3, f3, f3&, bool, bool) const {}
@@ -409,9 +442,19 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
 
     const float shininess = (1.0f - roughness) * 1.0f;          // :84 (normalW.a == 1)
 
+    uint32_t dark = 0u;                                         // "dark lights" above
+    if (P.darkLights) {
+        bool ok = light_dark_guard(G0, G1, G2);
+#if defined(__HIP_DEVICE_COMPILE__)
+        ok = __builtin_amdgcn_ballot_w64(!ok) == 0;             // wave-uniform: the loop below stays converged
+#endif
+        dark = ok ? P.darkLights : 0u;
+    }
     f3 direct{ 0.0f, 0.0f, 0.0f };
-    for (int i = 0; i < P.numDirLights; ++i)                    // PBR.hlsl:99-106; shadowFactors[i>0] == 1 (:46-51)
+    for (int i = 0; i < P.numDirLights; ++i) {                  // PBR.hlsl:99-106; shadowFactors[i>0] == 1 (:46-51)
+        if ((dark >> i) & 1u) continue;
         pbr_dir_light(P.Lights[i], albedo, roughness, metalness, normalW, view, i == 0 ? shadow0 : 1.0f, direct, fixQ3, fixQ4);
+    }
     pointLights(posW, albedo, roughness, metalness, normalW, view, direct, fixQ3, fixQ4);   // extension; a no-op in the reference configuration
 
     const float invGamma = 1.0f / 2.2f;

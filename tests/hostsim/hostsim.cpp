@@ -232,6 +232,7 @@ void hs_light(const crychic_pass_constants* cb, const float* g0, const float* g1
     P.shadowDim = shadowDim; P.cubeDim = cubeDim; P.W = W; P.H = H; P.numDirLights = numDirLights; P.flags = flags;
     P.pointLights = pointLights; P.numPointLights = numPointLights;
     P.shadowWIsOne = light_shadow_w_is_one(P.ShadowTransforms) ? 1u : 0u;
+    P.darkLights = light_dark_mask(P.Lights, numDirLights);
     const AllPointLights pl{ pointLights, numPointLights };
     const f4a* G0 = (const f4a*)g0; const f4a* G1 = (const f4a*)g1; const f4a* G2 = (const f4a*)g2;
     for (uint32_t y = row0; y < row0 + rows; ++y)

@@ -260,3 +260,39 @@ def test_recycled_workspace_cannot_settle_a_tile(built_lib, oracle, hostsim, blu
     edge.view(np.uint32)[:] = 9
     got, _ = hostsim.compute_ssao(c.ssao_cb, normal_b, depth_b, randvec, eb, blur_count, edge=edge, stamp=9)
     assert np.array_equal(got, want_b)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_dark_light_skip_is_exact(built_lib, oracle, hostsim, seed):
+    """A directional light with Strength (0, 0, 0) -- the reference's third (CRYCHIC.cpp:863-864) -- is skipped where the pixel's
+    inputs are bounded (light_core.hpp "dark lights") and evaluated everywhere else.  G-buffer values on both sides of every bound
+    of the guard (roughness 0 / 0.03 / 10 / huge, albedo and metalness around 16, non-finite positions and normals), direction
+    lengths at the ends of the accepted range and outside it, a NaN strength: kernel bodies == oracle (RGBA8 and radiance bits)."""
+    import copy
+    W, H = 96, 64
+    p, c, scb, pcb, eb = setup(W, H, built_lib)
+    rng = np.random.default_rng(77 + seed)
+    g0, g1, g2 = p["g0"].copy(), p["g1"].copy(), p["g2"].copy()
+    depth = p["depth"].copy(); depth[:] = 1000                       # every pixel covered
+    n = W * H
+    pick = lambda vals: rng.choice(np.asarray(vals, dtype=np.float32), size=(H, W))
+    g1[..., 3] = pick([0.0, 0.02, 0.03, 0.031, 0.3, 0.8, 1.0, 9.99, 10.0, 10.5, 1e6, np.inf, np.nan, -0.5])
+    for ch in range(3):
+        g1[..., ch] = pick([0.0, 0.5, 0.9, 1.0, 15.9, 16.0, 16.5, -16.0, -17.0, 1e5, np.nan])
+    g0[..., 3] = pick([0.0, 0.5, 1.0, 16.0, 16.01, -16.0, 1e9, np.nan])
+    bad = rng.random((H, W)) < 0.1
+    g0[bad, 0] = rng.choice(np.asarray([np.inf, -np.inf, np.nan, 2e30, 1e30], dtype=np.float32), size=int(bad.sum()))
+    badn = rng.random((H, W)) < 0.1
+    g2[badn, 1] = rng.choice(np.asarray([np.inf, np.nan, 0.0, 3.3e38], dtype=np.float32), size=int(badn.sum()))
+    amb = rng.integers(0, 65536, size=(H // 2, W // 2), dtype=np.uint16)
+    cb = copy.deepcopy(c.pass_cb)
+    dirs = [(0.0, -0.707, -0.707), (0.0, -0.5001, 0.0), (0.0, -1.0004, 0.0), (0.0, -0.49, 0.0), (0.0, -1.01, 0.0), (np.nan, -1.0, 0.0)]
+    for d in dirs:
+        for strength in ((0.0, 0.0, 0.0), (-0.0, 0.0, -0.0), (0.0, np.nan, 0.0), (0.0, 1e-30, 0.0)):
+            cb.Lights[2].Direction[:] = d
+            cb.Lights[2].Strength[:] = strength
+            ocb = oracle_lib.as_oracle_cb(cb, oracle_lib.OrPassConstants)
+            ref, rref = oracle.deferred_light(ocb, g0, g1, g2, depth, amb, p["shadow"], p["cube"], 3, 0.0, want_radiance=True)
+            got, rgot = hostsim.light(cb, g0, g1, g2, depth, amb, p["shadow"], p["cube"], 3, 0.0, want_radiance=True)
+            assert np.array_equal(got, ref), (d, strength, int((got != ref).sum()))
+            assert np.array_equal(rgot.view(np.uint32), rref.view(np.uint32)), (d, strength)
