@@ -74,6 +74,7 @@ __device__ __forceinline__ void tile_origin_2d(uint32_t& bx, uint32_t& by, uint3
 //     any texel of rows belonging to cell row c lies below the clear depth it stamps cell (seg, c) with this frame's stamp -- a
 //     plain store: every writer of a cell stores the same value, and a stale or uninitialised word can only read as "geometry"
 //     (no shortcut), never as "sky".
+template <bool WRITE_PAIRS>
 __global__ __launch_bounds__(256) void depth_pairs_kernel(const uint32_t* __restrict__ depth, f4a* __restrict__ pairs, uint32_t* __restrict__ geo,
                                                           float* __restrict__ zcull, uint32_t stamp, uint32_t W, uint32_t H, CullParams cull,
                                                           uint32_t cellRow0)
@@ -98,7 +99,7 @@ __global__ __launch_bounds__(256) void depth_pairs_kernel(const uint32_t* __rest
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         const uint32_t py = 8u * cy + (uint32_t)k;
-        if (live && py < H + 3u) pairs[py * halfPitch + px2] = f4a{ r0[k], r0[k + 1], r1[k], r1[k + 1] };
+        if (WRITE_PAIRS && live && py < H + 3u) pairs[py * halfPitch + px2] = f4a{ r0[k], r0[k + 1], r1[k], r1[k + 1] };
     }
     // coarse geometry map: rows y0 .. y0 + 7 (row y0 + 8 is the next cell row's first) fall into at most two 32-row cells
     const int yFirst = y0 < 0 ? 0 : y0;
@@ -142,7 +143,8 @@ __global__ __launch_bounds__(256) void depth_pairs_kernel(const uint32_t* __rest
 
 // Shaders/Ssao.hlsl:117-199 over half-res rows [row0, row1).  EMIT_AO = false builds only the edge workspace.
 // PAIRS: the depth taps read the pairs plane of the edge workspace (built by depth_pairs_kernel earlier on the stream).
-template <bool EMIT_AO, bool PAIRS>
+// MAPS: the depth pass of this frame built the coarse maps (geometry, nearest depth) that the sky shortcut and the tap culling read.
+template <bool EMIT_AO, bool PAIRS, bool MAPS>
 __global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, const u2* __restrict__ normal,
                                                    const uint32_t* __restrict__ depth,
                                                    const uint32_t* __restrict__ randvec,
@@ -168,7 +170,7 @@ __global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, co
         if (y == row0) edge.grow[x] = normal[2u * x + 1u];      // texel (2x+1, 0)
     }
     // Sky shortcut (ssao_core.hpp): every live lane of this wave is a sky pixel and no cell its taps can reach holds geometry
-    if (EMIT_AO && PAIRS && sky.enabled && __builtin_amdgcn_ballot_w64(!c.sky) == 0) {
+    if (EMIT_AO && MAPS && sky.enabled && __builtin_amdgcn_ballot_w64(!c.sky) == 0) {
         const uint32_t x0 = bx * 64u, n = (w2 - x0) < 64u ? (w2 - x0) : 64u;
         const GeoCells g = ssao_sky_cells(sky, W, H, x0, n, y);
         const uint32_t ncx = g.cx1 - g.cx0 + 1u, ncells = ncx * (g.cy1 - g.cy0 + 1u), pitch = geo_map_cols(W);
@@ -185,14 +187,16 @@ __global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, co
     }
     if (EMIT_AO) {
         uint32_t v;
-        if (PAIRS && cullEnabled) v = ssao_pixel(cb, c, dp, randvec, W, H, x, y, sparseProjTex != 0, ZminMap{ edge.zcull, zmin_map_cols(W) });
+        const ZminMap zm{ edge.zcull, zmin_map_cols(W) };
+        if (PAIRS && MAPS && cullEnabled) v = ssao_pixel(cb, c, dp, randvec, W, H, x, y, sparseProjTex != 0, zm);
         else if (PAIRS) v = ssao_pixel(cb, c, dp, randvec, W, H, x, y, sparseProjTex != 0);
+        else if (MAPS && cullEnabled) v = ssao_pixel(cb, c, dd, randvec, W, H, x, y, sparseProjTex != 0, zm);
         else v = ssao_pixel(cb, c, dd, randvec, W, H, x, y, sparseProjTex != 0);
         ambient[y * w2 + x] = (uint16_t)v;
         // unoccluded-wavefront map (ssao_core.hpp "unoccluded tiles"): lane 0 is live whenever the wave is (x = 64 bx < w2).  The
         // word is written by EVERY wavefront that emits ambient values -- the stamp or 0 -- so no word of a row computed this
         // frame is ever stale.
-        if (PAIRS && stamp != 0u) {
+        if (MAPS && stamp != 0u) {
             const bool allOnes = __builtin_amdgcn_ballot_w64(v != 0xFFFFu) == 0;
             if ((threadIdx.x & 63u) == 0) edge.ones[y * ones_map_cols(W) + bx] = allOnes ? stamp : 0u;
         }
@@ -449,14 +453,16 @@ static inline dim3 grid_for(uint32_t width, uint32_t rows, uint32_t rows_per_blo
 }
 
 hipError_t launch_depth_pairs(const crychic_ssao_constants& cb, const uint32_t* depth, void* edge_base, uint32_t W, uint32_t H, uint32_t stamp,
-                              hipStream_t stream)
+                              bool writePairs, hipStream_t stream)
 {
     const EdgePlane e = edge_plane_carve(edge_base, W, H);
     // a wavefront per 128 entry columns x 8 entry rows (= one row of 16 cells of the nearest-depth map), four wavefronts per workgroup
     const uint32_t segs = (depth_pairs_pitch(W) / 2u + 63u) / 64u;
     const dim3 grid((segs + 3u) / 4u, zmin_map_rows(H), 1);
-    hipLaunchKernelGGL(depth_pairs_kernel, grid, dim3(256), 0, stream, depth, (f4a*)const_cast<void*>(e.pairs), e.geo, e.zcull, stamp, W, H,
-                       ssao_cull_params(cb), 0u);
+#define CRY_LAUNCH_DP(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, depth, (f4a*)const_cast<void*>(e.pairs), e.geo, e.zcull, stamp, W, H, \
+                                            ssao_cull_params(cb), 0u)
+    if (writePairs) CRY_LAUNCH_DP(depth_pairs_kernel<true>); else CRY_LAUNCH_DP(depth_pairs_kernel<false>);
+#undef CRY_LAUNCH_DP
     return hipGetLastError();
 }
 
@@ -480,12 +486,15 @@ hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, con
     grid.y = (grid.y + SY - 1u) / SY * SY;
     const int sparse = ssao_projtex_is_sparse(cb) ? 1 : 0;
     SkyReach sky = ssao_sky_reach(cb, W, H);
-    if (!use_pairs || stamp == 0u) sky.enabled = 0;      // stamp 0: the caller did not build the geometry map
-    const int cull = (use_pairs && stamp != 0u && ssao_cull_params(cb).enabled) ? 1 : 0;    // the nearest-depth map comes with the pairs plane
+    const bool maps = edge_base && stamp != 0u;        // stamp 0: the caller did not run the depth pass
+    if (!maps) sky.enabled = 0;
+    const int cull = (maps && ssao_cull_params(cb).enabled) ? 1 : 0;
 #define CRY_LAUNCH_SSAO(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, cb, (const u2*)normal, depth, (const uint32_t*)randvec, ambient, e, W, H, row0, row0 + rows, SX, SY, sparse, sky, stamp, cull)
-    if (emit_ao && use_pairs) CRY_LAUNCH_SSAO((ssao_kernel<true, true>));
-    else if (emit_ao) CRY_LAUNCH_SSAO((ssao_kernel<true, false>));
-    else CRY_LAUNCH_SSAO((ssao_kernel<false, false>));
+    if (!emit_ao) CRY_LAUNCH_SSAO((ssao_kernel<false, false, false>));
+    else if (use_pairs && maps) CRY_LAUNCH_SSAO((ssao_kernel<true, true, true>));
+    else if (use_pairs) CRY_LAUNCH_SSAO((ssao_kernel<true, true, false>));
+    else if (maps) CRY_LAUNCH_SSAO((ssao_kernel<true, false, true>));
+    else CRY_LAUNCH_SSAO((ssao_kernel<true, false, false>));
 #undef CRY_LAUNCH_SSAO
     return hipGetLastError();
 }

@@ -11,7 +11,7 @@ struct LightParams;
 // D24 depth plane -> the decoded, BORDER-padded pairs plane inside the edge workspace (ssao_core.hpp "depth pairs"); whole plane.
 // `stamp` (non-zero, different from the previous frame's) marks the cells of the coarse geometry map written by this call.
 hipError_t launch_depth_pairs(const crychic_ssao_constants& cb, const uint32_t* depth, void* edge_base, uint32_t W, uint32_t H, uint32_t stamp,
-                              hipStream_t stream);
+                              bool writePairs, hipStream_t stream);
 // use_pairs: the taps read the pairs plane (launch_depth_pairs earlier on the same stream) instead of the raw D24 plane.
 hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, const uint32_t* depth,
                        const uint8_t* randvec, uint16_t* ambient, void* edge_base, uint32_t W, uint32_t H,

@@ -164,15 +164,21 @@ struct DepthPairs {
 
 // The same sampler at the centre of half-res pixel (xi, yi) (even W, H): texels 2xi..2xi+1 x 2yi..2yi+1 with
 // weights 1/2; a pixel outside the half-res map only ever addresses border texels.
-CRY_HD float depth_at_half_pixel(const uint32_t* __restrict__ depth, uint32_t W, uint32_t H, int xi, int yi)
+CRY_HD void depth_at_half_pixel(const uint32_t* __restrict__ depth, uint32_t W, uint32_t H, int xi, int yi, float& t00, float& t10, float& t01,
+                                float& t11)
 {
     const bool in = ((uint32_t)(2 * xi) < W) & ((uint32_t)(2 * yi) < H);   // even sizes: all four in or all four out
     const uint32_t cx = (uint32_t)clampi(2 * xi, 0, (int)W - 2), cy = (uint32_t)clampi(2 * yi, 0, (int)H - 2);
     const uint32_t t0 = mul24(cy, W) + cx;
     const RawPair p0 = load_pair(depth, t0);
     const RawPair p1 = load_pair(depth, t0 + W);
-    const float t00 = d24_to_float(in ? p0.lo : 0x00FFFFFFu), t10 = d24_to_float(in ? p0.hi : 0x00FFFFFFu);
-    const float t01 = d24_to_float(in ? p1.lo : 0x00FFFFFFu), t11 = d24_to_float(in ? p1.hi : 0x00FFFFFFu);
+    t00 = d24_to_float(in ? p0.lo : 0x00FFFFFFu); t10 = d24_to_float(in ? p0.hi : 0x00FFFFFFu);
+    t01 = d24_to_float(in ? p1.lo : 0x00FFFFFFu); t11 = d24_to_float(in ? p1.hi : 0x00FFFFFFu);
+}
+CRY_HD float depth_at_half_pixel(const uint32_t* __restrict__ depth, uint32_t W, uint32_t H, int xi, int yi)
+{
+    float t00, t10, t01, t11;
+    depth_at_half_pixel(depth, W, H, xi, yi, t00, t10, t01, t11);
     return bilerp(t00, t10, t01, t11, 0.5f, 0.5f);
 }
 
@@ -360,8 +366,10 @@ CRY_HD SsaoCentre ssao_centre(const crychic_ssao_constants& cb, const u2* __rest
 {
     SsaoCentre c;
     c.nrm_bits = normal_texel_bits(normal, W, H, x, y);
-    c.vz = ndc_to_view(cb, depth_at_half_pixel(depth, W, H, x, y));
-    c.sky = false;
+    float t00, t10, t01, t11;
+    depth_at_half_pixel(depth, W, H, x, y, t00, t10, t01, t11);
+    c.vz = ndc_to_view(cb, bilerp(t00, t10, t01, t11, 0.5f, 0.5f));
+    c.sky = ssao_sky_lane(t00, t10, t01, t11, c.nrm_bits);
     return c;
 }
 // The same from the pairs plane (pixel inside the half-res map): the footprint at (2x, 2y) with weights 1/2.
