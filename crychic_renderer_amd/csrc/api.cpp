@@ -87,13 +87,14 @@ int ssao_compute_impl(const crychic_ssao_constants* cb, const void* normal, cons
     uint32_t r0, rn;
     cry::blur_chain_ssao_rows(blurCount, row0, rows, h2, &r0, &rn);
     uint16_t* planes[2] = { ambient0, ambient1 };
-    // With a workspace at hand the depth plane is re-laid once per frame as decoded pairs (whole plane: the taps of any row
-    // reach far up and down the frame) and the taps gather from that; its cost is part of the SSAO pass.
+    // With a workspace at hand the depth plane is re-laid once per frame as decoded pairs -- for the rows of this call and a margin:
+    // the taps of a row reach far up and down the frame, and the few that leave the margin take the raw plane -- and
+    // the taps gather from that; its cost is part of the SSAO pass.
     const uint32_t stamp = next_stamp();
     // (gathering from the raw D24 plane with the coarse maps alone was measured too: the depth pass drops from 20 to 7 us and the
     // SSAO kernel gains 15: the pairs plane stays)
     const bool usePairs = edge != nullptr;
-    if (edge) CRY_HIP(cry::launch_depth_pairs(*cb, depth, edge, W, H, stamp, usePairs, stream));
+    if (edge) CRY_HIP(cry::launch_depth_pairs(*cb, depth, edge, W, H, stamp, usePairs, r0, rn, stream));
     CRY_HIP(cry::launch_ssao(*cb, normal, depth, randvec, planes[cry::blur_chain_ssao_plane(blurCount)], edge, W, H, r0, rn, true, usePairs,
                              edge ? stamp : 0u, stream));
     if (afterSsao) CRY_HIP(hipEventRecord(afterSsao, stream));
@@ -199,7 +200,7 @@ int crychic_ssao(crychic_ctx* ctx, const crychic_ssao_constants* cb, const void*
     if (row0 > H / 2 || rows > H / 2 - row0) return fail(CRYCHIC_E_INVALID_ARG, "rows [%u,+%u) outside the %u-row ambient map", row0, rows, H / 2);
     const uint32_t stamp = next_stamp();
     const bool usePairs = edge_dev != nullptr;
-    if (edge_dev) CRY_HIP(cry::launch_depth_pairs(*cb, depth_dev, edge_dev, W, H, stamp, usePairs, (hipStream_t)stream));
+    if (edge_dev) CRY_HIP(cry::launch_depth_pairs(*cb, depth_dev, edge_dev, W, H, stamp, usePairs, row0, rows, (hipStream_t)stream));
     CRY_HIP(cry::launch_ssao(*cb, normal_dev, depth_dev, randvec_dev, ambient_out_dev, edge_dev, W, H, row0, rows, true, usePairs,
                              edge_dev ? stamp : 0u, (hipStream_t)stream));
     return 0;

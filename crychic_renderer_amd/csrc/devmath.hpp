@@ -128,7 +128,7 @@ CRY_HD v2f select2(v2i m, v2f a, v2f b) { return m ? a : b; }          // per la
 CRY_HD v2f saturate2(v2f x) { return v2f{ saturate(x.x), saturate(x.y) }; }   // NaN -> 0
 CRY_HD v2f max0_2(v2f x) { return select2(x > 0.0f, x, splat(0.0f)); }  // HLSL max(x, 0): NaN -> 0
 // sign(): +-1 with the sign bit of x copied in (v_bfi_b32), 0 for +-0 and NaN -- the same values as (x > 0) - (x < 0)
-CRY_HD float sign1(float x) { return ((x < 0.0f) | (x > 0.0f)) ? __builtin_copysignf(1.0f, x) : 0.0f; }
+CRY_HD float sign1(float x) { return __builtin_islessgreater(x, 0.0f) ? __builtin_copysignf(1.0f, x) : 0.0f; }      // v_cmp_lg_f32: false for 0 and NaN
 CRY_HD v2f sign2(v2f x) { return v2f{ sign1(x.x), sign1(x.y) }; }
 CRY_HD v2f floor2(v2f x) { return v2f{ __builtin_floorf(x.x), __builtin_floorf(x.y) }; }
 CRY_HD v2f sqrt2(v2f x) { return v2f{ __builtin_sqrtf(x.x), __builtin_sqrtf(x.y) }; }
@@ -260,8 +260,12 @@ CRY_HD int texel_index(float fl, uint32_t dim)
 {
     // clamp(fl, -2, dim) with NaN -> -2 (fmax returns the non-NaN operand); fl is already integral.  A footprint whose
     // top-left texel lies further out than that consists of out-of-range texels only, and so does its clamped stand-in.
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (int)__builtin_amdgcn_fmed3f(fl, -2.0f, (float)dim);      // one v_med3_f32; a quiet NaN comes out as the minimum, like clamp_len2
+#else
     const float c = __builtin_fminf(__builtin_fmaxf(fl, -2.0f), (float)dim);
     return (int)c;
+#endif
 }
 CRY_HD Bilin bilinear_setup(float u, float v, uint32_t w, uint32_t h)
 {

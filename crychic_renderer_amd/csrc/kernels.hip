@@ -144,13 +144,16 @@ __global__ __launch_bounds__(256) void depth_pairs_kernel(const uint32_t* __rest
 // Shaders/Ssao.hlsl:117-199 over half-res rows [row0, row1).  EMIT_AO = false builds only the edge workspace.
 // PAIRS: the depth taps read the pairs plane of the edge workspace (built by depth_pairs_kernel earlier on the stream).
 // MAPS: the depth pass of this frame built the coarse maps (geometry, nearest depth) that the sky shortcut and the tap culling read.
-template <bool EMIT_AO, bool PAIRS, bool MAPS>
+// ROWS: that pass was limited to the footprint rows [prepJ0, prepJ0 + prepNj) (a strip of a multi-GPU frame): taps that leave them
+// gather from the raw plane (ssao_core.hpp DepthPairsRows).
+struct PrepRows { int j0lo; uint32_t nj; };
+template <bool EMIT_AO, bool PAIRS, bool MAPS, bool ROWS>
 __global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, const u2* __restrict__ normal,
                                                    const uint32_t* __restrict__ depth,
                                                    const uint32_t* __restrict__ randvec,
                                                    uint16_t* __restrict__ ambient, EdgePlane edge, uint32_t W,
                                                    uint32_t H, uint32_t row0, uint32_t row1, uint32_t SX, uint32_t SY, int sparseProjTex,
-                                                   SkyReach sky, uint32_t stamp, int cullEnabled)
+                                                   SkyReach sky, uint32_t stamp, int cullEnabled, PrepRows prep)
 {
     const uint32_t w2 = W / 2;
     uint32_t bx, by;
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, co
             const uint32_t cy = k / ncx, cx = k - cy * ncx;
             geometry |= edge.geo[(g.cy0 + cy) * pitch + g.cx0 + cx] == stamp;
         }
-        if (__builtin_amdgcn_ballot_w64(geometry) == 0) {
+        if (g.known && __builtin_amdgcn_ballot_w64(geometry) == 0) {
             ambient[y * w2 + x] = (uint16_t)0xFFFFu;
             if ((threadIdx.x & 63u) == 0) edge.ones[y * ones_map_cols(W) + bx] = stamp;
             return;
@@ -188,7 +191,12 @@ __global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, co
     if (EMIT_AO) {
         uint32_t v;
         const ZminMap zm{ edge.zcull, zmin_map_cols(W) };
-        if (PAIRS && MAPS && cullEnabled) v = ssao_pixel(cb, c, dp, randvec, W, H, x, y, sparseProjTex != 0, zm);
+        if (ROWS) {      // PAIRS && MAPS
+            const DepthPairsRows dr{ dp, dd, prep.j0lo, prep.nj };
+            if (cullEnabled) v = ssao_pixel(cb, c, dr, randvec, W, H, x, y, sparseProjTex != 0, ZminMapRows{ zm, prep.j0lo, prep.nj });
+            else v = ssao_pixel(cb, c, dr, randvec, W, H, x, y, sparseProjTex != 0);
+        }
+        else if (PAIRS && MAPS && cullEnabled) v = ssao_pixel(cb, c, dp, randvec, W, H, x, y, sparseProjTex != 0, zm);
         else if (PAIRS) v = ssao_pixel(cb, c, dp, randvec, W, H, x, y, sparseProjTex != 0);
         else if (MAPS && cullEnabled) v = ssao_pixel(cb, c, dd, randvec, W, H, x, y, sparseProjTex != 0, zm);
         else v = ssao_pixel(cb, c, dd, randvec, W, H, x, y, sparseProjTex != 0);
@@ -453,14 +461,17 @@ static inline dim3 grid_for(uint32_t width, uint32_t rows, uint32_t rows_per_blo
 }
 
 hipError_t launch_depth_pairs(const crychic_ssao_constants& cb, const uint32_t* depth, void* edge_base, uint32_t W, uint32_t H, uint32_t stamp,
-                              bool writePairs, hipStream_t stream)
+                              bool writePairs, uint32_t row0, uint32_t rows, hipStream_t stream)
 {
     const EdgePlane e = edge_plane_carve(edge_base, W, H);
+    uint32_t c0, cn;
+    depth_pass_cell_rows(H, row0, rows, &c0, &cn);
+    if (cn == 0) return hipSuccess;
     // a wavefront per 128 entry columns x 8 entry rows (= one row of 16 cells of the nearest-depth map), four wavefronts per workgroup
     const uint32_t segs = (depth_pairs_pitch(W) / 2u + 63u) / 64u;
-    const dim3 grid((segs + 3u) / 4u, zmin_map_rows(H), 1);
+    const dim3 grid((segs + 3u) / 4u, cn, 1);
 #define CRY_LAUNCH_DP(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, depth, (f4a*)const_cast<void*>(e.pairs), e.geo, e.zcull, stamp, W, H, \
-                                            ssao_cull_params(cb), 0u)
+                                            ssao_cull_params(cb), c0)
     if (writePairs) CRY_LAUNCH_DP(depth_pairs_kernel<true>); else CRY_LAUNCH_DP(depth_pairs_kernel<false>);
 #undef CRY_LAUNCH_DP
     return hipGetLastError();
@@ -489,12 +500,22 @@ hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, con
     const bool maps = edge_base && stamp != 0u;        // stamp 0: the caller did not run the depth pass
     if (!maps) sky.enabled = 0;
     const int cull = (maps && ssao_cull_params(cb).enabled) ? 1 : 0;
-#define CRY_LAUNCH_SSAO(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, cb, (const u2*)normal, depth, (const uint32_t*)randvec, ambient, e, W, H, row0, row0 + rows, SX, SY, sparse, sky, stamp, cull)
-    if (!emit_ao) CRY_LAUNCH_SSAO((ssao_kernel<false, false, false>));
-    else if (use_pairs && maps) CRY_LAUNCH_SSAO((ssao_kernel<true, true, true>));
-    else if (use_pairs) CRY_LAUNCH_SSAO((ssao_kernel<true, true, false>));
-    else if (maps) CRY_LAUNCH_SSAO((ssao_kernel<true, false, true>));
-    else CRY_LAUNCH_SSAO((ssao_kernel<true, false, false>));
+    // what launch_depth_pairs prepared for these rows: everything, or footprint rows j0 with 8 c0 <= j0 + 2 < 8 (c0 + cn)
+    uint32_t c0, cn;
+    depth_pass_cell_rows(H, row0, rows, &c0, &cn);
+    const bool limited = maps && use_pairs && (c0 > 0u || c0 + cn < zmin_map_rows(H));
+    const PrepRows prep{ 8 * (int)c0 - 2, 8u * cn };
+    if (limited) {                      // geometry-map cells are known for the texel rows the pass visited (8 entry rows per cell row)
+        sky.y0 = 8 * (int)c0 - 2 < 0 ? 0 : 8 * (int)c0 - 2;
+        sky.y1 = 8 * (int)(c0 + cn) - 2 > (int)H ? (int)H : 8 * (int)(c0 + cn) - 2;
+    }
+#define CRY_LAUNCH_SSAO(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, cb, (const u2*)normal, depth, (const uint32_t*)randvec, ambient, e, W, H, row0, row0 + rows, SX, SY, sparse, sky, stamp, cull, prep)
+    if (!emit_ao) CRY_LAUNCH_SSAO((ssao_kernel<false, false, false, false>));
+    else if (limited) CRY_LAUNCH_SSAO((ssao_kernel<true, true, true, true>));
+    else if (use_pairs && maps) CRY_LAUNCH_SSAO((ssao_kernel<true, true, true, false>));
+    else if (use_pairs) CRY_LAUNCH_SSAO((ssao_kernel<true, true, false, false>));
+    else if (maps) CRY_LAUNCH_SSAO((ssao_kernel<true, false, true, false>));
+    else CRY_LAUNCH_SSAO((ssao_kernel<true, false, false, false>));
 #undef CRY_LAUNCH_SSAO
     return hipGetLastError();
 }

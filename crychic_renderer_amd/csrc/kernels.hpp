@@ -8,10 +8,12 @@ namespace cry {
 
 struct LightParams;
 
-// D24 depth plane -> the decoded, BORDER-padded pairs plane inside the edge workspace (ssao_core.hpp "depth pairs"); whole plane.
+// D24 depth plane -> the decoded, BORDER-padded pairs plane inside the edge workspace (ssao_core.hpp "depth pairs") and the coarse
+// maps of the SSAO shortcuts, for the SSAO pass over half-res rows [row0, row0 + rows): those rows' texels and a margin (the whole
+// plane when the rows are the whole map; launch_ssao called with the same rows knows what was prepared).
 // `stamp` (non-zero, different from the previous frame's) marks the cells of the coarse geometry map written by this call.
 hipError_t launch_depth_pairs(const crychic_ssao_constants& cb, const uint32_t* depth, void* edge_base, uint32_t W, uint32_t H, uint32_t stamp,
-                              bool writePairs, hipStream_t stream);
+                              bool writePairs, uint32_t row0, uint32_t rows, hipStream_t stream);
 // use_pairs: the taps read the pairs plane (launch_depth_pairs earlier on the same stream) instead of the raw D24 plane.
 hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, const uint32_t* depth,
                        const uint8_t* randvec, uint16_t* ambient, void* edge_base, uint32_t W, uint32_t H,

@@ -161,6 +161,33 @@ struct DepthPairs {
         t00 = v.x; t01 = v.y; t10 = v.z; t11 = v.w;
     }
 };
+// A tap of the SSAO loop: the footprint of a lane whose tap was culled is never looked at, so such a lane fetches the plane's
+// first footprint instead of its own (every culled lane of the wavefront the same line: the gather it is spared stays spared)
+// and the loads of a tap pair need no branch around them.
+template <class Depth>
+CRY_HD void depth_tap(const Depth& d, bool culled, int i0, int j0, float& t00, float& t10, float& t01, float& t11)
+{
+    d.footprint(culled ? -2 : i0, culled ? -2 : j0, t00, t10, t01, t11);
+}
+// Row-limited pairs plane (a rank's strip of a multi-GPU frame): the depth pass prepared the pairs plane and the
+// coarse maps only for footprints whose top row j0 lies in [j0lo, j0lo + nj) -- the strip's own rows and a margin.  The taps of
+// the strip's pixels may land anywhere in the frame; one that leaves the prepared rows gathers from the raw D24 plane instead
+// (and is never culled: ZminMapRows).  Same decode, same filter: every output bit is unchanged whatever the margin is, which is
+// therefore a pure performance knob.
+struct DepthPairsRows {
+    DepthPairs pairs; DepthD24 raw; int j0lo; uint32_t nj;
+    CRY_HD bool prepared(int j0) const { return (uint32_t)(j0 - j0lo) < nj; }
+};
+CRY_HD void depth_tap(const DepthPairsRows& d, bool culled, int i0, int j0, float& t00, float& t10, float& t01, float& t11)
+{
+    const bool ok = d.prepared(j0), dummy = culled | !ok;
+    d.pairs.footprint(dummy ? -2 : i0, dummy ? d.j0lo : j0, t00, t10, t01, t11);        // (-2, j0lo): a prepared, always valid entry
+    const bool slow = !ok & !culled;
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (__builtin_amdgcn_ballot_w64(slow) == 0) return;       // the whole wavefront stayed inside the prepared rows (nearly always)
+#endif
+    if (slow) d.raw.footprint(i0, j0, t00, t10, t01, t11);
+}
 
 // The same sampler at the centre of half-res pixel (xi, yi) (even W, H): texels 2xi..2xi+1 x 2yi..2yi+1 with
 // weights 1/2; a pixel outside the half-res map only ever addresses border texels.
@@ -241,10 +268,11 @@ CRY_HD bool ssao_projtex_is_sparse(const crychic_ssao_constants& cb)
 struct SkyReach {
     int enabled;          // 0: the constants do not allow the argument (see ssao_sky_reach)
     uint32_t rx, ry;      // a sky pixel's taps stay within +-rx / +-ry depth texels of its own 2 x 2 footprint
+    int y0, y1;           // depth texel rows [y0, y1) whose cells of the geometry map this frame's depth pass wrote (launcher)
 };
 CRY_HD SkyReach ssao_sky_reach(const crychic_ssao_constants& cb, uint32_t W, uint32_t H)
 {
-    SkyReach r{ 0, 0u, 0u };
+    SkyReach r{ 0, 0u, 0u, 0, (int)H };
     if (!ssao_projtex_is_sparse(cb)) return r;
     const double A = cb.Proj[4 * 2 + 2], B = cb.Proj[4 * 2 + 3];
     const double farZ = B / (1.0 - A);                            // view depth of z_ndc = 1 (Ssao.hlsl:110-115)
@@ -288,17 +316,34 @@ CRY_HD bool ssao_sky_lane(float t00, float t10, float t01, float t11, u2 nrmBits
     return (t00 == 1.0f) & (t10 == 1.0f) & (t01 == 1.0f) & (t11 == 1.0f) & finite;
 }
 // The cells of the coarse geometry map that the taps of half-res pixels [x0, x0 + n) of half-res row y can reach.
-struct GeoCells { uint32_t cx0, cx1, cy0, cy1; };
+struct GeoCells { uint32_t cx0, cx1, cy0, cy1; bool known; };
 CRY_HD GeoCells ssao_sky_cells(const SkyReach& r, uint32_t W, uint32_t H, uint32_t x0, uint32_t n, uint32_t y)
 {
     const int xa = 2 * (int)x0 - (int)r.rx, xb = 2 * (int)(x0 + n) - 1 + (int)r.rx;      // texel columns, inclusive
-    const int ya = 2 * (int)y - (int)r.ry, yb = 2 * (int)y + 1 + (int)r.ry;
+    const int ya = clampi(2 * (int)y - (int)r.ry, 0, (int)H - 1), yb = clampi(2 * (int)y + 1 + (int)r.ry, 0, (int)H - 1);
     GeoCells g;                                       // texels outside the plane are BORDER = the clear depth: nothing to look up
     g.cx0 = (uint32_t)((clampi(xa, 0, (int)W - 1) + 2) / 128);
     g.cx1 = (uint32_t)((clampi(xb, 0, (int)W - 1) + 2) / 128);
-    g.cy0 = (uint32_t)(clampi(ya, 0, (int)H - 1) / 32);
-    g.cy1 = (uint32_t)(clampi(yb, 0, (int)H - 1) / 32);
+    g.cy0 = (uint32_t)(ya / 32);
+    g.cy1 = (uint32_t)(yb / 32);
+    // a cell the depth pass of this frame did not visit says nothing (a row-limited pass, DepthPairsRows): no shortcut then
+    const int cellsEnd = 32 * (int)g.cy1 + 32 < (int)H ? 32 * (int)g.cy1 + 32 : (int)H;      // texel rows [32 cy0, cellsEnd) belong to the cells
+    g.known = 32 * (int)g.cy0 >= r.y0 && cellsEnd <= r.y1;
     return g;
+}
+
+// Cell rows of the nearest-depth map [*c0, *c0 + *cn) that the depth pass visits for an SSAO pass over half-res rows
+// [row0, row0 + rows): the rows' own texels and a margin of H / 11 texel rows on either side (4K: 200; the sky shortcut's reach
+// is 170 there), which keeps nearly every tap of the rows inside -- what leaves it takes DepthPairsRows' detour, so the margin is
+// a performance knob only (`margin` < 0: the default).  Footprint rows j0 with 8 c0 <= j0 + 2 < 8 (c0 + cn) are prepared.
+CRY_HD void depth_pass_cell_rows(uint32_t H, uint32_t row0, uint32_t rows, uint32_t* c0, uint32_t* cn, int margin = -1)
+{
+    if (margin < 0) margin = (int)((H / 11u + 7u) & ~7u) < 64 ? 64 : (int)((H / 11u + 7u) & ~7u);
+    int a = (2 * (int)row0 - margin + 2) / 8, b = (2 * (int)(row0 + rows) + margin + 2 + 7) / 8;
+    a = a < 0 ? 0 : a;
+    b = b > (int)zmin_map_rows(H) ? (int)zmin_map_rows(H) : b;
+    *c0 = (uint32_t)a;
+    *cn = (uint32_t)(b > a ? b - a : 0);
 }
 
 // ---- tap culling ---------------------------------------------------------------------------------------------------------
@@ -352,6 +397,19 @@ struct ZminMap {
     {
         const uint32_t cx = (uint32_t)(i0 + 2) >> 3, cy = (uint32_t)(j0 + 2) >> 3;
         return load_at<float>(cells, (mul24(cy, pitch) + cx) * 4u);
+    }
+};
+
+// The same over a row-limited depth pass (DepthPairsRows): a footprint outside the prepared rows has no cell -- NaN, which no
+// comparison culls.
+struct ZminMapRows {
+    static constexpr bool active = true;
+    ZminMap map; int j0lo; uint32_t nj;
+    CRY_HD float cell(int i0, int j0) const
+    {
+        const bool ok = (uint32_t)(j0 - j0lo) < nj;
+        const float c = map.cell(i0, ok ? j0 : j0lo);
+        return ok ? c : u2f(0x7FC00000u);
     }
 };
 
@@ -483,8 +541,8 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
         // Both footprints in one round trip as well: a culled lane fetches the plane's first footprint instead of its own (every
         // culled lane of the wavefront the same line, so the gather it is spared stays spared) and never looks at it.
         float a00, a10, a01, a11, b00, b10, b01, b11;
-        depth.footprint(ca ? -2 : i0a, ca ? -2 : j0a, a00, a10, a01, a11);
-        depth.footprint(cb2 ? -2 : i0b, cb2 ? -2 : j0b, b00, b10, b01, b11);
+        depth_tap(depth, ca, i0a, j0a, a00, a10, a01, a11);
+        depth_tap(depth, cb2, i0b, j0b, b00, b10, b01, b11);
         const v2f t00{ a00, b00 }, t10{ a10, b10 }, t01{ a01, b01 }, t11{ a11, b11 };
         const v2f zndc = lerp2(lerp2(t00, t10, fx), lerp2(t01, t11, fx), fy);
         const v2f rz = B * rcp2(zndc - A);                                        // :164-165

@@ -55,6 +55,13 @@ void hs_set_cull_mask_plane(uint16_t* plane) { g_cull_masks = plane; }
 static uint32_t g_stamp = 1u;
 void hs_set_stamp(uint32_t stamp) { g_stamp = stamp; }
 
+// margin of the depth pass around the rows of the call, in texel rows (launch_depth_pairs / depth_pass_cell_rows); < 0: the
+// product's default.  Everything the pass does not visit is poisoned, so a tap that wrongly trusted it would show.
+static int g_prep_margin = -1;
+void hs_set_prep_margin(int margin) { g_prep_margin = margin; }
+static uint32_t g_slow_taps = 0;
+uint32_t hs_last_unprepared_rows(void) { return g_slow_taps; }
+
 // use_pairs != 0: the product's default path -- build the decoded depth-pairs plane in the edge workspace (the body of
 // depth_pairs_kernel) and let the taps gather from it; 0: taps on the raw D24 plane (what runs without a workspace).
 void hs_ssao_path(const crychic_ssao_constants* cb, const void* normal, const uint32_t* depth, const uint8_t* randvec,
@@ -65,34 +72,51 @@ void hs_ssao_path(const crychic_ssao_constants* cb, const void* normal, const ui
     if (edge_base) e = edge_plane_carve(edge_base, W, H);
     const u2* nrm = (const u2*)normal;
     const bool pairs = use_pairs && edge_base;
+    // the cell rows the depth pass visits for these rows
+    uint32_t c0 = 0, cn = zmin_map_rows(H);
+    if (pairs) depth_pass_cell_rows(H, row0, rows, &c0, &cn, g_prep_margin);
+    const bool limited = pairs && (c0 > 0u || c0 + cn < zmin_map_rows(H));
+    const int j0lo = 8 * (int)c0 - 2;
+    const uint32_t nj = 8u * cn;
+    g_slow_taps = limited ? 8u * (zmin_map_rows(H) - cn) : 0u;
     if (pairs) {
         f4a* out = (f4a*)const_cast<void*>(e.pairs);
         const uint32_t halfPitch = depth_pairs_pitch(W) / 2u;
         for (uint32_t py = 0; py < H + 3u; ++py)
-            for (uint32_t px2 = 0; px2 < halfPitch; ++px2) out[py * halfPitch + px2] = depth_pairs_entry2(depth, W, H, 2 * (int)px2 - 2, (int)py - 2);
+            for (uint32_t px2 = 0; px2 < halfPitch; ++px2) {
+                const bool visited = py >= 8u * c0 && py < 8u * (c0 + cn);
+                out[py * halfPitch + px2] = visited ? depth_pairs_entry2(depth, W, H, 2 * (int)px2 - 2, (int)py - 2) : f4a{ -7.0f, -7.0f, -7.0f, -7.0f };
+            }
     }
     const DepthPairs dp{ e.pairs, depth_pairs_pitch(W) };
     const DepthD24 dd{ depth, W, H };
+    const DepthPairsRows dr{ dp, dd, j0lo, nj };
     const bool sparse = ssao_projtex_is_sparse(*cb);
     // the coarse geometry map as depth_pairs_kernel fills it (cells with geometry get the stamp, the others are left alone), and
     // the sky shortcut per "wavefront" of 64 consecutive pixels of a row, exactly as ssao_kernel takes it
     SkyReach sky = ssao_sky_reach(*cb, W, H);
     if (!pairs) sky.enabled = 0;
+    if (limited) {
+        sky.y0 = j0lo < 0 ? 0 : j0lo;
+        sky.y1 = 8 * (int)(c0 + cn) - 2 > (int)H ? (int)H : 8 * (int)(c0 + cn) - 2;
+    }
     const uint32_t stamp = g_stamp, gpitch = geo_map_cols(W);
     if (pairs) {
         const uint32_t halfPitch = depth_pairs_pitch(W) / 2u;
-        const f4a* pp = (const f4a*)e.pairs;
-        for (uint32_t py = 2; py < H + 2u; ++py)
+        for (uint32_t py = 2; py < H + 2u; ++py) {
+            if (py < 8u * c0 || py >= 8u * (c0 + cn)) continue;
             for (uint32_t px2 = 0; px2 < halfPitch; ++px2) {
-                const f4a v = pp[py * halfPitch + px2];
+                const f4a v = depth_pairs_entry2(depth, W, H, 2 * (int)px2 - 2, (int)py - 2);
                 if (v.x != 1.0f || v.z != 1.0f) e.geo[((py - 2u) >> 5) * gpitch + px2 / 64u] = stamp;
             }
+        }
     }
     // the nearest-depth map as depth_pairs_kernel fills it: per cell of 9 x 9 padded texels, cells 8 apart (padded (ex, ey) = texel
     // (ex - 2, ey - 2), anything outside the plane reads as the clear depth)
     const CullParams cp = ssao_cull_params(*cb);
     const bool culling = pairs && cp.enabled && use_pairs != 2;         // use_pairs == 2: pairs plane without tap culling
     const ZminMap win{ e.zcull, zmin_map_cols(W) };
+    const ZminMapRows winRows{ win, j0lo, nj };
     if (pairs) {
         for (uint32_t cy = 0; cy < zmin_map_rows(H); ++cy)
             for (uint32_t cx = 0; cx < zmin_map_cols(W); ++cx) {
@@ -102,12 +126,20 @@ void hs_ssao_path(const crychic_ssao_constants* cb, const void* normal, const ui
                         const int tx = (int)ex - 2, ty = (int)ey - 2;
                         if ((uint32_t)tx < W && (uint32_t)ty < H) m = __builtin_fminf(m, d24_to_float(depth[(uint32_t)ty * W + (uint32_t)tx]));
                     }
-                e.zcull[cy * zmin_map_cols(W) + cx] = zmin_cell_value(cp.A, cp.B, m);
+                const bool visited = cy >= c0 && cy < c0 + cn;
+                e.zcull[cy * zmin_map_cols(W) + cx] = visited ? zmin_cell_value(cp.A, cp.B, m) : 1.0e30f;      // poison: "cull everything"
             }
     }
     std::vector<SsaoCentre> row(w2);
     g_sky_waves = 0;
     g_culled_taps = 0;
+    auto pixel = [&](uint32_t x, uint32_t y, uint32_t* acc) -> uint32_t {
+        if (limited) return culling ? ssao_pixel(*cb, row[x], dr, (const uint32_t*)randvec, W, H, x, y, sparse, winRows, acc)
+                                    : ssao_pixel(*cb, row[x], dr, (const uint32_t*)randvec, W, H, x, y, sparse);
+        if (culling) return ssao_pixel(*cb, row[x], dp, (const uint32_t*)randvec, W, H, x, y, sparse, win, acc);
+        return pairs ? ssao_pixel(*cb, row[x], dp, (const uint32_t*)randvec, W, H, x, y, sparse)
+                     : ssao_pixel(*cb, row[x], dd, (const uint32_t*)randvec, W, H, x, y, sparse);
+    };
     for (uint32_t y = row0; y < row0 + rows; ++y) {
         for (uint32_t x = 0; x < w2; ++x) {
             const SsaoCentre c = pairs ? ssao_centre(*cb, nrm, dp, W, H, (int)x, (int)y) : ssao_centre(*cb, nrm, depth, W, H, (int)x, (int)y);
@@ -126,20 +158,17 @@ void hs_ssao_path(const crychic_ssao_constants* cb, const void* normal, const ui
             for (uint32_t k = 0; k < n && skip; ++k) skip = row[x0 + k].sky;
             if (skip) {
                 const GeoCells g = ssao_sky_cells(sky, W, H, x0, n, y);
+                skip = g.known;
                 for (uint32_t cy = g.cy0; cy <= g.cy1 && skip; ++cy)
                     for (uint32_t cx = g.cx0; cx <= g.cx1 && skip; ++cx) skip = e.geo[cy * gpitch + cx] != stamp;
             }
             g_sky_waves += skip ? 1u : 0u;
             bool allOnes = true;
             for (uint32_t x = x0; x < x0 + n; ++x) {
-                ambient[y * w2 + x] = skip ? (uint16_t)0xFFFFu
-                                           : (uint16_t)(culling ? [&] { uint32_t acc[2] = { 0u, 0u };
-                                                                         const uint32_t v = ssao_pixel(*cb, row[x], dp, (const uint32_t*)randvec, W, H, x, y, sparse, win, acc);
-                                                                         g_culled_taps += acc[0];
-                                                                         if (g_cull_masks) g_cull_masks[y * w2 + x] = (uint16_t)(acc[1] | 0x8000u);
-                                                                         return v; }()
-                                                        : pairs ? ssao_pixel(*cb, row[x], dp, (const uint32_t*)randvec, W, H, x, y, sparse)
-                                                                : ssao_pixel(*cb, row[x], dd, (const uint32_t*)randvec, W, H, x, y, sparse));
+                uint32_t acc[2] = { 0u, 0u };
+                ambient[y * w2 + x] = skip ? (uint16_t)0xFFFFu : (uint16_t)pixel(x, y, acc);
+                g_culled_taps += acc[0];
+                if (!skip && culling && g_cull_masks) g_cull_masks[y * w2 + x] = (uint16_t)(acc[1] | 0x8000u);
                 allOnes = allOnes && ambient[y * w2 + x] == 0xFFFFu;
             }
             if (pairs) e.ones[y * ones_map_cols(W) + x0 / 64u] = allOnes ? stamp : 0u;      // the unoccluded-wavefront map, as ssao_kernel writes it

@@ -61,6 +61,8 @@ class HostSim:
         L.hs_blur_chain_ssao_plane.restype = i; L.hs_blur_chain_ssao_plane.argtypes = [i]
         L.hs_blur_chain_ssao_rows.argtypes = [i, u32, u32, u32, vp, vp]
         L.hs_set_stamp.argtypes = [u32]
+        L.hs_set_prep_margin.argtypes = [i]
+        L.hs_last_unprepared_rows.restype = u32
         L.hs_rasterize.restype = i
         L.hs_rasterize.argtypes = [i, vp, vp, vp, u32, vp, u32, vp, u32, u32, u32, i, f, vp, vp, vp, vp, vp]
         L.hs_light.argtypes = [vp, vp, vp, vp, vp, vp, vp, u32, vp, u32, vp, vp, u32, u32, u32, u32, i, f, u32, vp, u32]
@@ -71,10 +73,11 @@ class HostSim:
         self.lib.hs_eval_array(kind, a.size, a.ctypes.data, b.ctypes.data, out.ctypes.data)
         return out
 
-    def ssao(self, cb, normal_f16, depth_u32, randvec_u8, edge_bytes, row0=0, rows=None, emit=True, pairs=True, cull=True, edge=None, stamp=1):
+    def ssao(self, cb, normal_f16, depth_u32, randvec_u8, edge_bytes, row0=0, rows=None, emit=True, pairs=True, cull=True, edge=None, stamp=1, margin=-1):
         """pairs=True: the taps gather from the decoded depth-pairs plane (the product's path when it has a workspace), and with
         cull=True skip the ones the nearest-depth map proves to add nothing; pairs=False: from the raw D24 plane.
-        edge: a workspace to (re)use as it is -- like the device, nothing clears it; stamp: the frame stamp of this call."""
+        edge: a workspace to (re)use as it is -- like the device, nothing clears it; stamp: the frame stamp of this call;
+        margin: texel rows the depth pass visits beyond the rows of the call (-1: the product's default)."""
         H, W = depth_u32.shape
         rows = H // 2 - row0 if rows is None else rows
         out = np.zeros((H // 2, W // 2), dtype=np.uint16)
@@ -82,6 +85,7 @@ class HostSim:
             edge = np.zeros((edge_bytes,), dtype=np.uint8)
         n = np.ascontiguousarray(normal_f16.view(np.uint16)); d = np.ascontiguousarray(depth_u32); r = np.ascontiguousarray(randvec_u8)
         self.lib.hs_set_stamp(int(stamp))
+        self.lib.hs_set_prep_margin(int(margin))
         self.lib.hs_ssao_path(C.addressof(cb), n.ctypes.data, d.ctypes.data, r.ctypes.data, out.ctypes.data if emit else None,
                               edge.ctypes.data, W, H, row0, rows, (1 if cull else 2) if pairs else 0)
         return out, edge
@@ -94,7 +98,7 @@ class HostSim:
         return out
 
     def compute_ssao(self, cb, normal_f16, depth_u32, randvec_u8, edge_bytes, blur_count, row0=0, rows=None, use_exit=True, ones_margin=None,
-                     edge=None, stamp=1):
+                     edge=None, stamp=1, margin=-1):
         """Ssao::ComputeSsao as api.cpp sequences it (SSAO pass, then the two-launch blur chain of blur_tiles.hpp through the
         kernels' own tile bodies).  Returns (ambient0, edge); rows [row0, row0 + rows) of ambient0 are the result.
         ones_margin: the reach the unoccluded-tile exit assumes (default: what api.cpp passes, 5 per iteration)."""
@@ -103,7 +107,7 @@ class HostSim:
         rows = h2 - row0 if rows is None else rows
         r0, rn = C.c_uint32(), C.c_uint32()
         self.lib.hs_blur_chain_ssao_rows(blur_count, row0, rows, h2, C.addressof(r0), C.addressof(rn))
-        out, edge = self.ssao(cb, normal_f16, depth_u32, randvec_u8, edge_bytes, r0.value, rn.value, edge=edge, stamp=stamp)
+        out, edge = self.ssao(cb, normal_f16, depth_u32, randvec_u8, edge_bytes, r0.value, rn.value, edge=edge, stamp=stamp, margin=margin)
         planes = [np.full((h2, W // 2), 0xABCD, dtype=np.uint16), np.full((h2, W // 2), 0xABCD, dtype=np.uint16)]     # junk where nothing writes
         sp = self.lib.hs_blur_chain_ssao_plane(blur_count)
         planes[sp][r0.value:r0.value + rn.value] = out[r0.value:r0.value + rn.value]

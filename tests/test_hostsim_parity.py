@@ -296,3 +296,26 @@ def test_dark_light_skip_is_exact(built_lib, oracle, hostsim, seed):
             got, rgot = hostsim.light(cb, g0, g1, g2, depth, amb, p["shadow"], p["cube"], 3, 0.0, want_radiance=True)
             assert np.array_equal(got, ref), (d, strength, int((got != ref).sum()))
             assert np.array_equal(rgot.view(np.uint32), rref.view(np.uint32)), (d, strength)
+
+
+@pytest.mark.parametrize("margin", [0, 8, 40])
+def test_row_limited_depth_pass_is_exact(built_lib, oracle, hostsim, margin):
+    """A strip's depth pass visits the strip's rows and a margin only (ssao_core.hpp DepthPairsRows): everything else in the pairs
+    plane and the coarse maps is poison here.  Taps that leave the visited rows gather from the raw plane and are never culled,
+    sky wavefronts whose reach leaves them take no shortcut: the strip equals the oracle for any margin -- on the reference scene
+    (near ground: wide tap discs) and on the sky-probe frames (patches just outside the visited rows)."""
+    import fuzz_util
+    W, H = 256, 512
+    p, c, scb, pcb, eb = setup(W, H, built_lib)
+    want = oracle.ssao(scb, p["normal"], p["depth"], p["randvec"])
+    for row0, rows in ((0, 40), (100, 37), (200, 56), (180, 76)):
+        got, _ = hostsim.ssao(c.ssao_cb, p["normal"], p["depth"], p["randvec"], eb, row0, rows, margin=margin)
+        assert int(hostsim.lib.hs_last_unprepared_rows()) > 0          # the pass really was limited
+        assert np.array_equal(got[row0:row0 + rows], want[row0:row0 + rows]), (row0, rows, int((got[row0:row0 + rows] != want[row0:row0 + rows]).sum()))
+    for seed in (0, 12):
+        W, H, c, scb, depth, normal, randvec = fuzz_util.sky_probe_case(seed)
+        eb = int(built_lib.lib.crychic_edge_plane_bytes(W, H))
+        want = oracle.compute_ssao(scb, normal, depth, randvec, 2)
+        for row0, rows in ((0, H // 8), (H // 6, H // 7), (H // 2 - H // 9, H // 9)):
+            got, _ = hostsim.compute_ssao(c.ssao_cb, normal, depth, randvec, eb, 2, row0, rows, margin=margin)
+            assert np.array_equal(got[row0:row0 + rows], want[row0:row0 + rows]), (seed, row0, rows)
