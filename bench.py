@@ -386,16 +386,7 @@ def dump_scene(d, planes, args, pcf_radius):
 
 def bench_camera(args):
     from crychic_renderer_amd import scene
-    cam = scene.default_camera(args.width, args.height)
-    if args.camera == "covered":
-        # eye moved into the lane between two box columns and pitched down 25 degrees: the top edge of the view still meets
-        # the ground grid and nothing is nearer than the near plane, so every pixel is covered (checked: covered_pixel_fraction)
-        import math
-        a = math.radians(25.0)
-        cam.pos[:] = (2.5, 2.0, -15.0)
-        cam.look[:] = (0.0, -math.sin(a), math.cos(a))
-        cam.up[:] = (0.0, math.cos(a), math.sin(a))
-    return cam
+    return scene.covered_camera(args.width, args.height) if args.camera == "covered" else scene.default_camera(args.width, args.height)
 
 
 # ---- the benchmark proper -------------------------------------------------------------------------------------------------------

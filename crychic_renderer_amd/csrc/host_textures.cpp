@@ -133,6 +133,8 @@ int load_dds(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32_t* w
     std::vector<uint8_t> f((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
     DdsInfo d;
     if (!parse_header(f, d)) return CRYCHIC_E_UNSUPPORTED;
+    // D3D12's own limit (D3D12_REQ_TEXTURE2D_U_OR_V_DIMENSION): also keeps every size computed below far from wrapping
+    if (d.width == 0 || d.height == 0 || d.width > 16384u || d.height > 16384u) return CRYCHIC_E_UNSUPPORTED;
     uint32_t levels = 1;
     if (wantMips && (rd32(&f[8]) & 0x20000u)) {                // DDSD_MIPMAPCOUNT
         levels = rd32(&f[28]);

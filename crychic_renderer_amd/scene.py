@@ -35,6 +35,18 @@ def default_camera(W, H):
     return cam
 
 
+def covered_camera(W, H):
+    """The benchmark's "covered" camera (bench.py --camera covered): the eye moved into the lane between two box columns and
+    pitched down 25 degrees, so that the top edge of the view still meets the ground grid and nothing is nearer than the near
+    plane -- every pixel is covered (no sky) and every G-buffer texel is read."""
+    cam = default_camera(W, H)
+    a = math.radians(25.0)
+    cam.pos[:] = (2.5, 2.0, -15.0)
+    cam.look[:] = (0.0, -math.sin(a), math.cos(a))
+    cam.up[:] = (0.0, math.cos(a), math.sin(a))
+    return cam
+
+
 class Constants:
     """SsaoConstants + PassConstants + the light matrices of one frame (UpdateSsaoCB / UpdateMainPassCB /
     UpdateCascadeShadowTransform, CRYCHIC.cpp:634-937), built by the library's host code."""

@@ -202,7 +202,7 @@ public:
         f.numDirLights = mNumDirLights;
         f.pcfSearchRadius = crychic_pcf_search_radius(mShadowMap->Width(), mPcfLiteral ? 1 : 0);
         f.flags = mSkyEnabled ? CRYCHIC_LIGHT_SKY : 0u;                                             // :278-279
-        f.row0 = mStripRow0; f.rows = mStripRows ? mStripRows : mClientHeight - mStripRow0;           // whole frame unless SetStrip / JoinNode
+        f.row0 = mStripRow0; f.rows = mWholeFrame ? mClientHeight : mStripRows;                      // whole frame unless SetStrip / JoinNode
         f.normal_dev = mSsao->NormalMap()->Data();
         f.depth_dev = static_cast<const uint32_t*>(mDepthStencilBuffer->Data());
         f.randvec_dev = static_cast<const uint8_t*>(mSsao->RandomVectorMap()->Data());
@@ -233,8 +233,15 @@ public:
     }
 
     // ---- one frame on several GPUs (no counterpart in the single-GPU reference) ----------------------------------
-    // Rows [row0, row0 + rows) are this GPU's share of the hot path (row0 even); rows == 0 means "to the bottom".
-    void SetStrip(UINT row0, UINT rows) { mStripRow0 = row0; mStripRows = rows; }
+    // Rows [row0, row0 + rows) are this GPU's share of the hot path (row0 even).  An empty share is refused: a rank without rows
+    // would have nothing to contribute to the gather (and "0 rows" must never come to mean "the whole frame").
+    void SetStrip(UINT row0, UINT rows)
+    {
+        if (rows == 0 || row0 >= mClientHeight || rows > mClientHeight - row0)
+            throw CrychicException(CRYCHIC_E_INVALID_ARG, "CRYCHIC::SetStrip (empty strip or rows outside the frame)", __FILE__, __LINE__);
+        mStripRow0 = row0; mStripRows = rows; mWholeFrame = false;
+    }
+    void SetWholeFrame() { mStripRow0 = 0; mStripRows = 0; mWholeFrame = true; }
     // One process per GPU: `id` is the rendezvous id rank 0 obtained from crychic_comm_unique_id and handed to its peers.
     // Takes the crychic_strip_rows plan unless `bounds` (nranks x {row0, rows}) gives another tiling.
     void JoinNode(int nranks, int rank, const uint8_t id[CRYCHIC_COMM_ID_BYTES], const std::vector<uint32_t>& bounds = {})
@@ -251,7 +258,7 @@ public:
     {
         if (mComm) { mCommandList->Flush(); crychic_comm_destroy(mComm); mComm = nullptr; }
         mStripBounds.clear();
-        SetStrip(0, 0);
+        SetWholeFrame();
     }
 
     // mSwapChain->Present (CRYCHIC.cpp:294-297) for a headless build: read the back buffer back and write it as PPM.
@@ -510,7 +517,7 @@ private:
             mTextures.empty() ? nullptr : mTextures.data(), (uint32_t)mTextures.size(), static_cast<float*>(mDeferred->Resource(0)->Data()),
             static_cast<float*>(mDeferred->Resource(1)->Data()), static_cast<float*>(mDeferred->Resource(2)->Data()),
             static_cast<uint32_t*>(mDepthStencilBuffer->Data()), mClientWidth, mClientHeight, mStripRow0,
-            mStripRows ? mStripRows : mClientHeight - mStripRow0, ws, bytes, mCommandList->Stream()));
+            mWholeFrame ? mClientHeight : mStripRows, ws, bytes, mCommandList->Stream()));
     }
     void DrawNormalsDepthAndGBuffer()  // DrawNormalsAndDepth + DrawGBuffer: same items, same ViewProj, same visibility -> one rasterisation
     {
@@ -524,7 +531,7 @@ private:
             mTextures.empty() ? nullptr : mTextures.data(), (uint32_t)mTextures.size(), mSsao->NormalMap()->Data(),
             static_cast<float*>(mDeferred->Resource(0)->Data()), static_cast<float*>(mDeferred->Resource(1)->Data()),
             static_cast<float*>(mDeferred->Resource(2)->Data()), static_cast<uint32_t*>(mDepthStencilBuffer->Data()), mClientWidth, mClientHeight,
-            mStripRow0, mStripRows ? mStripRows : mClientHeight - mStripRow0, ws, bytes, mCommandList->Stream()));
+            mStripRow0, mWholeFrame ? mClientHeight : mStripRows, ws, bytes, mCommandList->Stream()));
     }
     void UpdateCascadeShadowTransform(const GameTimer&)  // CRYCHIC.cpp:634-815
     {
@@ -573,7 +580,8 @@ private:
     UINT64 mCurrentFence = 0;
     crychic_comm* mComm = nullptr;            // set by JoinNode: this GPU renders a strip and gathers the others'
     std::vector<uint32_t> mStripBounds;       // nranks x {row0, rows}; empty = crychic_strip_rows
-    UINT mStripRow0 = 0, mStripRows = 0;      // 0, 0 = the whole frame
+    UINT mStripRow0 = 0, mStripRows = 0;      // this GPU's rows when the frame is shared
+    bool mWholeFrame = true;
     std::unique_ptr<ID3D12Resource> mDepthStencilBuffer, mBackBuffer, mCubeMap;
     UINT mCubeMapSize = 0;
     UINT mClientWidth, mClientHeight;

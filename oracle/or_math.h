@@ -16,6 +16,22 @@
  * Version 1 (round 1) used unfused chains and IEEE division everywhere; version 2 exists because those choices cost the
  * GPU kernels ~40 % of their instruction issue without being any closer to what a D3D12 driver computes.  DESIGN.md
  * "Oracle definitions" lists every definition.
+ *
+ * DEFINITIONS THAT ARE NOT RESTATEMENTS.  The items above fix precision HLSL leaves open.  Two go further and fix BEHAVIOUR on
+ * inputs where HLSL's own result is different in kind -- they are build-defined semantics, not a reading of the reference:
+ *   - normalize(v) of a zero / denormal-length (or NaN-length) vector.  HLSL: v * rsqrt(0) = 0 * inf = NaN, which the
+ *     shaders' saturate() / max() then turn into 0 (a zero G-buffer or view normal renders BLACK on D3D: `normalize` at
+ *     Ssao.hlsl:125, GBuffer.hlsl:41, DeferredShading.hlsl:32, PBR.hlsl:53).  Here: the squared length is clamped to
+ *     [2^-100, 2^100] first (or_clamp_len2), so the result is the FINITE vector v * 2^50 -- (0,0,0) for an exact zero -- and the
+ *     pixel gets ambient access 1 / finite radiance.  Unreachable with the reference's producers (normals are normalised in
+ *     the vertex shaders, the normal map is cleared to (0,0,1,0), CRYCHIC.cpp:2526; the G-buffer is lit only under covered
+ *     pixels), reachable through the C ABI with hand-made planes.  tests/test_numpy_restatements.py::
+ *     test_zero_normal_is_a_definition shows the two behaviours side by side.
+ *   - pow(x, y) outside x > 0 (or_pow: x = 0 or subnormal -> 0, x < 0 or NaN -> NaN).  HLSL pow(x, y) = exp2(y * log2(x)) gives
+ *     NaN for x < 0 as well, 0 for x = 0 and is unspecified on subnormals; the only call with a computed base is the tone map
+ *     pow(direct / (direct + 1), 1 / 2.2) (DeferredShading.hlsl:89-90), whose base is >= 0 unless an input is negative or NaN.
+ * Both are shared bit for bit by the kernels (csrc/devmath.hpp) and pinned by the fuzz tests (tests/test_fuzz.py: zero, NaN and
+ * infinite vectors in every plane).
  */
 #ifndef OR_MATH_H
 #define OR_MATH_H

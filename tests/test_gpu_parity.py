@@ -366,6 +366,46 @@ def test_c3_4k_properties(ctx, built_lib, oracle):
         assert np.array_equal(app.mBackBuffer.cpu().numpy(), ref)
 
 
+def test_c3_4k_covered_camera_whole_frame(ctx, built_lib, oracle):
+    """The benchmark's covered-camera leg (bench.py config.camera_covered: camera pitched down until no pixel is sky, so none of
+    the sky exits fires and every G-buffer texel is read), 3840x2160, blurCount 4, 3 lights, 4 x 4096^2 cascades: the whole frame
+    against the oracle on a many-core host (the GPU box's), two bands of it elsewhere."""
+    import os
+    from crychic_renderer_amd import Crychic, scene
+    W, H = 3840, 2160
+    planes = scene.make_scene(W, H, shadow_dim=4096, cube_dim=256, device=str(ctx.device),
+                              consts=scene.Constants(W, H, 4096, cam=scene.covered_camera(W, H)))
+    p = scene_util.np_planes(planes)
+    consts = planes["consts"]
+    assert ((p["depth"] & 0xFFFFFF) != 0xFFFFFF).all()
+    scb = oracle_lib.as_oracle_cb(consts.ssao_cb, oracle_lib.OrSsaoConstants)
+    pcb = oracle_lib.as_oracle_cb(consts.pass_cb, oracle_lib.OrPassConstants)
+    app = Crychic(ctx, W, H, planes["randvec"], planes["cube"], shadow_dim=4096)
+    app.load_scene(planes)
+    app.blurCount, app.numDirLights = 4, 3
+    app.Draw()
+    torch.cuda.synchronize()
+    full = app.mBackBuffer.cpu().numpy()
+    ao = dev_u16(app.mSsao.mAmbientMap0)
+    if (os.cpu_count() or 1) >= 32:
+        ref_ao = oracle.compute_ssao(scb, p["normal"], p["depth"], p["randvec"], 4)
+        assert np.array_equal(ao, ref_ao), "AO differs in %d texels" % int((ao != ref_ao).sum())
+        ref = oracle.deferred_light(pcb, p["g0"], p["g1"], p["g2"], p["depth"], ref_ao, p["shadow"], p["cube"], 3, app.pcfSearchRadius)
+        assert np.array_equal(full, ref), "frame differs in %d bytes" % int((full != ref).sum())
+    else:
+        for band0, band1 in ((H // 2 - 16, H // 2 + 16), (H - 32, H)):
+            ref_ssao = oracle.ssao(scb, p["normal"], p["depth"], p["randvec"], band0 // 2, (band1 - band0) // 2)
+            check = built_lib.check
+            a = torch.zeros((H // 2, W // 2), dtype=torch.int16, device=ctx.device)
+            check(built_lib.lib.crychic_ssao(ctx.handle, C.byref(consts.ssao_cb), ptr(planes["normal"]), ptr(planes["depth"]), ptr(planes["randvec"]),
+                                             ptr(a), ptr(app.mSsao.mEdge), W, H, band0 // 2, (band1 - band0) // 2, stream(ctx)))
+            torch.cuda.synchronize()
+            assert np.array_equal(dev_u16(a)[band0 // 2:band1 // 2], ref_ssao[band0 // 2:band1 // 2])
+            ref_band = oracle.deferred_light(pcb, p["g0"], p["g1"], p["g2"], p["depth"], ao, p["shadow"], p["cube"], 3, app.pcfSearchRadius,
+                                             row0=band0, rows=band1 - band0)
+            assert np.array_equal(full[band0:band1], ref_band[band0:band1])
+
+
 @pytest.mark.parametrize("seed", [0, 1, 3, 12, 13, 15, 18])
 def test_sky_shortcut_on_device(ctx, built_lib, oracle, seed):
     """The SSAO sky shortcut on the device (wave-level skip driven by the coarse geometry map of depth_pairs_kernel) against the

@@ -279,3 +279,36 @@ def test_numpy_lighting_agrees_with_oracle(oracle, W, H, lights):
     assert close.mean() >= 0.998, (close.mean(), np.abs(gg - rr).max())
     d8 = np.abs(unorm_write(gg, 255) - ref8[covered].astype(np.int64))
     assert (d8 <= 1).mean() >= 0.998 and (d8 == 0).mean() >= 0.97, ((d8 <= 1).mean(), (d8 == 0).mean(), d8.max())
+
+
+def test_zero_normal_is_a_definition(oracle):
+    """Where the oracle DEFINES rather than restates (oracle/or_math.h "definitions that are not restatements"): normalize() of a
+    zero vector.  The HLSL text gives 0 * rsqrt(0) = NaN, which saturate() / max() turn into 0: SSAO over a zero view normal has
+    dp = max(dot(NaN, .), 0) = 0 for every tap => access 1 (the same 65535 either way), but a zero G-buffer normal lights to
+    NaN radiance => BLACK after the UNORM write on D3D.  The oracle clamps the squared length first, so the normal stays (0,0,0):
+    finite radiance, a visible pixel.  This test states both sides, so the documented difference cannot drift unnoticed."""
+    W, H = 64, 64
+    p, c, scb, pcb = _scene(W, H)
+    g2 = p["g2"].copy()
+    depth = p["depth"]
+    zero = np.zeros((H, W), dtype=bool); zero[H // 2:, 16:48] = True
+    zero &= (depth & 0xFFFFFF) != 0xFFFFFF                               # covered pixels only
+    assert zero.sum() > 200
+    g2[zero, :3] = 0.0
+    ao = np.full((H // 2, W // 2), 65535, dtype=np.uint16)
+    ref8, ref = oracle.deferred_light(pcb, p["g0"], p["g1"], g2, depth, ao, p["shadow"], p["cube"], 3, 0.0, want_radiance=True)
+    with np.errstate(all="ignore"):
+        lit, covered = numpy_light(pcb, p["g0"], p["g1"], g2, depth, ao, p["shadow"], p["cube"], 3)
+    # the HLSL text: NaN radiance on the zero-normal pixels, black after the UNORM write
+    assert np.isnan(lit[zero][:, :3]).all()
+    assert (unorm_write(lit[zero][:, :3], 255) == 0).all()
+    # the oracle's definition: finite radiance there (ambient + tone-mapped direct with a zero normal), not black
+    assert np.isfinite(ref[zero]).all() and (ref8[zero][:, :3] > 0).all()
+    # and everywhere else the two still agree as in test_numpy_lighting_agrees_with_oracle
+    rest = covered & ~zero
+    rr, gg = ref[rest].astype(F), lit[rest]
+    assert (np.abs(gg - rr) <= 1e-5 + 1e-4 * np.abs(rr)).all(axis=-1).mean() >= 0.998
+    # SSAO: a zero view normal gives access 1 under both readings
+    normal = p["normal"].copy(); normal[:] = 0
+    got = oracle.ssao(scb, normal, p["depth"], p["randvec"])
+    assert (got == 65535).all()

@@ -217,3 +217,28 @@ def test_reference_textures_mip_chains(built_lib, oracle):
             lo = got[1].astype(np.float32)
             hi = got[0].astype(np.float32).reshape(lo.shape[0], 2, lo.shape[1], 2, 4).mean(axis=(1, 3))
             assert np.abs(lo - hi).mean() < 12.0, name
+
+
+def test_dds_header_with_absurd_size_is_refused(built_lib, tmp_path):
+    """A header announcing 2^31 x 2^31 texels (width * height * 4 wraps to 0) must be refused before any size is computed from it
+    (ADVICE r2); so is a zero-sized one."""
+    import ctypes as C
+    import struct
+    lib = built_lib.lib
+    def header(w, h):
+        hdr = bytearray(128)
+        hdr[0:4] = b"DDS "
+        struct.pack_into("<7I", hdr, 4, 124, 0x1007, h, w, w * 4 & 0xFFFFFFFF, 0, 1)
+        struct.pack_into("<8I", hdr, 76, 32, 0x41, 0, 32, 0x00FF0000, 0x0000FF00, 0x000000FF, 0xFF000000)      # 32-bit masks
+        return bytes(hdr)
+    for w, h in ((1 << 31, 1 << 31), (0, 4), (20000, 4)):
+        path = str(tmp_path / ("bad_%d_%d.dds" % (w % 997, h % 997)))
+        open(path, "wb").write(header(w, h) + b"\0" * 64)
+        ww, hh = C.c_uint32(), C.c_uint32()
+        buf = (C.c_uint8 * 64)()
+        assert lib.crychic_load_dds_rgba8(path.encode(), buf, 64, C.byref(ww), C.byref(hh)) < 0, (w, h)
+    path = str(tmp_path / "ok.dds")
+    open(path, "wb").write(header(4, 4) + bytes(range(64)))
+    ww, hh = C.c_uint32(), C.c_uint32()
+    buf = (C.c_uint8 * 64)()
+    assert lib.crychic_load_dds_rgba8(path.encode(), buf, 64, C.byref(ww), C.byref(hh)) == 0 and (ww.value, hh.value) == (4, 4)
