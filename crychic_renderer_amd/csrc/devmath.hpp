@@ -253,6 +253,36 @@ CRY_HD float det_pow(float x, float y)
     return normal ? r : ((x >= 0.0f) ? 0.0f : u2f(0x7FC00000u));
 }
 
+// det_pow for two values at once (the red and green channel of the tone map): the bit manipulation and the seeds are per
+// lane, the polynomial steps packed; each lane is bit-identical to det_pow.
+CRY_HD v2f rcp_normal2(v2f b)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    const v2f r0{ __builtin_amdgcn_rcpf(b.x), __builtin_amdgcn_rcpf(b.y) };
+    return fma2(fma2(-b, r0, 1.0f), r0, r0);
+#else
+    return v2f{ rcp_normal(b.x), rcp_normal(b.y) };
+#endif
+}
+CRY_HD v2f det_pow2(v2f x, float y)
+{
+    const bool n0 = x.x >= 1.17549435e-38f, n1 = x.y >= 1.17549435e-38f;
+    const uint32_t u0 = f2u(n0 ? x.x : 1.0f) - 0x3F3504F3u, u1 = f2u(n1 ? x.y : 1.0f) - 0x3F3504F3u;
+    const v2f ef{ (float)((int32_t)u0 >> 23), (float)((int32_t)u1 >> 23) };
+    const v2f m{ u2f((u0 & 0x007FFFFFu) + 0x3F3504F3u), u2f((u1 & 0x007FFFFFu) + 0x3F3504F3u) };
+    const v2f s = (m - 1.0f) * rcp_normal2(m + 1.0f);
+    const v2f s2 = s * s;
+    const v2f p = fma2(fma2(fma2(splat(0.43174004554748535f), s2, splat(0.5767142176628113f)), s2, splat(0.9617988467216492f)), s2, splat(2.885390043258667f));
+    const v2f z = y * fma2(s, p, ef);
+    const v2f zc{ clampf(z.x, -125.0f, 127.0f), clampf(z.y, -125.0f, 127.0f) };
+    const v2f n{ __builtin_rintf(zc.x), __builtin_rintf(zc.y) };
+    const v2f f = zc - n;
+    const v2f q = fma2(fma2(fma2(fma2(fma2(fma2(splat(0.00015406982856802642f), f, splat(0.0013400138122960925f)), f, splat(0.009618260897696018f)), f,
+                                           splat(0.05550328269600868f)), f, splat(0.24022649228572845f)), f, splat(0.6931471824645996f)), f, splat(1.0f));
+    const float r0 = __builtin_ldexpf(q.x, (int)n.x), r1 = __builtin_ldexpf(q.y, (int)n.y);
+    return v2f{ n0 ? r0 : ((x.x >= 0.0f) ? 0.0f : u2f(0x7FC00000u)), n1 ? r1 : ((x.y >= 0.0f) ? 0.0f : u2f(0x7FC00000u)) };
+}
+
 // ---- bilinear addressing --------------------------------------------------------------
 struct Bilin { int i0, j0; float fx, fy; };
 

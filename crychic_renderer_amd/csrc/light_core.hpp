@@ -173,22 +173,36 @@ CRY_HD void pbr_light(f3 lightDir, const float* strength, float att, f3 albedo, 
     const float invPi = 1.0f / CRY_PBR_PI;
     const float oneMinusMetal = 1.0f - metalness;
 
-    const float alb[3] = { albedo.x, albedo.y, albedo.z };
-    float res[3] = { result.x, result.y, result.z };
-#pragma unroll
-    for (int ch = 0; ch < 3; ++ch) {
-        const float f0 = lerpf(0.04f, alb[ch], metalness);
-        const float F = fma(1.0f - f0, fr, f0);
-        float fs = 0.25f * D * G * F;
+    // The three colour channels run the same expression tree: red and green as one packed pair (v_pk_*_f32: two channels per
+    // issue slot), blue as scalars.  Every lane is the scalar expression bit for bit (devmath.hpp "two-wide packed fp32").
+    const float c025DG = 0.25f * D * G;
+    {
+        const v2f alb{ albedo.x, albedo.y }, str{ strength[0], strength[1] };
+        const v2f f0 = fma2(splat(metalness), alb - 0.04f, splat(0.04f));       // lerp(0.04, albedo, metalness)
+        const v2f F = fma2(1.0f - f0, splat(fr), f0);
+        v2f fs = c025DG * F;
         fs = fs * rdenom;
-        const float fd = alb[ch] * invPi;
-        const float kd = (1.0f - F) * oneMinusMetal;
-        const float brdf = fixQ4 ? kd * fd + fs : fma(F, fs, kd * fd);  // ks = F (Q4)
-        float lightStrength = strength[ch] * nDotl;           // :104 / :118
-        if (POINT) lightStrength = lightStrength * att;       // :120
-        res[ch] = fma(scale * brdf, lightStrength, res[ch]);  // :105 / :122
+        const v2f fd = alb * invPi;
+        const v2f kd = (1.0f - F) * oneMinusMetal;
+        const v2f brdf = fixQ4 ? kd * fd + fs : fma2(F, fs, kd * fd);           // ks = F (Q4)
+        v2f lightStrength = str * nDotl;                                         // :104 / :118
+        if (POINT) lightStrength = lightStrength * att;                          // :120
+        const v2f res = fma2(scale * brdf, lightStrength, v2f{ result.x, result.y });   // :105 / :122
+        result.x = res.x;
+        result.y = res.y;
     }
-    result = f3{ res[0], res[1], res[2] };
+    {
+        const float f0 = lerpf(0.04f, albedo.z, metalness);
+        const float F = fma(1.0f - f0, fr, f0);
+        float fs = c025DG * F;
+        fs = fs * rdenom;
+        const float fd = albedo.z * invPi;
+        const float kd = (1.0f - F) * oneMinusMetal;
+        const float brdf = fixQ4 ? kd * fd + fs : fma(F, fs, kd * fd);
+        float lightStrength = strength[2] * nDotl;
+        if (POINT) lightStrength = lightStrength * att;
+        result.z = fma(scale * brdf, lightStrength, result.z);
+    }
 }
 
 // One directional light of PBRShading (PBR.hlsl:99-106).
@@ -240,19 +254,28 @@ CRY_HD CubeFetch cube_fetch(const uint32_t* __restrict__ cube, uint32_t dim, f3 
     f.fy = b.fy;
     return f;
 }
+// WANT_ALPHA = false (the reflection lookup of a lit pixel, which uses .rgb only): blue as scalars, .w = 0.
+template <bool WANT_ALPHA = true>
 CRY_HD f4 cube_resolve(const CubeFetch& f)
 {
     const uint32_t t00 = f.p0.a, t10 = f.p0.b, t01 = f.p1.a, t11 = f.p1.b;
-    f4 o;
-    o.x = bilerp(unorm8_to_float(t00 & 255u), unorm8_to_float(t10 & 255u), unorm8_to_float(t01 & 255u),
-                 unorm8_to_float(t11 & 255u), f.fx, f.fy);
-    o.y = bilerp(unorm8_to_float((t00 >> 8) & 255u), unorm8_to_float((t10 >> 8) & 255u),
-                 unorm8_to_float((t01 >> 8) & 255u), unorm8_to_float((t11 >> 8) & 255u), f.fx, f.fy);
-    o.z = bilerp(unorm8_to_float((t00 >> 16) & 255u), unorm8_to_float((t10 >> 16) & 255u),
-                 unorm8_to_float((t01 >> 16) & 255u), unorm8_to_float((t11 >> 16) & 255u), f.fx, f.fy);
-    o.w = bilerp(unorm8_to_float(t00 >> 24), unorm8_to_float(t10 >> 24), unorm8_to_float(t01 >> 24),
-                 unorm8_to_float(t11 >> 24), f.fx, f.fy);
-    return o;
+    // red + green (and blue + alpha) as packed pairs: each lane is bilerp of the decoded texels, bit for bit
+    auto pair = [&](uint32_t sh) {
+        const v2f a00{ unorm8_to_float((t00 >> sh) & 255u), unorm8_to_float((t00 >> (sh + 8u)) & 255u) };
+        const v2f a10{ unorm8_to_float((t10 >> sh) & 255u), unorm8_to_float((t10 >> (sh + 8u)) & 255u) };
+        const v2f a01{ unorm8_to_float((t01 >> sh) & 255u), unorm8_to_float((t01 >> (sh + 8u)) & 255u) };
+        const v2f a11{ unorm8_to_float((t11 >> sh) & 255u), unorm8_to_float((t11 >> (sh + 8u)) & 255u) };
+        const v2f top = lerp2(a00, a10, splat(f.fx)), bot = lerp2(a01, a11, splat(f.fx));
+        return lerp2(top, bot, splat(f.fy));
+    };
+    const v2f rg = pair(0u);
+    if (WANT_ALPHA) {
+        const v2f ba = pair(16u);
+        return f4{ rg.x, rg.y, ba.x, ba.y };
+    }
+    const float b = bilerp(unorm8_to_float((t00 >> 16) & 255u), unorm8_to_float((t10 >> 16) & 255u), unorm8_to_float((t01 >> 16) & 255u),
+                           unorm8_to_float((t11 >> 16) & 255u), f.fx, f.fy);
+    return f4{ rg.x, rg.y, b, 0.0f };
 }
 CRY_HD f4 cube_linear(const uint32_t* __restrict__ cube, uint32_t dim, f3 r) { return cube_resolve(cube_fetch(cube, dim, r)); }
 
@@ -459,15 +482,17 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
 
     const float invGamma = 1.0f / 2.2f;
     f4 lit;
-    lit.x = det_pow(divf(direct.x, direct.x + 1.0f), invGamma) + amb.x;  // :89-92
-    lit.y = det_pow(divf(direct.y, direct.y + 1.0f), invGamma) + amb.y;
+    const v2f d2{ direct.x, direct.y };
+    const v2f tm = det_pow2(d2 * rcp2(d2 + 1.0f), invGamma) + v2f{ amb.x, amb.y };     // :89-92, red and green packed
     lit.z = det_pow(divf(direct.z, direct.z + 1.0f), invGamma) + amb.z;
 
-    const f4 refl = cube_resolve(cf);
+    const f4 refl = cube_resolve<false>(cf);
     const float f0 = 1.0f - saturate(dot3(normalW, r));         // LightingUtil.hlsl:54-57
     const float f5 = f0 * f0 * f0 * f0 * f0;
-    lit.x = fma(shininess * fma(1.0f - R0.x, f5, R0.x), refl.x, lit.x);  // :97
-    lit.y = fma(shininess * fma(1.0f - R0.y, f5, R0.y), refl.y, lit.y);
+    const v2f R02{ R0.x, R0.y };
+    const v2f spec = fma2(shininess * fma2(1.0f - R02, splat(f5), R02), v2f{ refl.x, refl.y }, tm);  // :97
+    lit.x = spec.x;
+    lit.y = spec.y;
     lit.z = fma(shininess * fma(1.0f - R0.z, f5, R0.z), refl.z, lit.z);
     lit.w = 1.0f;                                               // :99
     return lit;

@@ -491,10 +491,15 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
     float occlusionSum = 0.0f;
     auto taps = [&](auto sparseTag) {
     constexpr bool SPARSE = decltype(sparseTag)::value;
+    // the offset vectors of a pair are fetched (scalar loads from the constants) one iteration ahead of their use
+    f3x2 oNext{ v2f{ cb.OffsetVectors[0][0], cb.OffsetVectors[1][0] }, v2f{ cb.OffsetVectors[0][1], cb.OffsetVectors[1][1] },
+                v2f{ cb.OffsetVectors[0][2], cb.OffsetVectors[1][2] } };
 #pragma unroll 1
     for (int i = 0; i < 14; i += 2) {
-        const f3x2 o{ v2f{ cb.OffsetVectors[i][0], cb.OffsetVectors[i + 1][0] }, v2f{ cb.OffsetVectors[i][1], cb.OffsetVectors[i + 1][1] },
-                      v2f{ cb.OffsetVectors[i][2], cb.OffsetVectors[i + 1][2] } };
+        const f3x2 o = oNext;
+        const int in = i + 2 < 14 ? i + 2 : 0;
+        oNext = f3x2{ v2f{ cb.OffsetVectors[in][0], cb.OffsetVectors[in + 1][0] }, v2f{ cb.OffsetVectors[in][1], cb.OffsetVectors[in + 1][1] },
+                      v2f{ cb.OffsetVectors[in][2], cb.OffsetVectors[in + 1][2] } };
         const v2f d2 = 2.0f * dot3x2(rv2, o);                                     // reflect(o, randVec)  :148
         const v2f nd2 = -d2;
         const f3x2 offset{ fma2(nd2, rv2.x, o.x), fma2(nd2, rv2.y, o.y), fma2(nd2, rv2.z, o.z) };
@@ -528,8 +533,8 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
         // tap culling: a tap whose footprint cannot return a surface in front of the pixel adds exactly +0.  Both lookups are
         // issued unconditionally and together (one round trip; a NaN on either side of the comparison: not culled)
         const float cellA = cull.cell(i0a, j0a), cellB = cull.cell(i0b, j0b);
-        const bool ca = Cull::active && (q.z.x >= 1.0e-3f) && (cellA >= pzEps);
-        const bool cb2 = Cull::active && (q.z.y >= 1.0e-3f) && (cellB >= pzEps);
+        const bool ca = Cull::active & (q.z.x >= 1.0e-3f) & (cellA >= pzEps);          // & not &&: neither load may hide behind a branch
+        const bool cb2 = Cull::active & (q.z.y >= 1.0e-3f) & (cellB >= pzEps);
         if (Cull::active) {
 #if defined(__HIP_DEVICE_COMPILE__)
             if (__builtin_amdgcn_ballot_w64(!(ca & cb2)) == 0) continue;      // the whole wavefront skips both taps
