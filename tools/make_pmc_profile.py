@@ -1,13 +1,15 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 PMC passes of tools/pmc_passes.sh (pmc_table.json) plus the kernel-trace stats of a bench.py run into
-profiles/r02_pmc_counters.json, the file bench.py's `roofline` object reads hardware-counter figures from.
+profiles/r03_pmc_counters.json, the file bench.py's `roofline` object reads hardware-counter figures from.
 
     tools/make_pmc_profile.py <pmc dir with pmc_table.json> <kernel_stats.csv of the same workload> [out.json]
 
-Per pass (ssao = depth_pairs_kernel + zmin_combine_kernel + ssao_kernel, blur = all sweeps, light) and per launch of the 4K bench frame:
+Per pass (ssao = depth_pairs_kernel + ssao_kernel, blur = blur_pair_kernel + (blurCount - 1) x blur_replay_kernel, light) and per launch
+of the 4K bench frame:
   hbm_bytes_per_launch  (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950
                         (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact
-  valu_issue_frac       SQ_ACTIVE_INST_VALU * 4 cycles / (1024 SIMDs * kernel cycles at 2.4 GHz)
+  valu_issue_frac       SQ_ACTIVE_INST_VALU * 4 cycles / (1024 SIMDs * kernel cycles), the cycles MEASURED: GRBM_GUI_ACTIVE of the same
+                        dispatches (round 2 assumed 2.4 GHz and got fractions above 1; the part runs these kernels near 2.1 GHz)
   l2_read_GBs           TCP_TCC_READ_REQ_sum * 64 B / kernel time
   ta_busy_frac          TA_TA_BUSY_sum / 256 TAs / kernel cycles
   bound                 the largest of the fractions, by name
@@ -20,12 +22,12 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-CLOCK_GHZ, SIMDS, TAS = 2.4, 1024, 256
+SIMDS, TAS = 1024, 256
 
 
 def main():
     pmc_dir, stats_csv = sys.argv[1], sys.argv[2]
-    out_path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r02_pmc_counters.json")
+    out_path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r03_pmc_counters.json")
     table = json.load(open(os.path.join(pmc_dir, "pmc_table.json")))
     dur = {}
     for r in csv.DictReader(open(stats_csv)):
@@ -51,13 +53,15 @@ def main():
     import bench
     args = type("A", (), {})()
     wl = {"width": 3840, "height": 2160, "blur_count": 4, "lights": 3, "pcf": "literal", "shadow_dim": 4096, "camera": "reference"}
-    passes = {"ssao": [("depth_pairs_kernel", 1), ("zmin_combine_kernel", 1), ("ssao_kernel<true, true>", 1)],
-              "blur": [("blur_kernel<true, true>", 1), ("blur_kernel<false, true>", 1), ("blur_replay_pair_kernel", wl["blur_count"] - 1)],
+    passes = {"ssao": [("depth_pairs_kernel", 1), ("ssao_kernel<true, true, true, false>", 1)],
+              "blur": [("blur_pair_kernel<true>", 1), ("blur_replay_kernel", wl["blur_count"] - 1)],
               "light": [("light_kernel<true, false>", 1)]}
     kernels = {}
     for name, kw in passes.items():
         t = agg(kw)
-        cyc = t["us"] * 1e-6 * CLOCK_GHZ * 1e9
+        cyc = t.get("GRBM_GUI_ACTIVE", 0.0)                 # summed over the pass's launches, like every other counter
+        if cyc <= 0.0:
+            raise SystemExit("GRBM_GUI_ACTIVE missing from the PMC table: the fractions need measured cycles")
         fr = {"valu": t.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (SIMDS * cyc), "ta": t.get("TA_TA_BUSY_sum", 0.0) / TAS / cyc}
         hbm = (2.0 * t.get("FETCH_SIZE", 0.0) + t.get("WRITE_SIZE", 0.0)) * 1024.0
         fr["hbm"] = hbm / (t["us"] * 1e-6) / 8.0e12
@@ -66,8 +70,10 @@ def main():
                          "ta_busy_frac": round(fr["ta"], 3), "hbm_frac_by_counters": round(fr["hbm"], 3),
                          "l2_read_GBs": round(t.get("TCP_TCC_READ_REQ_sum", 0.0) * 64.0 / (t["us"] * 1e-6) / 1e9, 1),
                          "l2_hit_rate": round(t.get("TCC_HIT_sum", 0.0) / max(1.0, t.get("TCC_HIT_sum", 0.0) + t.get("TCC_MISS_sum", 0.0)), 3),
+                         "clock_GHz_implied": round(cyc / (t["us"] * 1e-6) / 1e9, 2),      # PMC-run cycles over the unprofiled duration
                          "bound": max(fr, key=fr.get)}
-    out = {"workload": wl, "kernel_source_hash": bench.kernel_source_hash(), "clock_GHz_assumed": CLOCK_GHZ,
+    out = {"workload": wl, "kernel_source_hash": bench.kernel_source_hash(),
+           "cycles": "GRBM_GUI_ACTIVE per dispatch (measured, no clock assumed)",
            "method": "rocprofv3 --pmc, one pass per counter group, tools/pmc_passes.sh on the torch-free tools/prof_driver; durations from "
                      "rocprofv3 --kernel-trace --stats of bench.py; hbm = (2*FETCH_SIZE + WRITE_SIZE) KiB",
            "kernels": kernels, "per_kernel_counters": {k: v for k, v in table.items() if "cry::" in k}}
