@@ -102,6 +102,61 @@ CRY_HD float pcf_zero_radius(float tap)
     return percentLit * 0.0625f;
 }
 
+// The comparison of gsamShadow in the integer domain.  d24_to_float is non-decreasing in the texel, so `ref <= d24_to_float(t)` is
+// `t >= T(ref)` with T(ref) = the number of D24 values that decode below ref (2^24 if all do: no texel passes; NaN ref: the same,
+// as NaN <= x is false).  ref * (2^24 - 1), truncated, is within [-3, +2] of T (decode rounds by at most half a D24 step, the
+// product by at most one), so T is that estimate minus 2 plus the number of the six candidates there that decode below ref --
+// six decodes once per lookup position instead of four per tap.  Exhaustively checked against the definition on the host
+// (tests/test_devmath_host.py::test_d24_threshold).
+CRY_HD uint32_t d24_threshold(float ref)
+{
+    if (!(ref == ref)) return 0x01000000u;
+    const float rc = __builtin_fminf(__builtin_fmaxf(ref, 0.0f), 1.0f);
+    const int t0 = (int)(rc * 16777215.0f) - 2;
+    const uint32_t base = t0 < 0 ? 0u : (uint32_t)t0;
+    uint32_t T = base;
+#pragma unroll
+    for (uint32_t k = 0; k < 6u; ++k) {
+        const uint32_t t = base + k;
+        T += (t <= 0x00FFFFFFu && d24_to_float(t) < ref) ? 1u : 0u;
+    }
+    return T;
+}
+// The 16 rotated Poisson taps of one cascade lookup (Common.hlsl:301-315) when every tap's footprint lies inside the map and all
+// coordinates are finite (pcf_taps_inside, wave-uniform at the caller): no BORDER selects, no NaN handling, the four compares of
+// a footprint on the raw texels against d24_threshold(depth).  Same taps, same filter weights, same accumulation order as the
+// general loop of pcf_poisson, hence the same bits.  (The two coordinates of a tap as one packed pair: measured 6 % slower.)
+CRY_HD bool pcf_taps_inside(uint32_t dim, float x, float y, float depth, float radius)
+{
+    const float fd = (float)dim, reach = fma(1.42f * radius, fd, 1.0f);      // |rotated poissonDisk[i]| <= 1.415 (points in [-1, 1]^2)
+    const float tx = fma(x, fd, -0.5f), ty = fma(y, fd, -0.5f);
+    return (tx - reach >= 1.0f) & (tx + reach <= fd - 3.0f) & (ty - reach >= 1.0f) & (ty + reach <= fd - 3.0f) & (__builtin_fabsf(depth) < 1.0e30f) &
+           (radius < 64.0f);
+}
+CRY_HD float pcf_poisson_inside(const uint32_t* __restrict__ s, uint32_t dim, float x, float y, float depth, float radius)
+{
+    const float theta = nrand(x, y);                          // :301
+    const float c = det_cos(theta), sn = det_sin(theta);      // :302-303
+    const uint32_t T = d24_threshold(depth);
+    const float fd = (float)dim;
+    const float P[32] = CRY_POISSON_TABLE;
+    float percentLit = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {                            // :308
+        const float px = fma(P[2 * i + 1], -sn, P[2 * i] * c); // mul(poissonDisk[i], float2x2(c, s, -s, c))
+        const float py = fma(P[2 * i + 1], c, P[2 * i] * sn);
+        const float tx = fma(fma(px, radius, x), fd, -0.5f), ty = fma(fma(py, radius, y), fd, -0.5f);     // bilinear_setup, in range
+        const float flx = __builtin_floorf(tx), fly = __builtin_floorf(ty);
+        const float fx = tx - flx, fy = ty - fly;
+        const uint32_t t0 = mul24((uint32_t)(int)fly, dim) + (uint32_t)(int)flx;
+        const RawPair r0 = load_pair(s, t0), r1 = load_pair(s, t0 + dim);
+        const float c00 = (r0.lo & 0x00FFFFFFu) >= T ? 1.0f : 0.0f, c10 = (r0.hi & 0x00FFFFFFu) >= T ? 1.0f : 0.0f;
+        const float c01 = (r1.lo & 0x00FFFFFFu) >= T ? 1.0f : 0.0f, c11 = (r1.hi & 0x00FFFFFFu) >= T ? 1.0f : 0.0f;
+        percentLit += bilerp(c00, c10, c01, c11, fx, fy);     // :311-313
+    }
+    return percentLit * 0.0625f;                              // :315
+}
+
 // CalcCascadeShadowFactorWithPoisson  Common.hlsl:263-317
 // ZERO_RADIUS is a compile-time promise that radius == 0 (the reference's own value): it removes the general tap loop
 // from the instantiation the reference-literal configuration runs.
@@ -117,6 +172,11 @@ CRY_HD float pcf_poisson(const uint32_t* __restrict__ s, uint32_t dim, float spx
     if (ZERO_RADIUS || radius == 0.0f) {
         return pcf_zero_radius(shadow_cmp_linear(s, dim, x, y, depth));
     } else {
+        bool inside = pcf_taps_inside(dim, x, y, depth, radius);
+#if defined(__HIP_DEVICE_COMPILE__)
+        inside = __builtin_amdgcn_ballot_w64(!inside) == 0;      // wave-uniform: the rim of a cascade runs the general loop
+#endif
+        if (inside) return pcf_poisson_inside(s, dim, x, y, depth, radius);
         const float theta = nrand(x, y);                          // :301
         const float c = det_cos(theta), sn = det_sin(theta);      // :302-303
         const float P[32] = CRY_POISSON_TABLE;

@@ -23,6 +23,32 @@ float hs_det_exp2(float x) { return det_exp2(x); }
 float hs_det_pow(float x, float y) { return det_pow(x, y); }
 float hs_nrand(float u, float v) { return nrand(u, v); }
 
+// d24_threshold against its definition, for every D24 value t and the references decode(t), the float below and the float above:
+// returns the number of mismatches (0 expected).  Also probes the out-of-range references.
+uint32_t hs_check_d24_threshold(void)
+{
+    uint32_t bad = 0;
+    auto expect = [](float ref, uint32_t near) {
+        uint32_t lo = near > 8u ? near - 8u : 0u;
+        uint32_t T = lo;
+        while (T <= 0x00FFFFFFu && d24_to_float(T) < ref) ++T;          // monotone: the first value that does not decode below ref
+        return T;
+    };
+    for (uint32_t t = 0; t <= 0x00FFFFFFu; ++t) {
+        const float d = d24_to_float(t);
+        const float refs[3] = { d, __builtin_nextafterf(d, 2.0f), __builtin_nextafterf(d, -1.0f) };
+        for (float r : refs) bad += d24_threshold(r) != expect(r, t) ? 1u : 0u;
+    }
+    const float special[] = { -1.0f, -0.0f, 0.0f, 1.0f, 1.0000001f, 2.0f, 1.0e30f, -1.0e30f, __builtin_inff(), -__builtin_inff() };
+    for (float r : special) {
+        uint32_t T = 0;
+        while (T <= 0x00FFFFFFu && d24_to_float(T) < r) { if (r > 1.5f) { T = 0x01000000u; break; } ++T; }
+        bad += d24_threshold(r) != T ? 1u : 0u;
+    }
+    bad += d24_threshold(__builtin_nanf("")) != 0x01000000u ? 1u : 0u;
+    return bad;
+}
+
 // kind: 0 sin, 1 cos, 2 log2, 3 exp2, 4 pow, 5 nrand, 6 d24, 7 unorm16, 8 unorm8, 9 half (same numbering as or_eval_array)
 void hs_eval_array(int kind, size_t n, const float* in, const float* in2, float* out)
 {

@@ -50,6 +50,7 @@ class HostSim:
             getattr(L, n).restype = f; getattr(L, n).argtypes = [f]
         L.hs_det_pow.restype = f; L.hs_det_pow.argtypes = [f, f]
         L.hs_nrand.restype = f; L.hs_nrand.argtypes = [f, f]
+        L.hs_check_d24_threshold.restype = u32
         L.hs_eval_array.argtypes = [i, C.c_size_t, vp, vp, vp]
         L.hs_ssao.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, u32, u32]
         L.hs_ssao_path.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, i]

@@ -42,3 +42,9 @@ def test_transcendentals_bit_identical(hostsim, oracle):
     assert np.array_equal(bits(hostsim.eval_array(4, base, expo)), bits(oracle.eval_array(4, base, expo)))
     u = rng.uniform(-2, 3, 200000).astype(np.float32); v = rng.uniform(-2, 3, 200000).astype(np.float32)
     assert np.array_equal(bits(hostsim.eval_array(5, u, v)), bits(oracle.eval_array(5, u, v)))
+
+
+def test_d24_threshold(hostsim):
+    """light_core.hpp d24_threshold(ref): `ref <= d24_to_float(t)` <=> `t >= d24_threshold(ref)` -- checked against the definition
+    for every D24 value (references: the decoded value, its two float neighbours) and for out-of-range / NaN references."""
+    assert int(hostsim.lib.hs_check_d24_threshold()) == 0

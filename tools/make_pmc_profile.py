@@ -8,8 +8,11 @@ Per pass (ssao = depth_pairs_kernel + ssao_kernel, blur = blur_pair_kernel + (bl
 of the 4K bench frame:
   hbm_bytes_per_launch  (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950
                         (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact
-  valu_issue_frac       SQ_ACTIVE_INST_VALU * 4 cycles / (1024 SIMDs * kernel cycles), the cycles MEASURED: GRBM_GUI_ACTIVE of the same
-                        dispatches (round 2 assumed 2.4 GHz and got fractions above 1; the part runs these kernels near 2.1 GHz)
+  valu_issue_frac       SQ_ACTIVE_INST_VALU * 4 cycles (the SQ_ACTIVE_INST_* counters tick in quad-cycles, MI355X_MICROARCH.md) /
+                        (1024 SIMDs * kernel cycles), the cycles MEASURED in the very pass that counted the instructions:
+                        SQ_BUSY_CYCLES / 32 (rocprofv3 sums the 32 shader engines).  Round 2 assumed 2.4 GHz over the unprofiled
+                        duration and got fractions above 1; profiled dispatches run near 2.0 GHz and are not to be mixed with
+                        unprofiled timings.  GRBM_GUI_ACTIVE / 8 is recorded beside it (reads high on dispatches this short)
   l2_read_GBs           TCP_TCC_READ_REQ_sum * 64 B / kernel time
   ta_busy_frac          TA_TA_BUSY_sum / 256 TAs / kernel cycles
   bound                 the largest of the fractions, by name
@@ -30,7 +33,7 @@ def main():
     out_path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r03_pmc_counters.json")
     table = json.load(open(os.path.join(pmc_dir, "pmc_table.json")))
     dur = {}
-    for r in csv.DictReader(open(stats_csv)):
+    for r in csv.DictReader(l for l in open(stats_csv) if not l.startswith("#")):
         if "cry::" in r["Name"]:
             dur[r["Name"].split("(")[0].replace("void ", "")] = (float(r["AverageNs"]) * 1e-3, int(r["Calls"]))
 
@@ -59,9 +62,9 @@ def main():
     kernels = {}
     for name, kw in passes.items():
         t = agg(kw)
-        cyc = t.get("GRBM_GUI_ACTIVE", 0.0)                 # summed over the pass's launches, like every other counter
+        cyc = t.get("SQ_BUSY_CYCLES", 0.0) / 32.0           # summed over the pass's launches, like every other counter
         if cyc <= 0.0:
-            raise SystemExit("GRBM_GUI_ACTIVE missing from the PMC table: the fractions need measured cycles")
+            raise SystemExit("SQ_BUSY_CYCLES missing from the PMC table: the fractions need measured cycles")
         fr = {"valu": t.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / (SIMDS * cyc), "ta": t.get("TA_TA_BUSY_sum", 0.0) / TAS / cyc}
         hbm = (2.0 * t.get("FETCH_SIZE", 0.0) + t.get("WRITE_SIZE", 0.0)) * 1024.0
         fr["hbm"] = hbm / (t["us"] * 1e-6) / 8.0e12
@@ -70,10 +73,10 @@ def main():
                          "ta_busy_frac": round(fr["ta"], 3), "hbm_frac_by_counters": round(fr["hbm"], 3),
                          "l2_read_GBs": round(t.get("TCP_TCC_READ_REQ_sum", 0.0) * 64.0 / (t["us"] * 1e-6) / 1e9, 1),
                          "l2_hit_rate": round(t.get("TCC_HIT_sum", 0.0) / max(1.0, t.get("TCC_HIT_sum", 0.0) + t.get("TCC_MISS_sum", 0.0)), 3),
-                         "clock_GHz_implied": round(cyc / (t["us"] * 1e-6) / 1e9, 2),      # PMC-run cycles over the unprofiled duration
+                         "kernel_cycles": int(cyc), "grbm_gui_active_over_8": int(t.get("GRBM_GUI_ACTIVE", 0.0) / 8.0),
                          "bound": max(fr, key=fr.get)}
     out = {"workload": wl, "kernel_source_hash": bench.kernel_source_hash(),
-           "cycles": "GRBM_GUI_ACTIVE per dispatch (measured, no clock assumed)",
+           "cycles": "SQ_BUSY_CYCLES / 32 of the profiled dispatches (measured in the pass that counted the instructions; no clock assumed)",
            "method": "rocprofv3 --pmc, one pass per counter group, tools/pmc_passes.sh on the torch-free tools/prof_driver; durations from "
                      "rocprofv3 --kernel-trace --stats of bench.py; hbm = (2*FETCH_SIZE + WRITE_SIZE) KiB",
            "kernels": kernels, "per_kernel_counters": {k: v for k, v in table.items() if "cry::" in k}}
