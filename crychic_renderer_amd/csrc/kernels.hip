@@ -486,11 +486,12 @@ hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, con
     if (edge_base) e = edge_plane_carve(edge_base, W, H);
     if (use_pairs && !edge_base) return hipErrorInvalidValue;
     dim3 grid = grid_for(W / 2, rows);
-    // super-tiles of SX x SY workgroup tiles (64 x 4 half-res pixels each) per XCD; the grid is padded to whole super-tiles
-    // 4 x 32 tiles = 256 x 128 half-res pixels (512 x 256 depth texels, 1 MB of the pairs plane plus the reach of the taps
-    // around it, against 4 MiB of L2): best of 11 shapes on the pairs plane at 4K (pass 112.2 us with 6 x 32, the best shape on
-    // the raw D24 plane, 106.4 us with 4 x 32; full-width stripes of 16 tile rows were 208 us in round 1)
-    uint32_t SX = 4u, SY = 32u;
+    // super-tiles of SX x SY workgroup tiles (64 x 4 half-res pixels each) per XCD; the grid is padded to whole super-tiles.
+    // 2 x 16 tiles = 128 x 64 half-res pixels.  Round 2 ran 4 x 32 (every tap gathered: L2 locality of the gathers decided); with
+    // the tap culling only one tap in seven gathers and the balance between XCDs -- sky is cheap, near ground is not -- weighs
+    // more: 4K 81.7 -> 77.4 us for the pass, 1080p 33.4 -> 31.7, covered camera equal, 8K +1.5 % (natural order: 77.5 / 31.4 /
+    // +2 % / +3 %; profiles/r03_supertile_sweep.txt)
+    uint32_t SX = 2u, SY = 16u;
     SX = SX > grid.x ? grid.x : SX;
     SY = SY > grid.y ? grid.y : SY;
     grid.x = (grid.x + SX - 1u) / SX * SX;
