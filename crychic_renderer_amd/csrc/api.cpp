@@ -139,6 +139,9 @@ int fill_light_params(cry::LightParams& P, const crychic_pass_constants* cb, con
     P.numPointLights = 0;
     P.shadowWIsOne = cry::light_shadow_w_is_one(P.ShadowTransforms) ? 1u : 0u;
     P.darkLights = cry::light_dark_mask(P.Lights, numDirLights);
+    P.unitLights = cry::light_dark_lengths_ok(P.Lights, numDirLights) ? 1u : 0u;
+    P.rcpW = cry::rcp((float)W);          // sky_pixel's pixel-centre uv: (x + 0.5) * rcp(W), the reciprocal taken once
+    P.rcpH = cry::rcp((float)H);
     return 0;
 }
 

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, co
                                                    const uint32_t* __restrict__ randvec,
                                                    uint16_t* __restrict__ ambient, EdgePlane edge, uint32_t W,
                                                    uint32_t H, uint32_t row0, uint32_t row1, uint32_t SX, uint32_t SY, int sparseProjTex,
-                                                   SkyReach sky, uint32_t stamp, int cullEnabled, PrepRows prep)
+                                                   SkyReach sky, uint32_t stamp, int cullEnabled, PrepRows prep, HalfResScale hs)
 {
     const uint32_t w2 = W / 2;
     uint32_t bx, by;
@@ -193,13 +193,13 @@ __global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, co
         const ZminMap zm{ edge.zcull, zmin_map_cols(W) };
         if (ROWS) {      // PAIRS && MAPS
             const DepthPairsRows dr{ dp, dd, prep.j0lo, prep.nj };
-            if (cullEnabled) v = ssao_pixel(cb, c, dr, randvec, W, H, x, y, sparseProjTex != 0, ZminMapRows{ zm, prep.j0lo, prep.nj });
-            else v = ssao_pixel(cb, c, dr, randvec, W, H, x, y, sparseProjTex != 0);
+            if (cullEnabled) v = ssao_pixel(cb, c, dr, randvec, W, H, x, y, hs, sparseProjTex != 0, ZminMapRows{ zm, prep.j0lo, prep.nj });
+            else v = ssao_pixel(cb, c, dr, randvec, W, H, x, y, hs, sparseProjTex != 0);
         }
-        else if (PAIRS && MAPS && cullEnabled) v = ssao_pixel(cb, c, dp, randvec, W, H, x, y, sparseProjTex != 0, zm);
-        else if (PAIRS) v = ssao_pixel(cb, c, dp, randvec, W, H, x, y, sparseProjTex != 0);
-        else if (MAPS && cullEnabled) v = ssao_pixel(cb, c, dd, randvec, W, H, x, y, sparseProjTex != 0, zm);
-        else v = ssao_pixel(cb, c, dd, randvec, W, H, x, y, sparseProjTex != 0);
+        else if (PAIRS && MAPS && cullEnabled) v = ssao_pixel(cb, c, dp, randvec, W, H, x, y, hs, sparseProjTex != 0, zm);
+        else if (PAIRS) v = ssao_pixel(cb, c, dp, randvec, W, H, x, y, hs, sparseProjTex != 0);
+        else if (MAPS && cullEnabled) v = ssao_pixel(cb, c, dd, randvec, W, H, x, y, hs, sparseProjTex != 0, zm);
+        else v = ssao_pixel(cb, c, dd, randvec, W, H, x, y, hs, sparseProjTex != 0);
         ambient[y * w2 + x] = (uint16_t)v;
         // unoccluded-wavefront map (ssao_core.hpp "unoccluded tiles"): lane 0 is live whenever the wave is (x = 64 bx < w2).  The
         // word is written by EVERY wavefront that emits ambient values -- the stamp or 0 -- so no word of a row computed this
@@ -510,7 +510,7 @@ hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, con
         sky.y0 = 8 * (int)c0 - 2 < 0 ? 0 : 8 * (int)c0 - 2;
         sky.y1 = 8 * (int)(c0 + cn) - 2 > (int)H ? (int)H : 8 * (int)(c0 + cn) - 2;
     }
-#define CRY_LAUNCH_SSAO(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, cb, (const u2*)normal, depth, (const uint32_t*)randvec, ambient, e, W, H, row0, row0 + rows, SX, SY, sparse, sky, stamp, cull, prep)
+#define CRY_LAUNCH_SSAO(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, cb, (const u2*)normal, depth, (const uint32_t*)randvec, ambient, e, W, H, row0, row0 + rows, SX, SY, sparse, sky, stamp, cull, prep, half_res_scale(W, H))
     if (!emit_ao) CRY_LAUNCH_SSAO((ssao_kernel<false, false, false, false>));
     else if (limited) CRY_LAUNCH_SSAO((ssao_kernel<true, true, true, true>));
     else if (use_pairs && maps) CRY_LAUNCH_SSAO((ssao_kernel<true, true, true, false>));

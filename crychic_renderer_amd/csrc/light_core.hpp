@@ -27,6 +27,8 @@ struct LightParams {
     uint32_t numPointLights;
     uint32_t shadowWIsOne;     // light_shadow_w_is_one(): every cascade's ShadowTransform has the w column (0, 0, 0, 1)
     uint32_t darkLights;       // light_dark_mask(): bit i = directional light i has Strength (0, 0, 0) and a sane direction
+    float rcpW, rcpH;          // rcp((float)W), rcp((float)H)
+    uint32_t unitLights;       // light_dark_lengths_ok(): every directional light in use has a finite direction no longer than 1.001
 };
 
 constexpr uint32_t kMaxPointLights = 1024;   // tile masks live in LDS: 32 words
@@ -209,10 +211,14 @@ CRY_HD float pow5(float x) { float x2 = x * x, x4 = x2 * x2; return x4 * x; }
 // GetPBRDesc (PBR.hlsl:72-88) + GetBRDF (:45-70) for light direction `lightDir`; adds scale * brdf * (strength * nDotl * att)
 // in the shader's association order.  Directional lights: att = 1 is skipped (POINT = false).
 // fixQ3 / fixQ4: the CRYCHIC_FIX_Q3 / Q4 forms (crychic_hip.h); both false = the reference as written.
-template <bool POINT>
+// BOUNDED: a promise that the pixel passed light_dark_guard() and that the light direction is no longer than 1.001 (light_dark_mask's
+// test) -- then every reciprocal below has a normal argument with a normal result (the Smith denominators lie in [0.13, 15.2],
+// nDotl * nDotv in [1e-6, 1.01], pi * tt^2 in [2.5e-6, 3.2e4]: see "dark lights"), where rcp_normal IS rcp, two instructions shorter.
+template <bool POINT, bool BOUNDED = false>
 CRY_HD void pbr_light(f3 lightDir, const float* strength, float att, f3 albedo, float roughness, float metalness, f3 normal,
                       f3 view, float scale, f3& result, bool fixQ3 = false, bool fixQ4 = false)
 {
+    auto rcpB = [](float b) { return BOUNDED ? rcp_normal(b) : rcp(b); };
     const f3 halfVec = normalize3(f3{ view.x + lightDir.x, view.y + lightDir.y, view.z + lightDir.z });
     const float hDotv = maxnn(dot3(halfVec, view), 0.001f);
     const float nDotl = maxnn(dot3(normal, lightDir), 0.001f);
@@ -223,13 +229,13 @@ CRY_HD void pbr_light(f3 lightDir, const float* strength, float att, f3 albedo, 
     const float a2 = roughness * roughness;
     const float nDoth = maxnn(dot3(normal, halfVec), 0.001f);
     const float tt = fma(nDoth * nDoth, a2 - 1.0f, 1.0f);
-    const float D = a2 * rcp(CRY_PBR_PI * (tt * tt));
+    const float D = a2 * rcpB(CRY_PBR_PI * (tt * tt));
     // FresnelSchlick :40-43
     const float fr = pow5(saturate(1.0f - nDotvQ));
     // GeometrySmith :29-38 (true nDotv)
     const float k = 0.125f * (roughness + 1.0f) * (roughness + 1.0f);
-    const float G = divf(nDotv, fma(nDotv, 1.0f - k, k)) * divf(nDotl, fma(nDotl, 1.0f - k, k));
-    const float rdenom = rcp(nDotl * (fixQ3 ? nDotv : nDotvQ));
+    const float G = (nDotv * rcpB(fma(nDotv, 1.0f - k, k))) * (nDotl * rcpB(fma(nDotl, 1.0f - k, k)));      // a / b = a * rcp(b)
+    const float rdenom = rcpB(nDotl * (fixQ3 ? nDotv : nDotvQ));
     const float invPi = 1.0f / CRY_PBR_PI;
     const float oneMinusMetal = 1.0f - metalness;
 
@@ -266,11 +272,12 @@ CRY_HD void pbr_light(f3 lightDir, const float* strength, float att, f3 albedo, 
 }
 
 // One directional light of PBRShading (PBR.hlsl:99-106).
+template <bool BOUNDED = false>
 CRY_HD void pbr_dir_light(const crychic_light& L, f3 albedo, float roughness, float metalness, f3 normal, f3 view,
                           float shadow, f3& result, bool fixQ3 = false, bool fixQ4 = false)
 {
-    pbr_light<false>(f3{ -L.Direction[0], -L.Direction[1], -L.Direction[2] }, L.Strength, 1.0f, albedo, roughness, metalness, normal,
-                     view, pow5(shadow), result, fixQ3, fixQ4);
+    pbr_light<false, BOUNDED>(f3{ -L.Direction[0], -L.Direction[1], -L.Direction[2] }, L.Strength, 1.0f, albedo, roughness, metalness, normal,
+                              view, pow5(shadow), result, fixQ3, fixQ4);
 }
 
 // Point light, BUILD-DEFINED EXTENSION: the reference's branch (PBR.hlsl:109-124) is dead code; enabled as evidently
@@ -387,6 +394,14 @@ CRY_HD uint32_t light_dark_mask(const crychic_light* L, int n)
         if (s[0] == 0.0f && s[1] == 0.0f && s[2] == 0.0f && len2 >= 0.25f && len2 <= 1.002f) m |= 1u << i;       // NaN fails every test
     }
     return m;
+}
+CRY_HD bool light_dark_lengths_ok(const crychic_light* L, int n)
+{
+    for (int i = 0; i < n; ++i) {
+        const float* d = L[i].Direction;
+        if (!(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] <= 1.002f)) return false;      // NaN fails
+    }
+    return true;
 }
 CRY_HD bool light_dark_guard(f4a G0, f4a G1, f4a G2)
 {
@@ -525,18 +540,22 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
 
     const float shininess = (1.0f - roughness) * 1.0f;          // :84 (normalW.a == 1)
 
-    uint32_t dark = 0u;                                         // "dark lights" above
+    // "dark lights" above: with a dark light in the list and bounded inputs on every pixel of the wavefront, the dark lights are
+    // skipped and the others -- whose directions light_dark_lengths_ok() vouches for -- take the shorter reciprocals
+    bool bounded = false;
     if (P.darkLights) {
-        bool ok = light_dark_guard(G0, G1, G2);
+        bounded = light_dark_guard(G0, G1, G2);
 #if defined(__HIP_DEVICE_COMPILE__)
-        ok = __builtin_amdgcn_ballot_w64(!ok) == 0;             // wave-uniform: the loop below stays converged
+        bounded = __builtin_amdgcn_ballot_w64(!bounded) == 0;   // wave-uniform: the loop below stays converged
 #endif
-        dark = ok ? P.darkLights : 0u;
     }
+    const uint32_t dark = bounded ? P.darkLights : 0u;
+    const bool shortRcp = bounded && P.unitLights;
     f3 direct{ 0.0f, 0.0f, 0.0f };
     for (int i = 0; i < P.numDirLights; ++i) {                  // PBR.hlsl:99-106; shadowFactors[i>0] == 1 (:46-51)
         if ((dark >> i) & 1u) continue;
-        pbr_dir_light(P.Lights[i], albedo, roughness, metalness, normalW, view, i == 0 ? shadow0 : 1.0f, direct, fixQ3, fixQ4);
+        if (shortRcp) pbr_dir_light<true>(P.Lights[i], albedo, roughness, metalness, normalW, view, i == 0 ? shadow0 : 1.0f, direct, fixQ3, fixQ4);
+        else pbr_dir_light<false>(P.Lights[i], albedo, roughness, metalness, normalW, view, i == 0 ? shadow0 : 1.0f, direct, fixQ3, fixQ4);
     }
     pointLights(posW, albedo, roughness, metalness, normalW, view, direct, fixQ3, fixQ4);   // extension; a no-op in the reference configuration
 
@@ -561,7 +580,7 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
 // sky.hlsl:21-47 for an uncovered pixel: cubemap lookup along the pixel's view ray.
 CRY_HD f4 sky_pixel(const LightParams& P, const uint32_t* __restrict__ cube, uint32_t x, uint32_t y)
 {
-    const float u = divf((float)x + 0.5f, (float)P.W), v = divf((float)y + 0.5f, (float)P.H);
+    const float u = ((float)x + 0.5f) * P.rcpW, v = ((float)y + 0.5f) * P.rcpH;         // (x + 0.5) / W as a * rcp(b)
     const float hx = fma(2.0f, u, -1.0f), hy = fma(-2.0f, v, 1.0f);
     const float phx = mulcol(hx, hy, 0.0f, 1.0f, P.InvProj + 0);
     const float phy = mulcol(hx, hy, 0.0f, 1.0f, P.InvProj + 4);

@@ -446,14 +446,19 @@ CRY_HD SsaoCentre ssao_centre(const crychic_ssao_constants& cb, const u2* __rest
 // Ssao.hlsl:117-199 for half-res pixel (x, y); returns the R16_UNORM ambient value.  `sparseProjTex` = ssao_projtex_is_sparse(cb).
 // `cull`: NoCull, or the ZminMap of the tap culling.  `culledTaps` (host builds only, may be null): two words -- [0] += the number
 // of taps culled, [1] |= bit i for every culled tap i -- for the tests that check that the culling bites.
+// The pixel centre's uv = (x + 0.5) / (W / 2), (y + 0.5) / (H / 2) is a * rcp(b) with a wave-uniform b: the reciprocals are taken
+// once on the host (the same correctly rounded rcp, devmath.hpp) and handed to the kernel.
+struct HalfResScale { float rw2, rh2; };
+CRY_HD HalfResScale half_res_scale(uint32_t W, uint32_t H) { return HalfResScale{ rcp((float)(W / 2)), rcp((float)(H / 2)) }; }
+
 template <class Depth, class Cull = NoCull>
 CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c,
                            const Depth depth, const uint32_t* __restrict__ randvec, uint32_t W,
-                           uint32_t H, uint32_t x, uint32_t y, bool sparseProjTex, const Cull cull = Cull(), uint32_t* culledTaps = nullptr)
+                           uint32_t H, uint32_t x, uint32_t y, const HalfResScale hs, bool sparseProjTex, const Cull cull = Cull(),
+                           uint32_t* culledTaps = nullptr)
 {
-    const uint32_t w2 = W / 2, h2 = H / 2;
-    const float u = divf((float)x + 0.5f, (float)w2);
-    const float v = divf((float)y + 0.5f, (float)h2);
+    const float u = ((float)x + 0.5f) * hs.rw2;
+    const float v = ((float)y + 0.5f) * hs.rh2;
 
     // VS :58-72 evaluated at the pixel centre
     const float hx = fma(2.0f, u, -1.0f), hy = fma(-2.0f, v, 1.0f);

@@ -159,12 +159,13 @@ void hs_ssao_path(const crychic_ssao_constants* cb, const void* normal, const ui
     std::vector<SsaoCentre> row(w2);
     g_sky_waves = 0;
     g_culled_taps = 0;
+    const HalfResScale hs = half_res_scale(W, H);
     auto pixel = [&](uint32_t x, uint32_t y, uint32_t* acc) -> uint32_t {
-        if (limited) return culling ? ssao_pixel(*cb, row[x], dr, (const uint32_t*)randvec, W, H, x, y, sparse, winRows, acc)
-                                    : ssao_pixel(*cb, row[x], dr, (const uint32_t*)randvec, W, H, x, y, sparse);
-        if (culling) return ssao_pixel(*cb, row[x], dp, (const uint32_t*)randvec, W, H, x, y, sparse, win, acc);
-        return pairs ? ssao_pixel(*cb, row[x], dp, (const uint32_t*)randvec, W, H, x, y, sparse)
-                     : ssao_pixel(*cb, row[x], dd, (const uint32_t*)randvec, W, H, x, y, sparse);
+        if (limited) return culling ? ssao_pixel(*cb, row[x], dr, (const uint32_t*)randvec, W, H, x, y, hs, sparse, winRows, acc)
+                                    : ssao_pixel(*cb, row[x], dr, (const uint32_t*)randvec, W, H, x, y, hs, sparse);
+        if (culling) return ssao_pixel(*cb, row[x], dp, (const uint32_t*)randvec, W, H, x, y, hs, sparse, win, acc);
+        return pairs ? ssao_pixel(*cb, row[x], dp, (const uint32_t*)randvec, W, H, x, y, hs, sparse)
+                     : ssao_pixel(*cb, row[x], dd, (const uint32_t*)randvec, W, H, x, y, hs, sparse);
     };
     for (uint32_t y = row0; y < row0 + rows; ++y) {
         for (uint32_t x = 0; x < w2; ++x) {
@@ -288,6 +289,8 @@ void hs_light(const crychic_pass_constants* cb, const float* g0, const float* g1
     P.pointLights = pointLights; P.numPointLights = numPointLights;
     P.shadowWIsOne = light_shadow_w_is_one(P.ShadowTransforms) ? 1u : 0u;
     P.darkLights = light_dark_mask(P.Lights, numDirLights);
+    P.unitLights = light_dark_lengths_ok(P.Lights, numDirLights) ? 1u : 0u;
+    P.rcpW = rcp((float)W); P.rcpH = rcp((float)H);
     const AllPointLights pl{ pointLights, numPointLights };
     const f4a* G0 = (const f4a*)g0; const f4a* G1 = (const f4a*)g1; const f4a* G2 = (const f4a*)g2;
     for (uint32_t y = row0; y < row0 + rows; ++y)

@@ -230,6 +230,53 @@ def test_deferred_light_bit_exact(ctx, built_lib, oracle, W, H, num_dir_lights, 
     assert np.array_equal(got_rad.view(np.uint32), ref_rad.view(np.uint32))
 
 
+@pytest.mark.parametrize("seed", [0, 1])
+def test_dark_light_skip_on_device(ctx, built_lib, oracle, seed):
+    """The device twin of tests/test_hostsim_parity.py::test_dark_light_skip_is_exact: a zero-strength directional light is
+    skipped, and the other lights take the shorter reciprocals, only on wavefronts whose every pixel is inside the input bounds
+    (light_core.hpp "dark lights").  G-buffer values on both sides of every bound, in runs of whole wavefronts and pixel by
+    pixel; device == oracle (RGBA8 and radiance bits)."""
+    import copy
+    import fuzz_util
+    W, H = 256, 64
+    c = get_case(ctx, built_lib, 256, 256)
+    lib, check = built_lib.lib, built_lib.check
+    rng = np.random.default_rng(900 + seed)
+    g0, g1, g2 = (c.np[k][:H].copy() for k in ("g0", "g1", "g2"))
+    depth = np.full((H, W), 1000, dtype=np.uint32)
+    def pick(vals, shape):
+        return rng.choice(np.asarray(vals, dtype=np.float32), size=shape)
+    # rows 0..31: per-wavefront (64 pixels) constant values, rows 32..63: per pixel
+    rough = [0.0, 0.02, 0.03, 0.031, 0.3, 0.8, 1.0, 9.99, 10.0, 10.5, 1e6, np.inf, np.nan, -0.5]
+    alb = [0.0, 0.5, 0.9, 1.0, 15.9, 16.0, 16.5, -16.0, -17.0, 1e5, np.nan]
+    met = [0.0, 0.5, 1.0, 16.0, 16.01, -16.0, 1e9, np.nan]
+    g1[:32, :, 3] = np.repeat(pick(rough, (32, W // 64)), 64, axis=1); g1[32:, :, 3] = pick(rough, (32, W))
+    for ch in range(3):
+        g1[:32, :, ch] = np.repeat(pick(alb, (32, W // 64)), 64, axis=1); g1[32:, :, ch] = pick(alb, (32, W))
+    g0[:32, :, 3] = np.repeat(pick(met, (32, W // 64)), 64, axis=1); g0[32:, :, 3] = pick(met, (32, W))
+    bad = rng.random((H, W)) < 0.03
+    g0[bad, 0] = pick([np.inf, -np.inf, np.nan, 2e30, 1e30], int(bad.sum()))
+    badn = rng.random((H, W)) < 0.03
+    g2[badn, 1] = pick([np.inf, np.nan, 0.0, 3.3e38], int(badn.sum()))
+    amb = rng.integers(0, 65536, size=(H // 2, W // 2), dtype=np.uint16)
+    dev = ctx.device
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32) if a.dtype == np.uint32 else np.ascontiguousarray(a)).to(dev)
+    dg0, dg1, dg2, dd, da = t(g0), t(g1), t(g2), t(depth), torch.from_numpy(amb.view(np.int16)).to(dev)
+    out = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev); rad = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
+    cb = copy.deepcopy(c.consts.pass_cb)
+    for d, strength in (((0.0, -0.707, -0.707), (0.0, 0.0, 0.0)), ((0.0, -1.0004, 0.0), (-0.0, 0.0, -0.0)), ((0.0, -1.01, 0.0), (0.0, 0.0, 0.0)),
+                        ((0.0, -0.707, -0.707), (0.0, 1e-30, 0.0))):
+        cb.Lights[2].Direction[:] = d
+        cb.Lights[2].Strength[:] = strength
+        ocb = oracle_lib.as_oracle_cb(cb, oracle_lib.OrPassConstants)
+        check(lib.crychic_deferred_light(ctx.handle, C.byref(cb), ptr(dg0), ptr(dg1), ptr(dg2), ptr(dd), ptr(da), c.shadow_ptrs, c.np["shadow"].shape[1],
+                                         ptr(c.dev["cube"]), c.np["cube"].shape[1], ptr(out), ptr(rad), W, H, 0, H, 3, 0.0, 0, stream(ctx)))
+        torch.cuda.synchronize()
+        ref, rref = oracle.deferred_light(ocb, g0, g1, g2, depth, amb, c.np["shadow"], c.np["cube"], 3, 0.0, want_radiance=True)
+        assert np.array_equal(out.cpu().numpy(), ref), (d, strength)
+        assert fuzz_util.same_floats(rad.cpu().numpy(), rref), (d, strength)       # x86 and gfx950 differ in the payload of generated NaNs
+
+
 @pytest.mark.parametrize("fixes,literal", [(0x100, 1), (0x200, 1), (0x400, 1), (0x700, 0)])
 def test_quirk_fix_switches_on_device(ctx, built_lib, oracle, fixes, literal):
     """CRYCHIC_FIX_Q1 / Q3 / Q4 through the C ABI == the oracle with the same switches (RGBA8 and radiance bits)."""
