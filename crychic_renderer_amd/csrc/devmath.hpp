@@ -297,6 +297,9 @@ CRY_HD int texel_index(float fl, uint32_t dim)
     return (int)c;
 #endif
 }
+// FINITE: a promise that u and v are finite and small enough for tx, ty to be finite (the caller bounded what they come from):
+// the non-finite case below cannot occur and its tests are dropped.
+template <bool FINITE = false>
 CRY_HD Bilin bilinear_setup(float u, float v, uint32_t w, uint32_t h)
 {
     Bilin b;
@@ -304,7 +307,7 @@ CRY_HD Bilin bilinear_setup(float u, float v, uint32_t w, uint32_t h)
     const float ty = fma(v, (float)h, -0.5f);
     const float flx = __builtin_floorf(tx), fly = __builtin_floorf(ty);
     const float fx = tx - flx, fy = ty - fly;
-    const bool bad = !(fx == fx) | !(fy == fy);   // non-finite coordinates address only out-of-range texels
+    const bool bad = !FINITE && (!(fx == fx) | !(fy == fy));   // non-finite coordinates address only out-of-range texels
     b.fx = bad ? 0.0f : fx;
     b.fy = bad ? 0.0f : fy;
     b.i0 = bad ? -2 : texel_index(flx, w);

@@ -48,10 +48,11 @@ CRY_HD float nrand(float u, float v)
 //
 // gsamShadow: LESS_EQUAL comparison on each texel, then bilinear; BORDER colour 0  (CRYCHIC.cpp:2649-2658)
 struct ShadowFetch { TexelPair p0, p1; Bilin b; };
+template <bool FINITE = false>
 CRY_HD ShadowFetch shadow_fetch(const uint32_t* __restrict__ s, uint32_t dim, float u, float v)
 {
     ShadowFetch f;
-    f.b = bilinear_setup(u, v, dim, dim);
+    f.b = bilinear_setup<FINITE>(u, v, dim, dim);
     const uint32_t r0 = (uint32_t)clampi(f.b.j0, 0, (int)dim - 1), r1 = (uint32_t)clampi(f.b.j0 + 1, 0, (int)dim - 1);
     f.p0 = pair_at(s, r0, dim, f.b.i0);   // one 8-byte load per footprint row
     f.p1 = pair_at(s, r1, dim, f.b.i0);
@@ -470,7 +471,9 @@ template <bool ZERO_RADIUS>
 CRY_HD bool cascade_fetch_uniform(const LightParams& P, f3 posW, float distance, bool fixQ1, CascadePair& c)
 {
     if (!ZERO_RADIUS || fixQ1 || !P.shadowWIsOne) return false;
-    const float pmax = 1.2676506e30f;     // light_shadow_w_is_one: bounded posW
+    // |posW| < 1e15 with the transforms' entries below 1e12 (light_shadow_w_is_one): shadowPosH.w == 1, and the shadow
+    // coordinates stay below 4e27, so the sampler's texel coordinates (x 16384 at most) are finite: bilinear_setup<FINITE>
+    const float pmax = 1.0e15f;
     const int j = cascade_index(distance);
     int J = j;
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -484,8 +487,8 @@ CRY_HD bool cascade_fetch_uniform(const LightParams& P, f3 posW, float distance,
 #endif
     const float* T0 = P.ShadowTransforms[J];
     const float* T1 = P.ShadowTransforms[J + 1];
-    c.f0 = shadow_fetch(P.shadow[J], P.shadowDim, mulcol1(posW.x, posW.y, posW.z, T0 + 0), mulcol1(posW.x, posW.y, posW.z, T0 + 4));
-    c.f1 = shadow_fetch(P.shadow[J + 1], P.shadowDim, mulcol1(posW.x, posW.y, posW.z, T1 + 0), mulcol1(posW.x, posW.y, posW.z, T1 + 4));
+    c.f0 = shadow_fetch<true>(P.shadow[J], P.shadowDim, mulcol1(posW.x, posW.y, posW.z, T0 + 0), mulcol1(posW.x, posW.y, posW.z, T0 + 4));
+    c.f1 = shadow_fetch<true>(P.shadow[J + 1], P.shadowDim, mulcol1(posW.x, posW.y, posW.z, T1 + 0), mulcol1(posW.x, posW.y, posW.z, T1 + 4));
     c.z0 = mulcol1(posW.x, posW.y, posW.z, T0 + 8);
     c.z1 = mulcol1(posW.x, posW.y, posW.z, T1 + 8);
     return true;

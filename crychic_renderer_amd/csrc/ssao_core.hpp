@@ -555,7 +555,9 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
         depth_tap(depth, cb2, i0b, j0b, b00, b10, b01, b11);
         const v2f t00{ a00, b00 }, t10{ a10, b10 }, t01{ a01, b01 }, t11{ a11, b11 };
         const v2f zndc = lerp2(lerp2(t00, t10, fx), lerp2(t01, t11, fx), fy);
-        const v2f rz = B * rcp2(zndc - A);                                        // :164-165
+        // :164-165.  With the tap culling on, the host has checked 1.000002 < A < 1e6 (ssao_cull_params) and zndc is a filtered
+        // decoded D24 value in [0, 1 + 2^-21]: zndc - A is a normal number with a normal reciprocal, where rcp_normal IS rcp
+        const v2f rz = B * (Cull::active ? rcp_normal2(zndc - A) : rcp2(zndc - A));
         const v2f sc = rz * rqz;                                                  // :171
         const f3x2 r{ sc * q.x, sc * q.y, sc * q.z };
         const v2f distZ = p2.z - r.z;                                             // :185
