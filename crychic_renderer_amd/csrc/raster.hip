@@ -4,7 +4,7 @@
 // Structure (all launches stream-ordered, no host synchronisation):
 //   clear_vis      visibility buffer := (depth 1.0, no primitive)
 //   setup_kernel   one lane per (instance, triangle): vertex shader x3, clip to 0 <= z <= w, viewport + 1/256 snap,
-//                  cull; up to 3 setup triangles land in slots fixed by draw order (slot = serial, so equal depths
+//                  cull; up to 7 setup triangles (z and guard-band clipping) land in slots fixed by draw order (slot = serial, so equal depths
 //                  resolve to the earlier primitive exactly like in-order LESS testing); live slots are appended to
 //                  a list with one atomic each
 //   raster_kernel  persistent workgroups walk the live list, one wavefront per small triangle (a workgroup per large one); a 16 x 4 lane footprint sweeps
@@ -68,8 +68,9 @@ __global__ __launch_bounds__(128) void setup_kernel(ItemBatch batch, const crych
     const uint32_t inst = (uint32_t)(gid / ntri), tri = (uint32_t)(gid - (uint64_t)inst * ntri);
     const crychic_instance_data I = item.instances_dev[inst];
     const crychic_material_data* M = (materials && I.MaterialIndex < nMaterials) ? &materials[I.MaterialIndex] : nullptr;
-    const uint32_t slot0 = target * slotsPerTarget + slotBase + (uint32_t)bid * 3u;
-    tris[slot0].A2 = 0; tris[slot0 + 1].A2 = 0; tris[slot0 + 2].A2 = 0;
+    const uint32_t slot0 = target * slotsPerTarget + slotBase + (uint32_t)bid * (uint32_t)kSlotsPerTriangle;
+#pragma unroll
+    for (int c = 0; c < kSlotsPerTriangle; ++c) tris[slot0 + (uint32_t)c].A2 = 0;
 
     VsOut v[3];
     bool bad = false;
@@ -82,8 +83,12 @@ __global__ __launch_bounds__(128) void setup_kernel(ItemBatch batch, const crych
     if (bad) { atomicOr(&counters->overflow, 2u); return; }
 
     bool overflow = false;
-    const bool inside = (v[0].posH[2] >= 0.0f) & (v[1].posH[2] >= 0.0f) & (v[2].posH[2] >= 0.0f) &
-                        (v[0].posH[3] - v[0].posH[2] >= 0.0f) & (v[1].posH[3] - v[1].posH[2] >= 0.0f) & (v[2].posH[3] - v[2].posH[2] >= 0.0f);
+    const float gx = guard_band(W), gy = guard_band(H);
+    bool inside = true;                    // nearly every triangle: inside all six planes, no clipping
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int plane = 0; plane < kClipPlanes; ++plane) inside = inside & (clip_distance(v[c], plane, gx, gy) >= 0.0f);
     if (inside) {
         SetupTri s;
         if (setup_triangle(v[0], v[1], v[2], I.MaterialIndex, W, H, s, &overflow)) {
@@ -92,10 +97,9 @@ __global__ __launch_bounds__(128) void setup_kernel(ItemBatch batch, const crych
             append(s, slot0);
         }
     } else {
-        VsOut poly[8], tmp[8];
+        VsOut poly[kMaxPolyVerts], tmp[kMaxPolyVerts];
         poly[0] = v[0]; poly[1] = v[1]; poly[2] = v[2];
-        int n = clip_plane(poly, 3, 0, tmp);
-        n = clip_plane(tmp, n, 1, poly);
+        const int n = clip_triangle(poly, tmp, W, H);
         for (int c = 1; c + 1 < n; ++c) {
             SetupTri s;
             if (setup_triangle(poly[0], poly[c], poly[c + 1], I.MaterialIndex, W, H, s, &overflow)) {
@@ -191,7 +195,7 @@ __global__ __launch_bounds__(256) void resolve_kernel(int mode, const unsigned l
 
 size_t raster_workspace_bytes(uint64_t triangles, uint32_t W, uint32_t H)
 {
-    const uint64_t slots = triangles * 3u;
+    const uint64_t slots = triangles * (uint64_t)kSlotsPerTriangle;
     return (size_t)((uint64_t)W * H * 8u + slots * sizeof(SetupTri) + slots * 4u + 64u * sizeof(Texture) + sizeof(RasterCounters) + 1024u);
 }
 
@@ -203,7 +207,7 @@ hipError_t launch_raster_pass(RasterPass& p, hipStream_t stream)
     const bool shadow = p.mode == 0;
     const uint32_t nT = (shadow && p.nTargets > 1u) ? p.nTargets : 1u;     // cascades rasterised by one fused shadow pass
     if (nT > 4u) return hipErrorInvalidValue;
-    const uint64_t slotsPerTarget = total * 3u, slots = slotsPerTarget * nT;
+    const uint64_t slotsPerTarget = total * (uint64_t)kSlotsPerTriangle, slots = slotsPerTarget * nT;
     if (slots >= 0xFFFFFFF0ull) return hipErrorInvalidValue;
     if (raster_workspace_bytes(total * nT, p.W, p.H) > p.workspaceBytes || p.nTextures > 64u) return hipErrorInvalidValue;
     char* base = (char*)p.workspace;
@@ -253,7 +257,7 @@ hipError_t launch_raster_pass(RasterPass& p, hipStream_t stream)
         const uint64_t n = b.first[b.n];
         hipLaunchKernelGGL(setup_kernel, dim3((uint32_t)((n + 127u) / 128u), nT), dim3(128), 0, stream, b, p.materials, p.nMaterials,
                            vps, p.W, p.H, tris, slotBase, (uint32_t)slotsPerTarget, live, (uint32_t)slots, counters, yLo, yHi);
-        slotBase += (uint32_t)(n * 3u);
+        slotBase += (uint32_t)(n * (uint64_t)kSlotsPerTriangle);
     }
     if (slots) {
 #define CRY_RASTER(S, F) hipLaunchKernelGGL((raster_kernel<S, F>), dim3(256u * 8u), dim3(256), 0, stream, tris, live, (uint32_t)slots, counters, vis, targets, p.W, p.H, p.depthBias, p.slopeScaledDepthBias, yLo, yHi)

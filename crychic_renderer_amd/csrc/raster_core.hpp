@@ -67,20 +67,56 @@ CRY_HD VsOut lerp_vertex(const VsOut& a, const VsOut& b, float t)
     return o;
 }
 
-// Sutherland-Hodgman against plane 0 (z >= 0) or 1 (w - z >= 0); returns the new vertex count (<= n + 1).
-CRY_HD int clip_plane(const VsOut* in, int n, int plane, VsOut* out)
+// Clipping.  D3D12 clips to 0 <= z <= w (DepthClipEnable, Common/d3dx12.h:203-216) and to a GUARD BAND in x and y: a triangle
+// with a vertex far outside the viewport is rendered, not dropped (CRYCHIC.cpp:2473 draws whatever the scene holds).  The
+// fixed-point edge functions below are defined up to +-2^22 pixels, so a polygon that leaves the band |x|, |y| <= g w with
+// g = 2^21 / (dim / 2) NDC units (i.e. +-2^21 pixels around the viewport centre, half the representable range) is clipped to it;
+// the new edges lie two million pixels outside the target and cannot touch a pixel centre.  A polygon inside the band is not
+// touched, so every image rendered before this clipper existed is unchanged bit for bit.
+// Planes: 0: z >= 0   1: w - z >= 0   2: g w + x >= 0   3: g w - x >= 0   4: g w + y >= 0   5: g w - y >= 0  (g = gx for 2, 3; gy for 4, 5).
+constexpr int kClipPlanes = 6;
+constexpr int kMaxPolyVerts = 3 + kClipPlanes + 1;      // Sutherland-Hodgman adds at most one vertex per plane
+constexpr int kSlotsPerTriangle = 3 + kClipPlanes - 2;   // fan triangles of a 9-gon
+CRY_HD float guard_band(uint32_t dim) { return 2097152.0f / (0.5f * (float)dim); }
+CRY_HD float clip_distance(const VsOut& v, int plane, float gx, float gy)
+{
+    switch (plane) {
+    case 0: return v.posH[2];
+    case 1: return v.posH[3] - v.posH[2];
+    case 2: return gx * v.posH[3] + v.posH[0];
+    case 3: return gx * v.posH[3] - v.posH[0];
+    case 4: return gy * v.posH[3] + v.posH[1];
+    default: return gy * v.posH[3] - v.posH[1];
+    }
+}
+// Sutherland-Hodgman against one plane; returns the new vertex count (<= n + 1).
+CRY_HD int clip_plane(const VsOut* in, int n, int plane, VsOut* out, float gx = 0.0f, float gy = 0.0f)
 {
     int m = 0;
     for (int i = 0; i < n; ++i) {
         const VsOut& a = in[i];
         const VsOut& b = in[(i + 1 == n) ? 0 : i + 1];
-        const float da = plane == 0 ? a.posH[2] : a.posH[3] - a.posH[2];
-        const float db = plane == 0 ? b.posH[2] : b.posH[3] - b.posH[2];
+        const float da = clip_distance(a, plane, gx, gy), db = clip_distance(b, plane, gx, gy);
         const bool ina = da >= 0.0f, inb = db >= 0.0f;
         if (ina) out[m++] = a;
         if (ina != inb) out[m++] = lerp_vertex(a, b, da / (da - db));
     }
     return m;
+}
+// The whole clipper for one triangle: `poly` holds the three vertices on entry and the clipped polygon on return (`tmp` is
+// scratch; both kMaxPolyVerts long).  Only the planes some vertex is outside of are applied, in plane order.
+CRY_HD int clip_triangle(VsOut* poly, VsOut* tmp, uint32_t W, uint32_t H)
+{
+    const float gx = guard_band(W), gy = guard_band(H);
+    int n = 3;
+    for (int plane = 0; plane < kClipPlanes && n >= 3; ++plane) {
+        bool any = false;
+        for (int i = 0; i < n; ++i) any = any | !(clip_distance(poly[i], plane, gx, gy) >= 0.0f);
+        if (!any) continue;
+        n = clip_plane(poly, n, plane, tmp, gx, gy);
+        for (int i = 0; i < n; ++i) poly[i] = tmp[i];
+    }
+    return n;
 }
 
 CRY_HD int64_t orient2d(int32_t ax, int32_t ay, int32_t bx, int32_t by, int32_t px, int32_t py)
@@ -90,8 +126,9 @@ CRY_HD int64_t orient2d(int32_t ax, int32_t ay, int32_t bx, int32_t by, int32_t 
 // clockwise triangle on a y-down screen: left edges run upwards, the top edge runs to the right
 CRY_HD bool is_top_left(int32_t ax, int32_t ay, int32_t bx, int32_t by) { return (by < ay) || (by == ay && bx > ax); }
 
-// Viewport transform + snap + cull.  Returns false (and leaves A2 = 0) for culled / degenerate triangles; sets
-// *overflow when a coordinate leaves the +-2^22 pixel range the fixed-point edge functions are defined for.
+// Viewport transform + snap + cull.  Returns false (and leaves A2 = 0) for culled / degenerate triangles; sets *overflow when a
+// coordinate is outside the +-2^22 pixel range the fixed-point edge functions are defined for -- after clip_triangle that means
+// a non-finite vertex position, nothing else.
 CRY_HD bool setup_triangle(const VsOut& v0, const VsOut& v1, const VsOut& v2, uint32_t matIndex, uint32_t W, uint32_t H,
                            SetupTri& s, bool* overflow)
 {

@@ -320,8 +320,8 @@ int crychic_save_ppm(const char* path, const uint8_t* rgba8, uint32_t width, uin
 size_t crychic_raster_workspace_bytes(uint64_t triangles, uint32_t W, uint32_t H);
 
 /* The three producer passes.  Rasteriser state = CD3DX12_RASTERIZER_DESC(D3D12_DEFAULT): solid, cull back, clockwise
- * front, depth clip (Common/d3dx12.h:203-216); depth LESS + write against a target cleared to 1.0 (:120-132); top-left
- * rule, pixel centres at +0.5, 1/256-pixel vertex snap.  `passCB` supplies View / ViewProj.  Every pass clears its
+ * front, depth clip and guard-band clip (Common/d3dx12.h:203-216); depth LESS + write against a target cleared to 1.0 (:120-132);
+ * top-left rule, pixel centres at +0.5, 1/256-pixel vertex snap.  `passCB` supplies View / ViewProj.  Every pass clears its
  * targets first, like the reference (CRYCHIC.cpp:2489-2492, 2526-2527, 2554-2556).
  *   crychic_draw_scene_to_shadow_map : one cascade of CRYCHIC::DrawSceneToShadowMap (CRYCHIC.cpp:2477-2510) with the
  *       shadow PSO's DepthBias / SlopeScaledDepthBias (CRYCHIC.cpp:1601-1603: 10000, 2.0)
@@ -339,11 +339,11 @@ int crychic_draw_gbuffer(crychic_ctx* ctx, const crychic_pass_constants* passCB,
                          const crychic_texture* textures, uint32_t nTextures, float* g0_dev, float* g1_dev, float* g2_dev,
                          uint32_t* depth_dev, uint32_t W, uint32_t H, void* workspace_dev, size_t workspaceBytes, void* stream);
 
-/* What the most recent producer pass on this context had to drop (its workspace must still be alive): waits for `stream`, then
- * *flags = CRYCHIC_RASTER_* bits, 0 when every triangle was rasterised.  The D3D12 runtime clips to a guard band and would render
- * such triangles; this rasteriser clips to 0 <= z <= w only and DROPS a triangle with a vertex beyond +-2^22 pixels (its
- * fixed-point edge functions are defined up to there) -- a caller that can produce such geometry should check. */
-#define CRYCHIC_RASTER_COORD_OVERFLOW 1u   /* a post-clip vertex left the +-2^22 pixel range: triangle dropped */
+/* What the most recent producer pass on this context could not draw (its workspace must still be alive): waits for `stream`, then
+ * *flags = CRYCHIC_RASTER_* bits, 0 when every triangle was rasterised.  Triangles with vertices far outside the viewport ARE
+ * drawn: like the D3D12 runtime the rasteriser clips to 0 <= z <= w and to a guard band (+-2^21 pixels around the viewport centre;
+ * its fixed-point edge functions are defined up to +-2^22).  What remains undrawable is a vertex whose position is not finite. */
+#define CRYCHIC_RASTER_COORD_OVERFLOW 1u   /* a post-clip vertex outside the +-2^22 pixel range (a non-finite position): triangle dropped */
 #define CRYCHIC_RASTER_BAD_INDEX 2u        /* an index pointed outside the item's vertex buffer: triangle dropped */
 int crychic_raster_status(crychic_ctx* ctx, void* stream, uint32_t* flags);
 

@@ -6,7 +6,7 @@
  *
  * Rasteriser definition (D3D11.3 functional spec rules; arithmetic fixed here):
  *   - clip against 0 <= z <= w (depth clip on) in clip space, Sutherland-Hodgman, new vertex = a + t*(b - a),
- *     t = da / (da - db), fan triangulation; no x/y clipping (positions must stay within +-2^22 pixels);
+ *     t = da / (da - db), fan triangulation; then against a guard band of +-2^21 pixels in x and y (see clip_plane);
  *   - viewport: sx = (x/w + 1) * (W/2), sy = (1 - y/w) * (H/2), z = z/w; sx, sy snapped to 1/256 pixel
  *     (floor(v*256 + 0.5)); clockwise on screen = front, back faces culled;
  *   - coverage: 64-bit integer edge functions at pixel centres (+0.5), top-left rule;
@@ -58,14 +58,32 @@ static void lerp_vertex(const vs_out* a, const vs_out* b, float t, vs_out* o)
     for (size_t i = 0; i < sizeof(vs_out) / sizeof(float); ++i) fo[i] = fa[i] + t * (fb[i] - fa[i]);
 }
 
-/* Sutherland-Hodgman against one plane; dist(v) >= 0 is inside.  plane 0: z >= 0, plane 1: w - z >= 0. */
-static int clip_plane(const vs_out* in, int n, int plane, vs_out* out)
+/* Clipping: 0 <= z <= w (DepthClipEnable, Common/d3dx12.h:203-216) and a guard band in x and y -- D3D12 renders a triangle with
+ * a vertex far outside the viewport (CRYCHIC.cpp:2473), it does not drop it.  The band is |x|, |y| <= g w with
+ * g = 2^21 / (dim / 2) NDC units (+-2^21 pixels around the viewport centre: half of the +-2^22 pixels the fixed-point edge
+ * functions are defined for), a build-defined choice where D3D leaves the extent to the hardware; a polygon inside the band is
+ * not touched.  Planes: 0: z >= 0   1: w - z >= 0   2: g w + x >= 0   3: g w - x >= 0   4: g w + y >= 0   5: g w - y >= 0. */
+#define OR_CLIP_PLANES 6
+#define OR_MAX_POLY (3 + OR_CLIP_PLANES + 1)
+static float guard_band(uint32_t dim) { return 2097152.0f / (0.5f * (float)dim); }
+static float clip_distance(const vs_out* v, int plane, float gx, float gy)
+{
+    switch (plane) {
+    case 0: return v->posH[2];
+    case 1: return v->posH[3] - v->posH[2];
+    case 2: return gx * v->posH[3] + v->posH[0];
+    case 3: return gx * v->posH[3] - v->posH[0];
+    case 4: return gy * v->posH[3] + v->posH[1];
+    default: return gy * v->posH[3] - v->posH[1];
+    }
+}
+/* Sutherland-Hodgman against one plane; dist(v) >= 0 is inside. */
+static int clip_plane(const vs_out* in, int n, int plane, vs_out* out, float gx, float gy)
 {
     int m = 0;
     for (int i = 0; i < n; ++i) {
         const vs_out* a = &in[i]; const vs_out* b = &in[(i + 1) % n];
-        float da = plane == 0 ? a->posH[2] : a->posH[3] - a->posH[2];
-        float db = plane == 0 ? b->posH[2] : b->posH[3] - b->posH[2];
+        float da = clip_distance(a, plane, gx, gy), db = clip_distance(b, plane, gx, gy);
         int ina = da >= 0.0f, inb = db >= 0.0f;
         if (ina) out[m++] = *a;
         if (ina != inb) {
@@ -74,6 +92,20 @@ static int clip_plane(const vs_out* in, int n, int plane, vs_out* out)
         }
     }
     return m;
+}
+/* only the planes some vertex is outside of are applied, in plane order */
+static int clip_triangle(vs_out* poly, vs_out* tmp, uint32_t W, uint32_t H)
+{
+    const float gx = guard_band(W), gy = guard_band(H);
+    int n = 3;
+    for (int plane = 0; plane < OR_CLIP_PLANES && n >= 3; ++plane) {
+        int any = 0;
+        for (int i = 0; i < n; ++i) any |= !(clip_distance(&poly[i], plane, gx, gy) >= 0.0f);
+        if (!any) continue;
+        n = clip_plane(poly, n, plane, tmp, gx, gy);
+        for (int i = 0; i < n; ++i) poly[i] = tmp[i];
+    }
+    return n;
 }
 
 static int is_top_left(int32_t ax, int32_t ay, int32_t bx, int32_t by)
@@ -226,14 +258,13 @@ int or_rasterize(int mode, const float view[16], const float viewProj[16], const
             const or_material_data* M = (materials && I->MaterialIndex < nMaterials) ? &materials[I->MaterialIndex] : NULL;
             for (uint32_t k = 0; k < d->vertexCount; ++k) vertex_shader(&d->vertices[k], I, M, viewProj, &vs[k]);
             for (uint32_t t = 0; t + 2 < d->indexCount; t += 3) {
-                vs_out poly[8], tmp[8];
+                vs_out poly[OR_MAX_POLY], tmp[OR_MAX_POLY];
                 for (int c = 0; c < 3; ++c) {
                     int64_t vi = (int64_t)d->indices[d->startIndexLocation + t + c] + d->baseVertexLocation;
                     if (vi < 0 || vi >= (int64_t)d->vertexCount) { free(vs); free(L.t); return -1; }
                     poly[c] = vs[vi];
                 }
-                int n = clip_plane(poly, 3, 0, tmp);
-                n = clip_plane(tmp, n, 1, poly);
+                int n = clip_triangle(poly, tmp, W, H);
                 for (int c = 1; c + 1 < n; ++c) emit_triangle(&L, &poly[0], &poly[c], &poly[c + 1], I->MaterialIndex, W, H);
             }
         }

@@ -327,16 +327,15 @@ int hs_rasterize(int mode, const float* view, const float* viewProj, const crych
                 const crychic_instance_data& I = d.instances_dev[inst];
                 const crychic_material_data* M = (materials && I.MaterialIndex < nMaterials) ? &materials[I.MaterialIndex] : nullptr;
                 const size_t slot0 = tris.size();
-                tris.resize(slot0 + 3);
-                tris[slot0].A2 = tris[slot0 + 1].A2 = tris[slot0 + 2].A2 = 0;
-                VsOut poly[8], tmp[8];
+                tris.resize(slot0 + kSlotsPerTriangle);
+                for (int c = 0; c < kSlotsPerTriangle; ++c) tris[slot0 + (size_t)c].A2 = 0;
+                VsOut poly[kMaxPolyVerts], tmp[kMaxPolyVerts];
                 for (int c = 0; c < 3; ++c) {
                     const int64_t vi = (int64_t)d.indices_dev[d.startIndexLocation + tri * 3u + c] + d.baseVertexLocation;
                     if (vi < 0 || vi >= (int64_t)d.vertexCount) return -1;
                     poly[c] = vertex_shader(d.vertices_dev[vi], I, M, viewProj);
                 }
-                int n = clip_plane(poly, 3, 0, tmp);
-                n = clip_plane(tmp, n, 1, poly);
+                const int n = clip_triangle(poly, tmp, W, H);
                 for (int c = 1; c + 1 < n; ++c) {
                     SetupTri s;
                     if (setup_triangle(poly[0], poly[c], poly[c + 1], I.MaterialIndex, W, H, s, &overflow)) tris[slot0 + (size_t)(c - 1)] = s;

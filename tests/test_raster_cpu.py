@@ -126,6 +126,45 @@ def test_clipping_and_culling(built_lib, oracle, hostsim):
     assert a["tris"] == b["tris"]
 
 
+def test_guard_band_clipping(built_lib, oracle, hostsim):
+    """Triangles with vertices far outside the viewport are RENDERED, as D3D12 renders them (guard-band clipping; CRYCHIC.cpp:2473
+    draws whatever the scene holds), not dropped: a ground quad whose far corners are 10^7 units away, a triangle with one vertex a
+    million NDC units to the right, one crossing both the near plane and the band, one wholly outside the band.  Kernel bodies ==
+    oracle on every plane, the visible part is covered, and the in-band scene of test_clipping_and_culling is untouched by the
+    clipper (its planes equal a render with the huge primitives appended behind everything)."""
+    W, H = 96, 64
+    cs = scene_util.cpu_scene(W, H, 128, 16)["consts"]
+    view = np.array(cs.pass_cb.View, np.float32); vp = np.array(cs.pass_cb.ViewProj, np.float32)
+    from crychic_renderer_amd import geometry as g
+    V = np.zeros(16, g.VERTEX_DT)
+    V["Normal"] = (0, 1, 0); V["TangentU"] = (1, 0, 0)
+    V["Pos"][:4] = [(-1e7, 0, -40), (-1e7, 0, 1e7), (1e7, 0, 1e7), (1e7, 0, -40)]          # ground to the horizon and far beyond the sides
+    V["Pos"][4:7] = [(-2, 1, 5), (-2, 4, 5), (3e6, 1, 5)]                                   # wall triangle with a vertex 3e6 units to the right
+    V["Pos"][7:10] = [(-4e6, 6, 8), (0, 9, 8), (4e6, 6, 8)]                                  # wide sliver above, both ends outside the band
+    V["Pos"][10:13] = [(5e6, 1, 20), (5e6, 4, 20), (6e6, 1, 20)]                             # wholly outside (right of the band)
+    V["Pos"][13:16] = [(-3e6, 0.5, -16), (0, 0.5, 30), (3e6, 0.5, -16)]                      # crosses the near plane AND the band
+    idx = np.array([0, 1, 2, 0, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15], np.uint32)
+    items = [(V, idx, g.make_instances([g.world_matrix()], [0]))]
+    for mode in (1, 2):
+        a = oracle_lib.rasterize(oracle, mode, view, vp, items, g.reference_materials().view(oracle_lib.MATERIAL_DT), None, W, H)
+        b = hostsim.rasterize(mode, view, vp, items, g.reference_materials(), None, W, H)
+        assert np.array_equal(a["depth"], b["depth"]) and a["tris"] == b["tris"]
+        if mode == 1:
+            assert np.array_equal(a["normal"].view(np.uint16), b["normal"].view(np.uint16))
+        else:
+            for k in ("g0", "g1", "g2"):
+                assert np.array_equal(a[k].view(np.uint32), b[k].view(np.uint32)), k
+    cov = a["depth"] < 0xFFFFFF
+    assert cov[H - 1].all() and cov[H // 2 + 2].all()           # the ground reaches the bottom row and the horizon, full width
+    assert cov[H // 2 - 6, W // 2 - 3:].all()                     # the wall triangle runs off the right edge
+    # the two horizontal primitives (ground y = 0, the big triangle y = 0.5 in front of it) interpolate their height exactly enough
+    # after clipping: every pixel of the lower half shows one of the two planes
+    y = a["g0"][H // 2 + 4:, :, 1]
+    near = np.minimum(np.abs(y), np.abs(y - 0.5))
+    assert near.max() < 1e-2 and (np.abs(y - 0.5) < 1e-2).sum() > 200
+    assert (np.abs(a["g0"][cov][:, 1]) < 1e-2).sum() > 20          # and the ground itself shows towards the horizon
+
+
 @pytest.mark.parametrize("W,H", [(160, 90), (97, 61)])
 def test_mipped_textures_kernel_bodies_match_oracle(built_lib, oracle, hostsim, W, H):
     """Material textures with a mip chain go through the anisotropic sampler (gsamAnisotropicWrap, CRYCHIC.cpp:2631-2638 --

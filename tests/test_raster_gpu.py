@@ -143,9 +143,11 @@ def test_raster_argument_errors(ctx, built_lib):
 
 
 @pytest.mark.gpu
-def test_raster_status_reports_dropped_triangles(ctx, built_lib):
-    """crychic_raster_status: a triangle with a post-clip vertex beyond +-2^22 pixels is dropped (no guard-band clipping) and a
-    bad vertex index is refused -- both are REPORTED instead of silently producing a wrong image."""
+def test_huge_triangles_render_and_bad_input_is_reported(ctx, built_lib, oracle):
+    """A triangle with a vertex a million NDC units outside the viewport is RENDERED (guard-band clipping, as D3D12 does), exactly
+    as the oracle renders it, and nothing is flagged; what cannot be drawn -- a vertex index outside the vertex buffer, a
+    non-finite position -- is REPORTED by crychic_raster_status instead of silently producing a wrong image."""
+    import oracle_lib
     from crychic_renderer_amd import SceneGeometry, geometry as g
     lib, check = built_lib.lib, built_lib.check
     W = H = 64
@@ -155,26 +157,35 @@ def test_raster_status_reports_dropped_triangles(ctx, built_lib):
     cb.ViewProj[:] = list(eye.reshape(-1)); cb.View[:] = list(eye.reshape(-1))
     depth = torch.zeros((H, W), dtype=torch.int32, device=ctx.device)
 
-    def tri(pts, idx=(0, 1, 2)):
+    def items(pts, idx=(0, 1, 2)):
         v = np.zeros(len(pts), dtype=g.VERTEX_DT)
         v["Pos"] = np.asarray(pts, dtype=np.float32); v["Normal"] = (0, 0, -1); v["TangentU"] = (1, 0, 0)
         both = list(idx) + [idx[0], idx[2], idx[1]]          # both windings: one of them faces the camera
-        return SceneGeometry(ctx, [(v, np.asarray(both, dtype=np.uint32), g.make_instances([np.eye(4, dtype=np.float32).reshape(-1)], [0]))])
+        return [(v, np.asarray(both, dtype=np.uint32), g.make_instances([np.eye(4, dtype=np.float32).reshape(-1)], [0]))]
 
-    def draw(geo):
-        geo.DrawSceneToShadowMap(cb, depth, depth_bias=0, slope_bias=0.0)
+    def draw(it):
+        SceneGeometry(ctx, it).DrawSceneToShadowMap(cb, depth, depth_bias=0, slope_bias=0.0)
         check(lib.crychic_raster_status(ctx.handle, None, C.byref(flags)))
-        return flags.value, int((depth.cpu() != 0xFFFFFF).sum())
+        return flags.value, depth.cpu().numpy().view(np.uint32)
 
     # an ordinary clockwise triangle inside the clip volume: nothing to report, pixels covered
-    st, cov = draw(tri([(-0.5, -0.5, 0.5), (-0.5, 0.5, 0.5), (0.5, -0.5, 0.5)]))
-    assert st == 0 and cov > 100
-    # one vertex 1e6 NDC units away (z inside the clip range, so the z-only clipper keeps it): dropped and flagged
-    st, cov = draw(tri([(-0.5, -0.5, 0.5), (-0.5, 0.5, 0.5), (1.0e6, -0.5, 0.5)]))
-    assert st & 1 and cov == 0
+    st, d = draw(items([(-0.5, -0.5, 0.5), (-0.5, 0.5, 0.5), (0.5, -0.5, 0.5)]))
+    assert st == 0 and (d != 0xFFFFFF).sum() > 100
+    # vertices 1e6 NDC units away, z inside the clip range: clipped to the guard band and drawn, like the oracle draws them
+    for pts in ([(-0.5, -0.5, 0.5), (-0.5, 0.5, 0.5), (1.0e6, -0.5, 0.5)], [(-1.0e6, -0.9, 0.25), (0.0, 2.0e6, 0.5), (1.0e6, -0.9, 0.75)],
+                [(3.0e5, -0.5, 0.5), (3.0e5, 0.5, 0.5), (4.0e5, 0.0, 0.5)]):
+        st, d = draw(items(pts))
+        ref = oracle_lib.rasterize(oracle, 0, np.array(cb.View, np.float32), np.array(cb.ViewProj, np.float32), items(pts), None, None, W, H, 0, 0.0)
+        assert st == 0 and np.array_equal(d, ref["depth"])
+    assert (d == 0xFFFFFF).all()                                # the last one lies wholly outside: nothing drawn, nothing flagged
+    st, d = draw(items([(-0.5, -0.5, 0.5), (-0.5, 0.5, 0.5), (1.0e6, -0.5, 0.5)]))
+    assert (d[H // 2 + 4, W // 2:] != 0xFFFFFF).all()          # the long triangle runs off the right edge of the target
+    # a non-finite position cannot be drawn: flagged
+    st, d = draw(items([(-0.5, -0.5, 0.5), (-0.5, 0.5, 0.5), (np.nan, -0.5, 0.5)]))
+    assert st & 1 and (d == 0xFFFFFF).all()
     # an index outside the 3-vertex buffer
-    st, cov = draw(tri([(-0.5, -0.5, 0.5), (-0.5, 0.5, 0.5), (0.5, -0.5, 0.5)], idx=(0, 1, 7)))
-    assert st & 2 and cov == 0
+    st, d = draw(items([(-0.5, -0.5, 0.5), (-0.5, 0.5, 0.5), (0.5, -0.5, 0.5)], idx=(0, 1, 7)))
+    assert st & 2 and (d == 0xFFFFFF).all()
 
 
 # ---- BASELINE configs[0]: CPU-only plumbing case ----------------------------------------------------------------------
