@@ -69,8 +69,7 @@ __global__ __launch_bounds__(128) void setup_kernel(ItemBatch batch, const crych
     const crychic_instance_data I = item.instances_dev[inst];
     const crychic_material_data* M = (materials && I.MaterialIndex < nMaterials) ? &materials[I.MaterialIndex] : nullptr;
     const uint32_t slot0 = target * slotsPerTarget + slotBase + (uint32_t)bid * (uint32_t)kSlotsPerTriangle;
-#pragma unroll
-    for (int c = 0; c < kSlotsPerTriangle; ++c) tris[slot0 + (uint32_t)c].A2 = 0;
+    // slots that receive no triangle are never listed in `live`, and only listed slots are read: nothing to clear here
 
     VsOut v[3];
     bool bad = false;

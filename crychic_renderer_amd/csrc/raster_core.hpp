@@ -27,7 +27,7 @@ struct SetupTri {       // 192 B
     float posW[3][3], normalW[3][3], tangentW[3][3], tex[3][2];
     uint32_t matIndex;
     uint32_t pad;
-    int64_t A2;                     // twice the signed area; <= 0 marks an empty slot
+    int64_t A2;                     // twice the signed area (> 0 in every listed slot; the host simulation marks empty slots with 0)
 };
 
 CRY_HD void mul3x3(const float v[3], const float* m, float out[3])
