@@ -96,11 +96,6 @@ __global__ __launch_bounds__(256) void depth_pairs_kernel(const uint32_t* __rest
         r1[k] = d24_to_float(t.hi);
     }
     const bool live = px2 < halfPitch;
-#pragma unroll
-    for (int k = 0; k < 8; ++k) {
-        const uint32_t py = 8u * cy + (uint32_t)k;
-        if (WRITE_PAIRS && live && py < H + 3u) pairs[py * halfPitch + px2] = f4a{ r0[k], r0[k + 1], r1[k], r1[k + 1] };
-    }
     // coarse geometry map: rows y0 .. y0 + 7 (row y0 + 8 is the next cell row's first) fall into at most two 32-row cells
     const int yFirst = y0 < 0 ? 0 : y0;
     const uint32_t c0 = (uint32_t)yFirst >> 5;
@@ -136,9 +131,20 @@ __global__ __launch_bounds__(256) void depth_pairs_kernel(const uint32_t* __rest
         v = __shfl(v, 0);
         if (lane >= 60u) next = v;
     }
-    m = __builtin_fminf(m, next);
+    m = __builtin_fminf(m, next);                                   // the same value in the four lanes of a cell
+    // The pairs plane.  A lane's entries (2 px2, 2 px2 + 1) are read by footprints whose left entry is 2 px2 - 1, 2 px2 or 2 px2 + 1:
+    // its own cell, and for the first lane of a cell the cell to the left as well.  Entries that only clear cells can reach are
+    // read by nobody (ssao_core.hpp "clear cells") and are not written.  The first cell of a wavefront always writes: its left
+    // neighbour belongs to another wavefront.
+    const float left = __shfl(m, (int)(lane - 1u) & 63);
+    const bool unread = cull.clear && m == 1.0f && lane >= 4u && ((lane & 3u) != 0u || left == 1.0f);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const uint32_t py = 8u * cy + (uint32_t)k;
+        if (WRITE_PAIRS && live && !unread && py < H + 3u) pairs[py * halfPitch + px2] = f4a{ r0[k], r0[k + 1], r1[k], r1[k + 1] };
+    }
     const uint32_t cellX = seg * 16u + (lane >> 2);
-    if ((lane & 3u) == 0 && cellX < zmin_map_cols(W)) zcull[cy * zmin_map_cols(W) + cellX] = zmin_cell_value(cull.A, cull.B, m);
+    if ((lane & 3u) == 0 && cellX < zmin_map_cols(W)) zcull[cy * zmin_map_cols(W) + cellX] = zmin_cell_value(cull, m);
 }
 
 // Shaders/Ssao.hlsl:117-199 over half-res rows [row0, row1).  EMIT_AO = false builds only the edge workspace.
@@ -164,7 +170,8 @@ __global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, co
 
     const DepthPairs dp{ edge.pairs, depth_pairs_pitch(W) };
     const DepthD24 dd{ depth, W, H };
-    const SsaoCentre c = PAIRS ? ssao_centre(cb, normal, dp, W, H, (int)x, (int)y) : ssao_centre(cb, normal, depth, W, H, (int)x, (int)y);
+    // the pixel's own depth comes from the D24 plane (coalesced): its pairs entry may be one the depth pass did not write
+    const SsaoCentre c = ssao_centre(cb, normal, depth, W, H, (int)x, (int)y);
     if (edge.nrm) {
         const uint32_t idx = y * w2 + x;
         edge.nrm[idx] = c.nrm_bits;

@@ -363,20 +363,32 @@ CRY_HD void depth_pass_cell_rows(uint32_t H, uint32_t row0, uint32_t rows, uint3
 //     the term is +0 and the sum does not change.
 // The lookup is one 4-byte load from a 0.5 MB map (L1 / L2 resident) in place of a 16-byte gather that misses L1; the parity
 // and fuzz tests run the kernel bodies with culling against an oracle that has none.
-struct CullParams { int enabled; float A, B; };
+//
+// Clear cells.  A cell whose 9 x 9 texels all hold the clear depth (decoded: exactly 1.0) gives every footprint inside it four
+// texels of 1.0, whatever the fractions: zndc = 1.0 exactly, rz = ndc_to_view(1.0) = the far distance F, r.z = F within 3 ulp.  The
+// pixel's own p.z is ndc_to_view of a filtered value <= 1.0, so p.z <= F within 3 ulp and distZ <= 2^-20 F -- below SurfaceEpsilon
+// when SurfaceEpsilon > 2^-16 F (the sky shortcut's guard, checked on the host: CullParams::clear).  Such a cell is stored as +inf:
+// every tap of a pixel that may cull at all is culled there, a tap of a pixel that may not (non-finite normal, huge p) reads the
+// footprint as four times 1.0 without looking at memory (ssao_pixel) -- so NOTHING reads the pairs entries that only clear cells
+// can reach, and depth_pairs_kernel does not write them: on the benchmark frame that is 35 of the plane's 67 MB.
+struct CullParams { int enabled; float A, B; int clear; };
 CRY_HD CullParams ssao_cull_params(const crychic_ssao_constants& cb)
 {
-    CullParams c{ 0, cb.Proj[4 * 2 + 2], cb.Proj[4 * 2 + 3] };
+    CullParams c{ 0, cb.Proj[4 * 2 + 2], cb.Proj[4 * 2 + 3], 0 };
     const float eps = cb.SurfaceEpsilon;
     // z - A < 0 for every filtered z <= 1 + 2^-21, B < 0: view depth positive and increasing in z; far plane finite
     const bool ok = c.A > 1.000002f && c.A < 1.0e6f && c.B < 0.0f && c.B > -1.0e12f && eps == eps && __builtin_fabsf(eps) < 1.0e30f;
     c.enabled = ok ? 1 : 0;
+    const double farZ = (double)c.B / (1.0 - (double)c.A);
+    c.clear = (ok && farZ > 0.0 && farZ < 1.0e6 && (double)eps > farZ * 1.52587890625e-5) ? 1 : 0;
     return c;
 }
-CRY_HD float zmin_cell_value(float A, float B, float blockMinNdc)
+CRY_HD float zmin_cell_value(const CullParams& c, float blockMinNdc)
 {
-    return divf(B, (blockMinNdc - 4.76837158203125e-7f) - A) * 0.999998f;       // ndc_to_view(min - 2^-21), scaled down
+    if (c.clear && blockMinNdc == 1.0f) return u2f(0x7F800000u);                      // a clear cell
+    return divf(c.B, (blockMinNdc - 4.76837158203125e-7f) - c.A) * 0.999998f;         // ndc_to_view(min - 2^-21), scaled down
 }
+CRY_HD bool zmin_cell_is_clear(float cell) { return cell == u2f(0x7F800000u); }
 // per pixel: p.z - epsilon when the pixel may cull at all, NaN (no comparison succeeds) otherwise
 CRY_HD float ssao_cull_threshold(f3 nRaw, f3 p, float eps)
 {
@@ -430,22 +442,10 @@ CRY_HD SsaoCentre ssao_centre(const crychic_ssao_constants& cb, const u2* __rest
     c.sky = ssao_sky_lane(t00, t10, t01, t11, c.nrm_bits);
     return c;
 }
-// The same from the pairs plane (pixel inside the half-res map): the footprint at (2x, 2y) with weights 1/2.
-CRY_HD SsaoCentre ssao_centre(const crychic_ssao_constants& cb, const u2* __restrict__ normal, const DepthPairs depth,
-                              uint32_t W, uint32_t H, int x, int y)
-{
-    SsaoCentre c;
-    c.nrm_bits = normal_texel_bits(normal, W, H, x, y);
-    float t00, t10, t01, t11;
-    depth.footprint(2 * x, 2 * y, t00, t10, t01, t11);
-    c.vz = ndc_to_view(cb, bilerp(t00, t10, t01, t11, 0.5f, 0.5f));
-    c.sky = ssao_sky_lane(t00, t10, t01, t11, c.nrm_bits);
-    return c;
-}
-
 // Ssao.hlsl:117-199 for half-res pixel (x, y); returns the R16_UNORM ambient value.  `sparseProjTex` = ssao_projtex_is_sparse(cb).
-// `cull`: NoCull, or the ZminMap of the tap culling.  `culledTaps` (host builds only, may be null): two words -- [0] += the number
-// of taps culled, [1] |= bit i for every culled tap i -- for the tests that check that the culling bites.
+// `cull`: NoCull, or the ZminMap of the tap culling.  `culledTaps` (host builds only, may be null): three words -- [0] += the number
+// of taps culled, [1] |= bit i for every culled tap i, [2] += the taps that were evaluated on a clear cell's constant footprint --
+// for the tests that check that the culling bites.
 // The pixel centre's uv = (x + 0.5) / (W / 2), (y + 0.5) / (H / 2) is a * rcp(b) with a wave-uniform b: the reciprocals are taken
 // once on the host (the same correctly rounded rcp, devmath.hpp) and handed to the kernel.
 struct HalfResScale { float rw2, rh2; };
@@ -553,6 +553,14 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
         float a00, a10, a01, a11, b00, b10, b01, b11;
         depth_tap(depth, ca, i0a, j0a, a00, a10, a01, a11);
         depth_tap(depth, cb2, i0b, j0b, b00, b10, b01, b11);
+        if (Cull::active) {      // a footprint inside a clear cell is four times 1.0; its pairs entries may not exist ("clear cells")
+            const bool sa = zmin_cell_is_clear(cellA), sb = zmin_cell_is_clear(cellB);
+            a00 = sa ? 1.0f : a00; a10 = sa ? 1.0f : a10; a01 = sa ? 1.0f : a01; a11 = sa ? 1.0f : a11;
+            b00 = sb ? 1.0f : b00; b10 = sb ? 1.0f : b10; b01 = sb ? 1.0f : b01; b11 = sb ? 1.0f : b11;
+#if !defined(__HIP_DEVICE_COMPILE__)
+            if (culledTaps) culledTaps[2] += (!ca && sa ? 1u : 0u) + (!cb2 && sb ? 1u : 0u);
+#endif
+        }
         const v2f t00{ a00, b00 }, t10{ a10, b10 }, t01{ a01, b01 }, t11{ a11, b11 };
         const v2f zndc = lerp2(lerp2(t00, t10, fx), lerp2(t01, t11, fx), fy);
         // :164-165.  With the tap culling on, the host has checked 1.000002 < A < 1e6 (ssao_cull_params) and zndc is a filtered

@@ -150,7 +150,8 @@ float crychic_pcf_search_radius(uint32_t shadowMapWidth, int literal);
  * Contract: the workspace is caller-owned scratch with NO initialisation requirement and no meaning between frames -- it may
  * be freshly allocated, recycled from another context, or shared by consecutive frames of one stream.  Every word a frame
  * reads was written earlier in that same frame (the maps are stamped from one process-wide counter and the passes write the
- * stamp or a non-stamp into every word they will look at), so stale contents can never be mistaken for this frame's. */
+ * stamp or a non-stamp into every word they will look at), so stale contents can never be mistaken for this frame's.  Parts
+ * of it are deliberately left unwritten (depth-pairs entries under clear sky, which nothing reads): do not read it back. */
 size_t crychic_edge_plane_bytes(uint32_t W, uint32_t H);
 
 /* Ssao.hlsl:PS (Shaders/Ssao.hlsl:117-199) over half-res rows [row0, row0+rows): writes ambient_out and,

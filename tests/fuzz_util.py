@@ -132,6 +132,24 @@ def sky_probe_case(seed):
     return W, H, c, scb, depth, normal, randvec
 
 
+def clear_cell_probe_case(seed):
+    """Inputs for the clear-cell rule of the SSAO depth pass (ssao_core.hpp "clear cells"): sky next to geometry that hugs the near
+    plane, an occlusion radius that puts taps at and behind the camera (q.z < 1e-3: never culled, landing anywhere -- mostly beyond
+    the plane's edge, which is clear by definition) and a few non-finite normals (pixels that may not cull at all)."""
+    import oracle_lib
+    W, H, c, scb, depth, normal, randvec = sky_probe_case(seed)
+    rng = np.random.default_rng(77 + seed)
+    A, B = c.ssao_cb.Proj[10], c.ssao_cb.Proj[11]
+    x0, x1 = W // 5, W // 5 + 90 + 8 * seed
+    vz = rng.uniform(1.0, 1.8, size=(H // 2, x1 - x0))
+    depth[H // 4:H // 4 + H // 2, x0:x1] = np.clip(np.round((A + B / vz) * 16777215.0), 0, 0xFFFFFF).astype(np.uint32)
+    normal[H // 4:H // 4 + H // 2, x0:x1, :3] = rng.standard_normal((H // 2, x1 - x0, 3)).astype(np.float16)
+    normal[rng.random((H, W)) < 0.002, 1] = np.nan
+    c.ssao_cb.OcclusionRadius = 3.0
+    scb = oracle_lib.as_oracle_cb(c.ssao_cb, oracle_lib.OrSsaoConstants)
+    return W, H, c, scb, depth, normal, randvec
+
+
 def cull_probe_case(seed, W=256, H=160):
     """Frames for the SSAO tap culling (ssao_core.hpp): the reference scene -- open ground, where most taps are culled -- with what
     the nearest-depth bound must not miss: single near texels (spikes a fraction of a block wide), texels just in front of their

@@ -74,6 +74,8 @@ static uint32_t g_sky_waves = 0;     // wavefronts the last hs_ssao_path call re
 uint32_t hs_last_sky_waves(void) { return g_sky_waves; }
 static uint32_t g_culled_taps = 0;   // taps the last hs_ssao_path call skipped through the nearest-depth map
 uint32_t hs_last_culled_taps(void) { return g_culled_taps; }
+static uint32_t g_clear_cell_taps = 0;   // taps of that call that were NOT culled and landed in a clear cell (footprint = 1.0 by rule)
+uint32_t hs_last_clear_cell_taps(void) { return g_clear_cell_taps; }
 static uint16_t* g_cull_masks = nullptr;      // optional: per half-res pixel, bit i = tap i culled (analysis only)
 void hs_set_cull_mask_plane(uint16_t* plane) { g_cull_masks = plane; }
 // The frame stamp the next hs_ssao_path / hs_blur_chain calls run with (api.cpp draws a fresh one per frame from a process-wide
@@ -105,13 +107,36 @@ void hs_ssao_path(const crychic_ssao_constants* cb, const void* normal, const ui
     const int j0lo = 8 * (int)c0 - 2;
     const uint32_t nj = 8u * cn;
     g_slow_taps = limited ? 8u * (zmin_map_rows(H) - cn) : 0u;
+    // the nearest-depth map as depth_pairs_kernel fills it: per cell of 9 x 9 padded texels, cells 8 apart (padded (ex, ey) = texel
+    // (ex - 2, ey - 2), anything outside the plane reads as the clear depth)
+    const CullParams cp = ssao_cull_params(*cb);
+    const bool culling = pairs && cp.enabled && use_pairs != 2;         // use_pairs == 2: pairs plane without tap culling
+    if (pairs) {
+        for (uint32_t cy = 0; cy < zmin_map_rows(H); ++cy)
+            for (uint32_t cx = 0; cx < zmin_map_cols(W); ++cx) {
+                float m = 1.0f;
+                for (uint32_t ey = 8u * cy; ey <= 8u * cy + 8u; ++ey)
+                    for (uint32_t ex = 8u * cx; ex <= 8u * cx + 8u; ++ex) {
+                        const int tx = (int)ex - 2, ty = (int)ey - 2;
+                        if ((uint32_t)tx < W && (uint32_t)ty < H) m = __builtin_fminf(m, d24_to_float(depth[(uint32_t)ty * W + (uint32_t)tx]));
+                    }
+                const bool visited = cy >= c0 && cy < c0 + cn;
+                e.zcull[cy * zmin_map_cols(W) + cx] = visited ? zmin_cell_value(cp, m) : 1.0e30f;      // poison: "cull everything"
+            }
+    }
+    // The pairs plane.  Entries the pass does not visit are poisoned, and so is every entry that only clear cells can reach
+    // (ssao_core.hpp "clear cells": the kernel may leave those unwritten -- here ALL of them are, the kernel keeps a few)
     if (pairs) {
         f4a* out = (f4a*)const_cast<void*>(e.pairs);
         const uint32_t halfPitch = depth_pairs_pitch(W) / 2u;
+        auto clear = [&](int cx, uint32_t cy) {
+            return cx < 0 || ((uint32_t)cx < zmin_map_cols(W) && cy < zmin_map_rows(H) && zmin_cell_is_clear(e.zcull[cy * zmin_map_cols(W) + (uint32_t)cx]));
+        };
         for (uint32_t py = 0; py < H + 3u; ++py)
             for (uint32_t px2 = 0; px2 < halfPitch; ++px2) {
                 const bool visited = py >= 8u * c0 && py < 8u * (c0 + cn);
-                out[py * halfPitch + px2] = visited ? depth_pairs_entry2(depth, W, H, 2 * (int)px2 - 2, (int)py - 2) : f4a{ -7.0f, -7.0f, -7.0f, -7.0f };
+                const bool unread = culling && visited && clear((2 * (int)px2 - 1) >> 3, py >> 3) && clear((int)(px2 >> 2), py >> 3);
+                out[py * halfPitch + px2] = visited && !unread ? depth_pairs_entry2(depth, W, H, 2 * (int)px2 - 2, (int)py - 2) : f4a{ -7.0f, -7.0f, -7.0f, -7.0f };
             }
     }
     const DepthPairs dp{ e.pairs, depth_pairs_pitch(W) };
@@ -137,28 +162,12 @@ void hs_ssao_path(const crychic_ssao_constants* cb, const void* normal, const ui
             }
         }
     }
-    // the nearest-depth map as depth_pairs_kernel fills it: per cell of 9 x 9 padded texels, cells 8 apart (padded (ex, ey) = texel
-    // (ex - 2, ey - 2), anything outside the plane reads as the clear depth)
-    const CullParams cp = ssao_cull_params(*cb);
-    const bool culling = pairs && cp.enabled && use_pairs != 2;         // use_pairs == 2: pairs plane without tap culling
     const ZminMap win{ e.zcull, zmin_map_cols(W) };
     const ZminMapRows winRows{ win, j0lo, nj };
-    if (pairs) {
-        for (uint32_t cy = 0; cy < zmin_map_rows(H); ++cy)
-            for (uint32_t cx = 0; cx < zmin_map_cols(W); ++cx) {
-                float m = 1.0f;
-                for (uint32_t ey = 8u * cy; ey <= 8u * cy + 8u; ++ey)
-                    for (uint32_t ex = 8u * cx; ex <= 8u * cx + 8u; ++ex) {
-                        const int tx = (int)ex - 2, ty = (int)ey - 2;
-                        if ((uint32_t)tx < W && (uint32_t)ty < H) m = __builtin_fminf(m, d24_to_float(depth[(uint32_t)ty * W + (uint32_t)tx]));
-                    }
-                const bool visited = cy >= c0 && cy < c0 + cn;
-                e.zcull[cy * zmin_map_cols(W) + cx] = visited ? zmin_cell_value(cp.A, cp.B, m) : 1.0e30f;      // poison: "cull everything"
-            }
-    }
     std::vector<SsaoCentre> row(w2);
     g_sky_waves = 0;
     g_culled_taps = 0;
+    g_clear_cell_taps = 0;
     const HalfResScale hs = half_res_scale(W, H);
     auto pixel = [&](uint32_t x, uint32_t y, uint32_t* acc) -> uint32_t {
         if (limited) return culling ? ssao_pixel(*cb, row[x], dr, (const uint32_t*)randvec, W, H, x, y, hs, sparse, winRows, acc)
@@ -169,7 +178,7 @@ void hs_ssao_path(const crychic_ssao_constants* cb, const void* normal, const ui
     };
     for (uint32_t y = row0; y < row0 + rows; ++y) {
         for (uint32_t x = 0; x < w2; ++x) {
-            const SsaoCentre c = pairs ? ssao_centre(*cb, nrm, dp, W, H, (int)x, (int)y) : ssao_centre(*cb, nrm, depth, W, H, (int)x, (int)y);
+            const SsaoCentre c = ssao_centre(*cb, nrm, depth, W, H, (int)x, (int)y);
             row[x] = c;
             if (e.nrm) {
                 e.nrm[y * w2 + x] = c.nrm_bits;
@@ -192,9 +201,10 @@ void hs_ssao_path(const crychic_ssao_constants* cb, const void* normal, const ui
             g_sky_waves += skip ? 1u : 0u;
             bool allOnes = true;
             for (uint32_t x = x0; x < x0 + n; ++x) {
-                uint32_t acc[2] = { 0u, 0u };
+                uint32_t acc[3] = { 0u, 0u, 0u };
                 ambient[y * w2 + x] = skip ? (uint16_t)0xFFFFu : (uint16_t)pixel(x, y, acc);
                 g_culled_taps += acc[0];
+                g_clear_cell_taps += acc[2];
                 if (!skip && culling && g_cull_masks) g_cull_masks[y * w2 + x] = (uint16_t)(acc[1] | 0x8000u);
                 allOnes = allOnes && ambient[y * w2 + x] == 0xFFFFu;
             }

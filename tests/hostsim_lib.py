@@ -56,6 +56,7 @@ class HostSim:
         L.hs_ssao_path.argtypes = [vp, vp, vp, vp, vp, vp, u32, u32, u32, u32, i]
         L.hs_last_sky_waves.restype = u32
         L.hs_last_culled_taps.restype = u32
+        L.hs_last_clear_cell_taps.restype = u32
         L.hs_blur.argtypes = [vp, vp, vp, vp, u32, u32, i, u32, u32]
         L.hs_blur_chain.argtypes = [vp, vp, vp, vp, u32, u32, i, u32, u32, i, i]
         L.hs_last_settled_tiles.restype = u32

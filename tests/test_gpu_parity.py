@@ -124,6 +124,37 @@ def test_tap_culling_on_device(ctx, built_lib, oracle, seed):
     assert np.array_equal(dev_u16(a0), oracle.compute_ssao(scb, normal, depth, randvec, 3))
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_clear_cells_on_device(ctx, built_lib, oracle, seed):
+    """depth_pairs_kernel does not write the pairs entries that only clear cells of the nearest-depth map can reach, and
+    ssao_kernel never reads them (ssao_core.hpp "clear cells").  The probe frames of
+    tests/test_hostsim_parity.py::test_clear_cells_are_never_read over a workspace filled with garbage, whole frame and strips,
+    then the ComputeSsao chain."""
+    import fuzz_util
+    W, H, c, scb, depth, normal, randvec = fuzz_util.clear_cell_probe_case(seed)
+    lib, check = built_lib.lib, built_lib.check
+    dev = ctx.device
+    d = torch.from_numpy(depth.view(np.int32)).to(dev); n = torch.from_numpy(normal).to(dev); r = torch.from_numpy(randvec).to(dev)
+    a0 = torch.zeros((H // 2, W // 2), dtype=torch.int16, device=dev)
+    a1 = torch.zeros_like(a0)
+    ref = oracle.ssao(scb, normal, depth, randvec)
+    for fill in (0xC0, 0x00, 0xFF):          # as floats: -6.02, 0.0 (the nearest depth there is), NaN
+        edge = torch.full((int(lib.crychic_edge_plane_bytes(W, H)),), fill, dtype=torch.uint8, device=dev)
+        check(lib.crychic_ssao(ctx.handle, C.byref(c.ssao_cb), ptr(n), ptr(d), ptr(r), ptr(a0), ptr(edge), W, H, 0, H // 2, stream(ctx)))
+        torch.cuda.synchronize()
+        got = dev_u16(a0)
+        assert np.array_equal(got, ref), (fill, int((got != ref).sum()))
+        for row0, rows in ((0, H // 8), (H // 4, H // 8)):
+            a0.zero_()
+            check(lib.crychic_ssao(ctx.handle, C.byref(c.ssao_cb), ptr(n), ptr(d), ptr(r), ptr(a0), ptr(edge), W, H, row0, rows, stream(ctx)))
+            torch.cuda.synchronize()
+            assert np.array_equal(dev_u16(a0)[row0:row0 + rows], ref[row0:row0 + rows]), (fill, row0)
+    assert (ref < 65535).sum() > 50
+    check(lib.crychic_ssao_compute(ctx.handle, C.byref(c.ssao_cb), ptr(n), ptr(d), ptr(r), ptr(a0), ptr(a1), ptr(edge), W, H, 3, 0, H // 2, stream(ctx)))
+    torch.cuda.synchronize()
+    assert np.array_equal(dev_u16(a0), oracle.compute_ssao(scb, normal, depth, randvec, 3))
+
+
 @pytest.mark.parametrize("W,H", SIZES)
 def test_blur_sweeps_bit_exact(ctx, built_lib, oracle, W, H):
     c = get_case(ctx, built_lib, W, H)

@@ -205,6 +205,28 @@ def test_tap_culling_is_exact_and_bites(built_lib, oracle, hostsim, seed):
         c.ssao_cb.Proj[4 * 2 + 3], c.ssao_cb.SurfaceEpsilon = keep
 
 
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_clear_cells_are_never_read(built_lib, oracle, hostsim, seed):
+    """Clear cells (ssao_core.hpp): the depth pass marks a cell of the nearest-depth map whose texels all hold the clear depth as
+    +inf and leaves the pairs entries that only such cells can reach unwritten.  The host simulation poisons ALL of those entries.
+    A frame of sky next to geometry that hugs the near plane, with an occlusion radius that puts taps at and behind the camera
+    (q.z < 1e-3: never culled, landing anywhere -- mostly beyond the plane's edge, which is clear by definition), and non-finite
+    normals (pixels that may not cull at all): kernel body == oracle, and such taps did land in clear cells."""
+    import fuzz_util
+    W, H, c, scb, depth, normal, randvec = fuzz_util.clear_cell_probe_case(seed)
+    eb = int(built_lib.lib.crychic_edge_plane_bytes(W, H))
+    want = oracle.ssao(scb, normal, depth, randvec)
+    got, _ = hostsim.ssao(c.ssao_cb, normal, depth, randvec, eb)
+    assert np.array_equal(got, want), int((got != want).sum())
+    assert int(hostsim.lib.hs_last_clear_cell_taps()) > 100           # the rule was needed: taps evaluated on a clear cell's 1.0s
+    assert int(hostsim.lib.hs_last_culled_taps()) > 1000
+    assert (want < 65535).sum() > 50
+    # strips: the row-limited pass leaves the same entries unwritten
+    for row0, rows in ((0, H // 8), (H // 4, H // 8)):
+        part, _ = hostsim.ssao(c.ssao_cb, normal, depth, randvec, eb, row0=row0, rows=rows)
+        assert np.array_equal(part[row0:row0 + rows], want[row0:row0 + rows])
+
+
 @pytest.mark.parametrize("seed", [0, 1, 5, 12, 14])
 @pytest.mark.parametrize("blur_count", [1, 2, 4, 5])
 def test_unoccluded_tile_exit_is_exact(built_lib, oracle, hostsim, seed, blur_count):
