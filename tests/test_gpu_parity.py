@@ -358,6 +358,44 @@ def test_draw_hot_path_matches_oracle_and_strips(ctx, built_lib, oracle):
         assert np.array_equal(app.mBackBuffer.cpu().numpy(), full), "strip decomposition nranks=%d differs" % nranks
 
 
+def test_hot_path_replays_from_a_hip_graph(ctx, built_lib, oracle):
+    """crychic_draw_hot_path is stream-ordered, allocation-free and never synchronises: a caller can capture it into a hipGraph
+    and replay it.  A replay re-uses the frame stamp that was drawn at capture time -- still exact, because every stamped word
+    a frame looks at is written earlier in that same frame (crychic_hip.h, workspace contract).  Frame A is captured; then
+    different planes are copied into the same buffers and the replay has to give frame B, bit for bit the oracle's."""
+    from crychic_renderer_amd import Crychic
+    W, H = 256, 256
+    c = get_case(ctx, built_lib, W, H)
+    planes = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in c.dev.items()}
+    app = Crychic(ctx, W, H, planes["randvec"], planes["cube"], shadow_dim=c.np["shadow"].shape[1])
+    app.load_scene({**planes, "consts": c.consts})
+    app.blurCount, app.numDirLights = 3, 3
+    app.pcfSearchRadius = built_lib.lib.crychic_pcf_search_radius(c.np["shadow"].shape[1], 0)
+    app.Draw()                                   # code objects loaded before the capture
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        app.Draw()
+
+    def want(normal, depth):
+        amb = oracle.compute_ssao(c.scb, normal, depth, c.np["randvec"], 3)
+        return oracle.deferred_light(c.pcb, c.np["g0"], c.np["g1"], c.np["g2"], depth, amb, c.np["shadow"], c.np["cube"], 3, app.pcfSearchRadius)
+
+    app.mBackBuffer.zero_()
+    graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(app.mBackBuffer.cpu().numpy(), want(c.np["normal"], c.np["depth"]))
+    # frame B: the depth / normal planes upside down (sky where the ground was), in the buffers the graph captured
+    depth_b, normal_b = np.ascontiguousarray(c.np["depth"][::-1]), np.ascontiguousarray(c.np["normal"][::-1])
+    planes["depth"].copy_(torch.from_numpy(depth_b.view(np.int32)))
+    planes["normal"].copy_(torch.from_numpy(normal_b))
+    for _ in range(2):
+        app.mBackBuffer.zero_()
+        graph.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(app.mBackBuffer.cpu().numpy(), want(normal_b, depth_b))
+
+
 def test_c2_1080p_parity(ctx, built_lib, oracle):
     """BASELINE config 2: 1920x1080, 3 lights, 14-sample SSAO + 1 blur pass, vs the oracle."""
     from crychic_renderer_amd import Crychic
