@@ -1,12 +1,15 @@
 """Fuzz parity: random planes + perturbed constants (tests/fuzz_util.py) through the oracle, the kernel bodies compiled
 for the host, and (gpu) the device.  Bar: AO and RGBA8 bit-exact; radiance bit-exact up to NaN payloads."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
 
 import fuzz_util
 import oracle_lib
+
+EXTRA = int(os.environ.get("CRY_FUZZ_EXTRA", "0"))      # a soak run: CRY_FUZZ_EXTRA=400 python -m pytest tests/test_fuzz.py
 
 
 def oracle_frame(oracle, planes, c, knobs):
@@ -18,7 +21,7 @@ def oracle_frame(oracle, planes, c, knobs):
     return ao, out, rad
 
 
-@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("seed", range(6 + EXTRA // 8))
 def test_fuzz_kernel_bodies(built_lib, oracle, hostsim, seed):
     W, H, planes, c, knobs = fuzz_util.random_case(seed, built_lib)
     ao, out, rad = oracle_frame(oracle, planes, c, knobs)
@@ -36,7 +39,7 @@ def test_fuzz_kernel_bodies(built_lib, oracle, hostsim, seed):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("seed", range(24))
+@pytest.mark.parametrize("seed", range(24 + EXTRA))
 def test_fuzz_device(built_lib, oracle, seed):
     import torch
     from crychic_renderer_amd import Context, Crychic
