@@ -46,8 +46,9 @@ int check_dims(uint32_t W, uint32_t H)
 {
     if (W == 0 || H == 0 || (W & 1u) || (H & 1u))
         return fail(CRYCHIC_E_INVALID_ARG, "frame size %ux%u must be non-zero and even (half-res maps are W/2 x H/2)", W, H);
-    if ((uint64_t)W * H > (1ull << 28) || W >= (1u << 20) || H >= (1u << 20))
-        return fail(CRYCHIC_E_UNSUPPORTED, "frame %ux%u exceeds 2^28 pixels (32-bit plane offsets)", W, H);
+    // 2^28 pixels: 32-bit plane offsets; 4 * 65535 rows: one workgroup row of the lighting pass per 4 pixel rows, grid.y <= 65535
+    if ((uint64_t)W * H > (1ull << 28) || W >= (1u << 20) || H > 4u * 65535u)
+        return fail(CRYCHIC_E_UNSUPPORTED, "frame %ux%u exceeds 2^28 pixels, 2^20 columns or 262140 rows", W, H);
     return 0;
 }
 

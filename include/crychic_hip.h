@@ -27,7 +27,8 @@
  *   cube     4 x uint8 RGBA, faces +X,-X,+Y,-Y,+Z,-Z                     6 x cubeDim x cubeDim
  *   out      4 x uint8 R8G8B8A8_UNORM back buffer (Common/d3dApp.h:124)  W x H
  *   edge     opaque half-res workspace, crychic_edge_plane_bytes(W,H) bytes (see crychic_ssao)
- * W and H must be even (the half-res maps are W/2 x H/2, Ssao.cpp:22-30).
+ * W and H must be even (the half-res maps are W/2 x H/2, Ssao.cpp:22-30); the smallest frame is 2 x 2, the largest 2^28 pixels
+ * with W < 2^20 and H <= 262140 (CRYCHIC_E_UNSUPPORTED beyond).
  */
 #ifndef CRYCHIC_HIP_H
 #define CRYCHIC_HIP_H

@@ -6,11 +6,14 @@ import ctypes as C
 import numpy as np
 
 
-def random_case(seed, built_lib):
+def random_case(seed, built_lib, size=None):
+    """size = (W, H): force the frame size (the random draws that follow are the same either way)."""
     from crychic_renderer_amd import scene
     rng = np.random.default_rng(seed)
     W = int(rng.integers(17, 100)) * 2
     H = int(rng.integers(17, 70)) * 2
+    if size is not None:
+        W, H = size
     sd = int(rng.choice([16, 64, 130]))
     cd = int(rng.choice([2, 8, 33]))
     c = scene.Constants(W, H, shadow_dim=sd)
@@ -18,7 +21,7 @@ def random_case(seed, built_lib):
     depth = rng.integers(0, 1 << 24, size=(H, W), dtype=np.uint32)
     depth[rng.random((H, W)) < 0.25] = 0xFFFFFF                         # uncovered
     depth[rng.random((H, W)) < 0.05] = 0
-    if rng.random() < 0.35:
+    if rng.random() < 0.35 and W > 16 and H > 16:
         # a smooth depth field (tilted plane + a little noise) with spikes, holes and sky patches: the SSAO tap culling gets
         # blocks it can cull and blocks a single texel spoils
         yy, xx = np.mgrid[0:H, 0:W]

@@ -76,3 +76,61 @@ def test_fuzz_device(built_lib, oracle, seed):
         assert fuzz_util.same_floats(r.cpu().numpy(), rad), knobs
     finally:
         ctx.close()
+
+
+# The smallest legal frames, single-row / single-column half-res maps, and the longest rows and columns a moderate pixel count
+# allows (tall frames: many workgroup rows; wide frames: long rows of tiles, one cell row of every coarse map).
+TINY = [(2, 2), (2, 4), (4, 2), (6, 6), (2, 70), (70, 2), (130, 2), (2, 130)]
+LONG = [(16, 131072), (131072, 16), (2, 262140), (1048574, 2)]
+
+
+@pytest.mark.parametrize("size", TINY)
+def test_tiny_frames_kernel_bodies(built_lib, oracle, hostsim, size):
+    W, H, planes, c, knobs = fuzz_util.random_case(77, built_lib, size=size)
+    knobs["ssao_on"], knobs["blurCount"] = True, 2
+    ao, out, rad = oracle_frame(oracle, planes, c, knobs)
+    eb = int(built_lib.lib.crychic_edge_plane_bytes(W, H))
+    got, _ = hostsim.compute_ssao(c.ssao_cb, planes["normal"], planes["depth"], planes["randvec"], eb, 2)
+    assert np.array_equal(got, ao), size
+    o2, r2 = hostsim.light(c.pass_cb, planes["g0"], planes["g1"], planes["g2"], planes["depth"], ao, planes["shadow"], planes["cube"],
+                           knobs["numDirLights"], knobs["pcfSearchRadius"], flags=knobs["sky"], want_radiance=True)
+    assert np.array_equal(o2, out), size
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("size", TINY + LONG)
+def test_tiny_and_long_frames_on_device(built_lib, oracle, size):
+    """crychic_draw_hot_path (SSAO + 2 blur iterations + lighting) on frames of extreme shape == oracle; one size past the limit is
+    refused with CRYCHIC_E_UNSUPPORTED rather than launched."""
+    import torch
+    from crychic_renderer_amd import Context, Crychic
+    W, H, planes, c, knobs = fuzz_util.random_case(78, built_lib, size=size)
+    knobs["ssao_on"], knobs["blurCount"] = True, 2
+    ao, out, rad = oracle_frame(oracle, planes, c, knobs)
+    ctx = Context(0)
+    try:
+        dev = {k: torch.from_numpy(np.ascontiguousarray(v).view(np.int32) if v.dtype == np.uint32 else np.ascontiguousarray(v)).to(ctx.device)
+               for k, v in planes.items()}
+        app = Crychic(ctx, W, H, dev["randvec"], dev["cube"], shadow_dim=planes["shadow"].shape[1])
+        app.load_scene({**dev, "consts": c})
+        app.blurCount, app.numDirLights, app.pcfSearchRadius, app.flags = 2, knobs["numDirLights"], knobs["pcfSearchRadius"], knobs["sky"]
+        app.Draw()
+        torch.cuda.synchronize()
+        assert np.array_equal(app.mSsao.mAmbientMap0.cpu().numpy().view(np.uint16), ao), size
+        assert np.array_equal(app.mBackBuffer.cpu().numpy(), out), size
+    finally:
+        ctx.close()
+
+
+@pytest.mark.gpu
+def test_oversized_frames_are_refused(built_lib):
+    from crychic_renderer_amd import Context
+    lib = built_lib.lib
+    ctx = Context(0)
+    try:
+        _, _, _, c, _ = fuzz_util.random_case(79, built_lib, size=(4, 4))
+        for W, H in ((2, 262142), (1 << 20, 2), (32768, 16384)):
+            rc = lib.crychic_ssao(ctx.handle, C.byref(c.ssao_cb), C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), C.c_void_p(8), None, W, H, 0, H // 2, None)
+            assert rc == -4, (W, H, rc)
+    finally:
+        ctx.close()
