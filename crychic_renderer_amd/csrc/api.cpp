@@ -358,7 +358,10 @@ static int raster_common(crychic_ctx* ctx, cry::RasterPass& p, const crychic_pas
 {
     if (int rc = bind(ctx)) return rc;
     if (!passCB || (!items && nItems) || (!p.depth && p.nTargets < 2u) || !p.workspace) return fail(CRYCHIC_E_INVALID_ARG, "null argument");
-    if (p.W == 0 || p.H == 0 || (uint64_t)p.W * p.H > 0x7FFFFFFFull) return fail(CRYCHIC_E_INVALID_ARG, "bad target size %ux%u", p.W, p.H);
+    if (p.W == 0 || p.H == 0) return fail(CRYCHIC_E_INVALID_ARG, "bad target size %ux%u", p.W, p.H);
+    // the same bounds as the full-screen passes: 32-bit plane offsets, and one workgroup row of the resolve pass per 4 pixel rows
+    if ((uint64_t)p.W * p.H > (1ull << 28) || p.W >= (1u << 20) || p.H > 4u * 65535u)
+        return fail(CRYCHIC_E_UNSUPPORTED, "target %ux%u exceeds 2^28 pixels, 2^20 columns or 262140 rows", p.W, p.H);
     for (uint32_t i = 0; i < nItems; ++i) {
         const crychic_draw_item& d = items[i];
         if (d.indexCount % 3u) return fail(CRYCHIC_E_INVALID_ARG, "item %u: indexCount %u is not a triangle list", i, d.indexCount);
