@@ -16,20 +16,52 @@ struct DdsInfo {
     enum Kind { BC1, BC3, RGBA_MASKS } kind = BC1;
     uint32_t bitCount = 0, rMask = 0, gMask = 0, bMask = 0, aMask = 0;
     size_t dataOffset = 128;
+    bool cube = false;             // six faces (+X, -X, +Y, -Y, +Z, -Z), each with its own mip chain, one after the other
+    uint32_t fileLevels = 1;       // levels the file stores per image (dwMipMapCount when DDSD_MIPMAPCOUNT is set)
 };
 
 uint32_t rd32(const uint8_t* p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
 
+bool set_dxgi_format(uint32_t fmt, DdsInfo& d)
+{
+    switch (fmt) {
+    case 71: case 72: d.kind = DdsInfo::BC1; return true;                    // BC1_UNORM(_SRGB)
+    case 77: case 78: d.kind = DdsInfo::BC3; return true;                    // BC3_UNORM(_SRGB)
+    case 28: case 29: d.kind = DdsInfo::RGBA_MASKS; d.bitCount = 32;         // R8G8B8A8_UNORM(_SRGB)
+        d.rMask = 0xFFu; d.gMask = 0xFF00u; d.bMask = 0xFF0000u; d.aMask = 0xFF000000u; return true;
+    case 87: case 91: d.kind = DdsInfo::RGBA_MASKS; d.bitCount = 32;         // B8G8R8A8_UNORM(_SRGB)
+        d.rMask = 0xFF0000u; d.gMask = 0xFF00u; d.bMask = 0xFFu; d.aMask = 0xFF000000u; return true;
+    case 88: case 93: d.kind = DdsInfo::RGBA_MASKS; d.bitCount = 32;         // B8G8R8X8_UNORM(_SRGB)
+        d.rMask = 0xFF0000u; d.gMask = 0xFF00u; d.bMask = 0xFFu; d.aMask = 0u; return true;
+    default: return false;
+    }
+}
+
+// DDS_HEADER (Common/DDSTextureLoader.cpp:94-110) and, behind the FourCC "DX10", DDS_HEADER_DXT10 (:112-119, read at :1355-1400)
 bool parse_header(const std::vector<uint8_t>& f, DdsInfo& d)
 {
     if (f.size() < 128 || std::memcmp(f.data(), "DDS ", 4) != 0 || rd32(&f[4]) != 124) return false;
     d.height = rd32(&f[12]);
     d.width = rd32(&f[16]);
-    const uint32_t pfFlags = rd32(&f[80]);
+    d.fileLevels = (rd32(&f[8]) & 0x20000u) ? rd32(&f[28]) : 1u;          // DDSD_MIPMAPCOUNT
+    if (d.fileLevels == 0) d.fileLevels = 1;
+    const uint32_t pfFlags = rd32(&f[80]), caps2 = rd32(&f[112]);
+    if (caps2 & 0x200u) {                       // DDSCAPS2_CUBEMAP: all six faces or nothing (DDSTextureLoader.cpp:1774-1779)
+        if ((caps2 & 0xFC00u) != 0xFC00u) return false;
+        d.cube = true;
+    }
     if (pfFlags & 0x4u) {                       // DDPF_FOURCC
         if (std::memcmp(&f[84], "DXT1", 4) == 0) d.kind = DdsInfo::BC1;
         else if (std::memcmp(&f[84], "DXT5", 4) == 0) d.kind = DdsInfo::BC3;
-        else return false;                      // DX10 header and the other FourCCs are not used by the reference's textures
+        else if (std::memcmp(&f[84], "DX10", 4) == 0) {
+            if (f.size() < 148) return false;
+            if (!set_dxgi_format(rd32(&f[128]), d)) return false;
+            if (rd32(&f[132]) != 3u) return false;                       // D3D10_RESOURCE_DIMENSION_TEXTURE2D
+            if (rd32(&f[136]) & 0x4u) d.cube = true;                      // DDS_RESOURCE_MISC_TEXTURECUBE (:1729-1732)
+            if (rd32(&f[140]) != 1u) return false;                        // arrays (of textures or of cubes) are not used by the reference
+            d.dataOffset = 148;
+        }
+        else return false;                      // the other FourCCs are not used by the reference's textures
     } else if (pfFlags & 0x40u) {               // DDPF_RGB
         d.kind = DdsInfo::RGBA_MASKS;
         d.bitCount = rd32(&f[88]);
@@ -135,12 +167,12 @@ int load_dds(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32_t* w
     if (!parse_header(f, d)) return CRYCHIC_E_UNSUPPORTED;
     // D3D12's own limit (D3D12_REQ_TEXTURE2D_U_OR_V_DIMENSION): also keeps every size computed below far from wrapping
     if (d.width == 0 || d.height == 0 || d.width > 16384u || d.height > 16384u) return CRYCHIC_E_UNSUPPORTED;
+    if (d.cube) return CRYCHIC_E_UNSUPPORTED;                   // a cube map: crychic_load_dds_cube_rgba8
     uint32_t levels = 1;
-    if (wantMips && (rd32(&f[8]) & 0x20000u)) {                // DDSD_MIPMAPCOUNT
-        levels = rd32(&f[28]);
+    if (wantMips) {
+        levels = d.fileLevels;
         uint32_t full = 1;
         for (uint32_t m = d.width > d.height ? d.width : d.height; m > 1; m >>= 1) ++full;
-        if (levels == 0) levels = 1;
         if (levels > full) return CRYCHIC_E_UNSUPPORTED;        // more levels than a 1 x 1 tail allows: not a file this loader trusts
     }
     if (width) *width = d.width;
@@ -163,7 +195,38 @@ int load_dds(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32_t* w
     return 0;
 }
 
+// The sky cube map: level 0 of each of the six faces, stacked in the file's (= D3D's) face order.
+int load_dds_cube(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32_t* dim)
+{
+    if (!path) return CRYCHIC_E_INVALID_ARG;
+    std::ifstream in(path, std::ios::binary);
+    if (!in) return CRYCHIC_E_INVALID_ARG;
+    std::vector<uint8_t> f((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    DdsInfo d;
+    if (!parse_header(f, d) || !d.cube) return CRYCHIC_E_UNSUPPORTED;
+    if (d.width != d.height || d.width > 16384u) return CRYCHIC_E_UNSUPPORTED;
+    uint32_t full = 1;
+    for (uint32_t m = d.width; m > 1; m >>= 1) ++full;
+    if (d.fileLevels > full) return CRYCHIC_E_UNSUPPORTED;
+    if (dim) *dim = d.width;
+    if (!rgba8) return 0;
+    const size_t faceOut = (size_t)d.width * d.width * 4;
+    if (capacityBytes < 6 * faceOut) return CRYCHIC_E_INVALID_ARG;
+    size_t faceFile = 0;                                          // a face's whole chain in the file
+    { uint32_t w = d.width; for (uint32_t k = 0; k < d.fileLevels; ++k) { faceFile += level_file_bytes(d, w, w); w = w > 1 ? w >> 1 : 1; } }
+    if (f.size() - d.dataOffset < 6 * faceFile) return CRYCHIC_E_INVALID_ARG;      // truncated payload
+    for (uint32_t face = 0; face < 6; ++face)
+        decode_level(d, f.data() + d.dataOffset + face * faceFile, d.width, d.width, rgba8 + face * faceOut);
+    return 0;
+}
+
 }  // namespace
+
+extern "C" int crychic_load_dds_cube_rgba8(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32_t* dim)
+{
+    if (!dim) return CRYCHIC_E_INVALID_ARG;
+    return load_dds_cube(path, rgba8, capacityBytes, dim);
+}
 
 extern "C" int crychic_load_dds_rgba8(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32_t* width, uint32_t* height)
 {

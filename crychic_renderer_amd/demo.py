@@ -1,4 +1,4 @@
-"""python -m crychic_renderer_amd.demo [--size WxH] [--out frame.ppm] [--textures DIR]
+"""python -m crychic_renderer_amd.demo [--size WxH] [--out frame.ppm] [--textures DIR] [--cube FILE.dds]
 
 Renders one frame of the reference's live scene entirely on the GPU -- 4 shadow cascades, view normals + depth, G-buffer
 (HIP rasteriser), SSAO + blur, deferred lighting + sky -- and writes it as PPM (the headless stand-in for Present)."""
@@ -14,6 +14,8 @@ def main():
     ap.add_argument("--out", default="frame.ppm")
     ap.add_argument("--shadow-dim", type=int, default=2048)
     ap.add_argument("--textures", default="", help="directory with the reference's DDS textures (else procedural stand-ins)")
+    ap.add_argument("--cube", default="", help="a DDS cube map for the sky and the reflections, e.g. the reference's Textures/snowcube1024.dds "
+                                               "(else a procedural one)")
     a = ap.parse_args()
     W, H = (int(v) for v in a.size.lower().split("x"))
     import torch
@@ -24,7 +26,8 @@ def main():
     tex = g.reference_textures(a.textures) if a.textures else g.procedural_textures(64)
     geo = SceneGeometry(ctx, g.cascade_scene_items(), g.reference_materials(), tex)
     sgeo = SceneGeometry(ctx, g.cascade_scene_items(shadow_layer=True))
-    app = Crychic(ctx, W, H, torch.from_numpy(consts.randvec.copy()).to(ctx.device), scene.make_cubemap(256, ctx.device), shadow_dim=a.shadow_dim)
+    cube = torch.from_numpy(g.load_dds_cube(a.cube)).to(ctx.device) if a.cube else scene.make_cubemap(256, ctx.device)
+    app = Crychic(ctx, W, H, torch.from_numpy(consts.randvec.copy()).to(ctx.device), cube, shadow_dim=a.shadow_dim)
     app.mMainPassCB, app.mSsaoCB = consts.pass_cb, consts.ssao_cb
     for k in range(4):
         cb = PassConstants()

@@ -195,6 +195,16 @@ def load_dds(path):
     return out
 
 
+def load_dds_cube(path):
+    """A DDS cube map as the 6 x dim x dim x 4 uint8 plane the lighting pass takes (crychic_load_dds_cube_rgba8): level 0 of the
+    faces +X, -X, +Y, -Y, +Z, -Z."""
+    d = C.c_uint32()
+    check(lib.crychic_load_dds_cube_rgba8(path.encode(), None, 0, C.byref(d)))
+    out = np.zeros((6, d.value, d.value, 4), np.uint8)
+    check(lib.crychic_load_dds_cube_rgba8(path.encode(), out.ctypes.data, out.nbytes, C.byref(d)))
+    return out
+
+
 def reference_textures(texture_dir):
     """gTextureMaps in heap order (CRYCHIC::LoadTextures, CRYCHIC.cpp:954-959): bricks2, bricks2_nmap, tile, tile_nmap,
     white1x1, default_nmap."""

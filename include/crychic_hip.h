@@ -313,6 +313,14 @@ int crychic_load_dds_rgba8(const char* path, uint8_t* rgba8, size_t capacityByte
 int crychic_load_dds_rgba8_mips(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32_t* width, uint32_t* height,
                                 uint32_t* mipLevels);
 
+/* The sky cube map CRYCHIC::LoadTextures opens (CRYCHIC.cpp:960,968: snowcube1024.dds through CreateDDSTextureFromFile12; bound
+ * as a TextureCube, CRYCHIC.cpp:1148-1151): a DDS cube map -- DDSCAPS2_CUBEMAP with all six faces, or a DX10 header with
+ * DDS_RESOURCE_MISC_TEXTURECUBE -- holding DXT1 / DXT5 / 32-bit pixels, decoded to the 6 x dim x dim R8G8B8A8 plane (faces +X, -X,
+ * +Y, -Y, +Z, -Z stacked) that crychic_deferred_light / crychic_draw_hot_path take as the cube map.  Level 0 of every face: the
+ * lighting and sky passes filter level 0.  NULL buffer: only *dim is written.  The 2-D loaders above refuse
+ * a cube file and this one refuses a 2-D file (CRYCHIC_E_UNSUPPORTED). */
+int crychic_load_dds_cube_rgba8(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32_t* dim);
+
 /* Present stand-in (row f3; the reference calls IDXGISwapChain::Present, CRYCHIC.cpp:294-297): writes a HOST R8G8B8A8
  * image as binary PPM (alpha dropped). */
 int crychic_save_ppm(const char* path, const uint8_t* rgba8, uint32_t width, uint32_t height);

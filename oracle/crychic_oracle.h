@@ -220,6 +220,8 @@ uint16_t or_float_to_half(float f);
 int or_load_dds_rgba8(const char* path, uint8_t* rgba8, size_t capacity, uint32_t* width, uint32_t* height);
 /* The same with the file's mip chain (levels back to back); *mips = number of levels decoded. */
 int or_load_dds_rgba8_mips(const char* path, uint8_t* rgba8, size_t capacity, uint32_t* width, uint32_t* height, uint32_t* mips);
+/* A DDS cube map (legacy caps2 or DX10 header): level 0 of the faces +X, -X, +Y, -Y, +Z, -Z as one 6 x dim x dim R8G8B8A8 plane. */
+int or_load_dds_cube_rgba8(const char* path, uint8_t* rgba8, size_t capacity, uint32_t* dim);
 
 /* or_deferred_light plus NUM_POINT_LIGHTS point lights from a separate buffer: BUILD-DEFINED EXTENSION for BASELINE
  * configs[4] (the reference's point-light branch, PBR.hlsl:109-124, is dead code); see or_light.c. */

@@ -86,6 +86,40 @@ static size_t decode_level(int kind, const uint32_t m[4], const unsigned char* s
     return need;
 }
 
+/* Pixel format of a DDS file whose magic and header size have been checked: 1 = DXT1, 5 = DXT5, 0 = 32-bit masks in m[], -1 = not
+ * one of the formats the path uses.  *off = where the pixel data starts (behind the DX10 header when there is one), *cube = the
+ * file is a cube map with all six faces (Common/DDSTextureLoader.cpp:1729-1732, 1774-1779). */
+static int pixel_kind(const unsigned char* d, size_t n, uint32_t m[4], size_t* off, int* cube)
+{
+    uint32_t pf = le32(d + 80), caps2 = le32(d + 112);
+    *off = 128;
+    *cube = 0;
+    if (caps2 & 0x200u) {
+        if ((caps2 & 0xFC00u) != 0xFC00u) return -1;
+        *cube = 1;
+    }
+    if ((pf & 4u) && memcmp(d + 84, "DXT1", 4) == 0) return 1;
+    if ((pf & 4u) && memcmp(d + 84, "DXT5", 4) == 0) return 5;
+    if ((pf & 4u) && memcmp(d + 84, "DX10", 4) == 0) {
+        if (n < 148 || le32(d + 132) != 3u || le32(d + 140) != 1u) return -1;
+        if (le32(d + 136) & 4u) *cube = 1;
+        *off = 148;
+        switch (le32(d + 128)) {
+        case 71: case 72: return 1;
+        case 77: case 78: return 5;
+        case 28: case 29: m[0] = 0xFFu; m[1] = 0xFF00u; m[2] = 0xFF0000u; m[3] = 0xFF000000u; return 0;
+        case 87: case 91: m[0] = 0xFF0000u; m[1] = 0xFF00u; m[2] = 0xFFu; m[3] = 0xFF000000u; return 0;
+        case 88: case 93: m[0] = 0xFF0000u; m[1] = 0xFF00u; m[2] = 0xFFu; m[3] = 0u; return 0;
+        default: return -1;
+        }
+    }
+    if (!(pf & 4u) && (pf & 0x40u) && le32(d + 88) == 32) {
+        m[0] = le32(d + 92); m[1] = le32(d + 96); m[2] = le32(d + 100); m[3] = (pf & 1u) ? le32(d + 104) : 0;
+        return 0;
+    }
+    return -1;
+}
+
 /* want_mips = 0: level 0 only.  Levels are written back to back, level k = max(1, w >> k) x max(1, h >> k)
  * (Common/DDSTextureLoader.cpp uploads the levels the file stores; it generates none). */
 static int load_dds(const char* path, uint8_t* rgba8, size_t capacity, uint32_t* width, uint32_t* height, uint32_t* mips, int want_mips)
@@ -100,15 +134,12 @@ static int load_dds(const char* path, uint8_t* rgba8, size_t capacity, uint32_t*
     fclose(f);
     int rc = -4;
     if (n >= 128 && memcmp(d, "DDS ", 4) == 0 && le32(d + 4) == 124) {
-        uint32_t h = le32(d + 12), w = le32(d + 16), pf = le32(d + 80);
-        int kind = -1;
+        uint32_t h = le32(d + 12), w = le32(d + 16);
         uint32_t m[4] = { 0, 0, 0, 0 };
-        if ((pf & 4u) && memcmp(d + 84, "DXT1", 4) == 0) kind = 1;
-        else if ((pf & 4u) && memcmp(d + 84, "DXT5", 4) == 0) kind = 5;
-        else if (!(pf & 4u) && (pf & 0x40u) && le32(d + 88) == 32) {
-            kind = 0;
-            m[0] = le32(d + 92); m[1] = le32(d + 96); m[2] = le32(d + 100); m[3] = (pf & 1u) ? le32(d + 104) : 0;
-        }
+        size_t off = 128;
+        int cube = 0;
+        int kind = pixel_kind(d, (size_t)n, m, &off, &cube);
+        if (cube) kind = -1;      /* a cube map: or_load_dds_cube_rgba8 */
         uint32_t levels = 1;
         if (want_mips && (le32(d + 8) & 0x20000u)) {
             levels = le32(d + 28);
@@ -126,8 +157,8 @@ static int load_dds(const char* path, uint8_t* rgba8, size_t capacity, uint32_t*
             if (!rgba8) rc = 0;
             else if (capacity < need) rc = -1;
             else {
-                const unsigned char* src = d + 128;
-                size_t avail = (size_t)n - 128;
+                const unsigned char* src = d + off;
+                size_t avail = (size_t)n - off;
                 uint32_t lw = w, lh = h;
                 rc = 0;
                 /* refuse a truncated file before writing anything */
@@ -158,4 +189,45 @@ int or_load_dds_rgba8_mips(const char* path, uint8_t* rgba8, size_t capacity, ui
 {
     if (!mips) return -1;
     return load_dds(path, rgba8, capacity, width, height, mips, 1);
+}
+
+/* The sky cube map (CRYCHIC.cpp:960,968,1148-1151): level 0 of the six faces, +X -X +Y -Y +Z -Z, each face followed in the file by
+ * the rest of its mip chain. */
+int or_load_dds_cube_rgba8(const char* path, uint8_t* rgba8, size_t capacity, uint32_t* dim)
+{
+    FILE* f = fopen(path, "rb");
+    if (!f) return -1;
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    unsigned char* d = (unsigned char*)malloc((size_t)(n > 0 ? n : 1));
+    if (fread(d, 1, (size_t)n, f) != (size_t)n) { fclose(f); free(d); return -1; }
+    fclose(f);
+    int rc = -4;
+    if (n >= 128 && memcmp(d, "DDS ", 4) == 0 && le32(d + 4) == 124) {
+        uint32_t h = le32(d + 12), w = le32(d + 16), m[4] = { 0, 0, 0, 0 };
+        uint32_t levels = (le32(d + 8) & 0x20000u) ? le32(d + 28) : 1u;
+        size_t off = 128;
+        int cube = 0;
+        int kind = pixel_kind(d, (size_t)n, m, &off, &cube);
+        uint32_t full = 1;
+        for (uint32_t mm = w; mm > 1; mm >>= 1) ++full;
+        if (levels == 0) levels = 1;
+        if (kind >= 0 && cube && w == h && w > 0 && w <= 16384u && levels <= full) {
+            if (dim) *dim = w;
+            size_t face_file = 0;
+            { uint32_t lw = w; for (uint32_t k = 0; k < levels; ++k) {
+                  face_file += kind == 0 ? (size_t)lw * lw * 4 : (size_t)((lw + 3) / 4) * ((lw + 3) / 4) * (kind == 1 ? 8 : 16);
+                  lw = lw > 1 ? lw >> 1 : 1; } }
+            if (!rgba8) rc = 0;
+            else if (capacity < (size_t)6 * w * w * 4 || (size_t)n - off < 6 * face_file) rc = -1;
+            else {
+                rc = 0;
+                for (uint32_t face = 0; face < 6; ++face)
+                    if (!decode_level(kind, m, d + off + face * face_file, (size_t)n - off - face * face_file, w, w, rgba8 + (size_t)face * w * w * 4)) rc = -1;
+            }
+        }
+    }
+    free(d);
+    return rc;
 }

@@ -7,6 +7,8 @@ import struct
 import numpy as np
 import pytest
 
+import oracle_lib
+
 REF_TEX = "/root/reference/Textures"
 
 
@@ -242,3 +244,119 @@ def test_dds_header_with_absurd_size_is_refused(built_lib, tmp_path):
     ww, hh = C.c_uint32(), C.c_uint32()
     buf = (C.c_uint8 * 64)()
     assert lib.crychic_load_dds_rgba8(path.encode(), buf, 64, C.byref(ww), C.byref(hh)) == 0 and (ww.value, hh.value) == (4, 4)
+
+
+# ---- the sky cube map (CRYCHIC.cpp:960,968: snowcube1024.dds; the file itself is not in the checkout) ---------------------------
+def cube_header(dim, levels, fourcc=None, masks=None, dx10=None, all_faces=True):
+    """Legacy cube header (DDSCAPS2_CUBEMAP + faces) or, with dx10 = (dxgiFormat, miscFlag), a DX10 one."""
+    if dx10:
+        pf = struct.pack("<II4sIIIII", 32, 0x4, b"DX10", 0, 0, 0, 0, 0)
+    else:
+        pf_flags = 0x4 if fourcc else (0x41 if masks[3] else 0x40)
+        pf = struct.pack("<II4sIIIII", 32, pf_flags, fourcc or b"\0\0\0\0", 0 if fourcc else 32, *(masks or (0, 0, 0, 0)))
+    caps2 = 0 if dx10 else (0x200 | (0xFC00 if all_faces else 0x0C00))
+    hdr = struct.pack("<IIIIIII", 124, 0x1007 | (0x20000 if levels > 1 else 0), dim, dim, 0, 0, levels) + b"\0" * 44 + pf \
+        + struct.pack("<IIIII", 0x1008 | (0x400000 if levels > 1 else 0), caps2, 0, 0, 0)
+    assert len(hdr) == 124
+    ext = struct.pack("<IIIII", dx10[0], 3, dx10[1], 1, 0) if dx10 else b""
+    return b"DDS " + hdr + ext
+
+
+def oracle_cube(oracle, path):
+    L = oracle.lib
+    L.or_load_dds_cube_rgba8.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    d = C.c_uint32()
+    assert L.or_load_dds_cube_rgba8(path.encode(), None, 0, C.byref(d)) == 0
+    out = np.zeros((6, d.value, d.value, 4), np.uint8)
+    assert L.or_load_dds_cube_rgba8(path.encode(), out.ctypes.data, out.nbytes, C.byref(d)) == 0
+    return out
+
+
+def test_cube_map_loader(built_lib, oracle, tmp_path):
+    """crychic_load_dds_cube_rgba8: six faces in D3D order, each followed in the file by its own mip tail (which the loader skips),
+    for uncompressed, DXT1 and DXT5 payloads and both header generations; known answers, and == the oracle's decoder."""
+    from crychic_renderer_amd import geometry as g
+    rng = np.random.default_rng(5)
+    # 32-bit A8R8G8B8, 4 x 4 faces with 3 levels (4, 2, 1): face k is filled with the value 10 k + level
+    def chain(face, dim, levels):
+        out = b""
+        for lv in range(levels):
+            d = max(1, dim >> lv)
+            px = np.zeros((d, d, 4), np.uint8)
+            px[..., 0], px[..., 1], px[..., 2], px[..., 3] = 10 * face + lv, 100 + face, 200 + lv, 255 - face      # memory order B, G, R, A
+            out += px.tobytes()
+        return out
+    p = tmp_path / "cube_argb.dds"
+    p.write_bytes(cube_header(4, 3, None, (0xFF0000, 0xFF00, 0xFF, 0xFF000000)) + b"".join(chain(k, 4, 3) for k in range(6)))
+    cube = g.load_dds_cube(str(p))
+    assert cube.shape == (6, 4, 4, 4)
+    for k in range(6):
+        assert (cube[k] == np.array([200, 100 + k, 10 * k, 255 - k], np.uint8)).all(), k       # R, G, B, A of level 0
+    assert np.array_equal(cube, oracle_cube(oracle, str(p)))
+    # DXT1 and DXT5, 8 x 8 faces with the full chain (8, 4, 2, 1): random blocks; the same payload behind a DX10 header
+    for fourcc, dxgi, blk in ((b"DXT1", 71, 8), (b"DXT5", 77, 16)):
+        def level_bytes(d):
+            return ((d + 3) // 4) ** 2 * blk
+        faces = [rng.integers(0, 256, sum(level_bytes(max(1, 8 >> lv)) for lv in range(4)), dtype=np.uint8).tobytes() for _ in range(6)]
+        legacy, dx10 = tmp_path / ("cube_%s.dds" % fourcc.decode()), tmp_path / ("cube_%s_dx10.dds" % fourcc.decode())
+        legacy.write_bytes(cube_header(8, 4, fourcc) + b"".join(faces))
+        dx10.write_bytes(cube_header(8, 4, dx10=(dxgi, 0x4)) + b"".join(faces))
+        a, b = g.load_dds_cube(str(legacy)), g.load_dds_cube(str(dx10))
+        assert a.shape == (6, 8, 8, 4) and np.array_equal(a, b)
+        assert np.array_equal(a, oracle_cube(oracle, str(legacy))) and np.array_equal(b, oracle_cube(oracle, str(dx10)))
+        # face k's level 0 is what the 2-D decoder makes of the same blocks
+        flat = tmp_path / "flat.dds"
+        for k in (0, 5):
+            flat.write_bytes(dds_header(8, 8, fourcc) + faces[k][:level_bytes(8)])
+            assert np.array_equal(a[k], g.load_dds(str(flat))), (fourcc, k)
+    # refusals: a 2-D file, a cube with missing faces, a truncated cube, a buffer that is too small; the 2-D loaders refuse a cube
+    lib = built_lib.lib
+    d, w, h = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    flat.write_bytes(dds_header(4, 4, b"DXT1") + bytes(8))
+    assert lib.crychic_load_dds_cube_rgba8(str(flat).encode(), None, 0, C.byref(d)) == -4
+    part = tmp_path / "part.dds"
+    part.write_bytes(cube_header(4, 1, b"DXT1", all_faces=False) + bytes(8 * 6))
+    assert lib.crychic_load_dds_cube_rgba8(str(part).encode(), None, 0, C.byref(d)) == -4
+    cut = tmp_path / "cut.dds"
+    cut.write_bytes(cube_header(4, 1, b"DXT1") + bytes(8 * 5))
+    buf = np.zeros(6 * 4 * 4 * 4, np.uint8)
+    assert lib.crychic_load_dds_cube_rgba8(str(cut).encode(), buf.ctypes.data, buf.nbytes, C.byref(d)) == -1
+    assert lib.crychic_load_dds_cube_rgba8(str(p).encode(), buf.ctypes.data, buf.nbytes - 1, C.byref(d)) == -1
+    assert lib.crychic_load_dds_rgba8(str(p).encode(), None, 0, C.byref(w), C.byref(h)) == -4
+
+
+@pytest.mark.gpu
+def test_loaded_cube_map_lights_a_frame(built_lib, oracle, tmp_path):
+    """A cube map that went through the DDS loader is the plane the lighting pass samples: sky + reflections of a small frame ==
+    the oracle fed with the oracle's decode of the same file."""
+    import torch
+    import scene_util
+    from crychic_renderer_amd import Context, Crychic, geometry as g
+    rng = np.random.default_rng(11)
+    dim = 16
+    faces = [rng.integers(0, 256, (dim // 4) ** 2 * 8, dtype=np.uint8).tobytes() for _ in range(6)]
+    p = tmp_path / "sky.dds"
+    p.write_bytes(cube_header(dim, 1, b"DXT1") + b"".join(faces))
+    cube = g.load_dds_cube(str(p))
+    assert np.array_equal(cube, oracle_cube(oracle, str(p)))
+    W, H = 128, 96
+    planes = scene_util.cpu_scene(W, H, 256, 8)
+    npl = scene_util.np_planes(planes)
+    npl["cube"] = cube
+    ctx = Context(0)
+    try:
+        dev = {k: torch.from_numpy(np.ascontiguousarray(v).view(np.int32) if v.dtype == np.uint32 else np.ascontiguousarray(v)).to(ctx.device)
+               for k, v in npl.items()}
+        app = Crychic(ctx, W, H, dev["randvec"], dev["cube"], shadow_dim=256)
+        app.load_scene({**dev, "consts": planes["consts"]})
+        app.blurCount, app.numDirLights, app.flags = 2, 3, 1           # CRYCHIC_LIGHT_SKY: uncovered pixels show the cube map
+        app.Draw()
+        torch.cuda.synchronize()
+        scb = oracle_lib.as_oracle_cb(planes["consts"].ssao_cb, oracle_lib.OrSsaoConstants)
+        pcb = oracle_lib.as_oracle_cb(planes["consts"].pass_cb, oracle_lib.OrPassConstants)
+        amb = oracle.compute_ssao(scb, npl["normal"], npl["depth"], npl["randvec"], 2)
+        ref = oracle.deferred_light(pcb, npl["g0"], npl["g1"], npl["g2"], npl["depth"], amb, npl["shadow"], cube, 3, app.pcfSearchRadius, sky=True)
+        assert np.array_equal(app.mBackBuffer.cpu().numpy(), ref)
+        assert (npl["depth"] & 0xFFFFFF == 0xFFFFFF).any()             # the frame does show sky
+    finally:
+        ctx.close()
