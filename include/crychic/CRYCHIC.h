@@ -274,6 +274,47 @@ public:
     ID3D12Resource* DepthStencilBuffer() { return mDepthStencilBuffer.get(); }
     ID3D12Resource* CurrentBackBuffer() { return mBackBuffer.get(); }
     void SetCubeMap(std::unique_ptr<ID3D12Resource> cube, UINT dim) { mCubeMap = std::move(cube); mCubeMapSize = dim; }
+
+    // CRYCHIC::LoadTextures (CRYCHIC.cpp:939-973): the six material textures in heap order (= gTextureMaps indices, :954-959) with the
+    // mip chains their files store, and the sky cube map, from `dir` (the reference opens "Textures/...").  The DDS decoding that
+    // CreateDDSTextureFromFile12 + the texture units do is done on the host (crychic_load_dds_*); a missing cube file keeps the
+    // cube map set through SetCubeMap (snowcube1024.dds is not part of the reference checkout).
+    void LoadTextures(const std::string& dir, bool requireCubeMap = false)
+    {
+        static const char* const files[6] = { "bricks2.dds", "bricks2_nmap.dds", "tile.dds", "tile_nmap.dds", "white1x1.dds", "default_nmap.dds" };
+        hipStream_t s = mCommandList->Stream();
+        std::vector<crychic_texture> tex;
+        std::vector<std::unique_ptr<ID3D12Resource>> planes;
+        std::vector<uint8_t> host;
+        for (const char* name : files) {
+            const std::string path = dir + "/" + name;
+            uint32_t w = 0, h = 0, levels = 0;
+            CrychicThrowIfFailed(crychic_load_dds_rgba8_mips(path.c_str(), nullptr, 0, &w, &h, &levels));
+            size_t bytes = 0;
+            for (uint32_t k = 0, lw = w, lh = h; k < levels; ++k) { bytes += (size_t)lw * lh * 4; lw = lw > 1 ? lw >> 1 : 1; lh = lh > 1 ? lh >> 1 : 1; }
+            host.resize(bytes);
+            CrychicThrowIfFailed(crychic_load_dds_rgba8_mips(path.c_str(), host.data(), host.size(), &w, &h, &levels));
+            planes.push_back(std::make_unique<ID3D12Resource>(bytes, ID3D12Resource::DEFAULT_HEAP));
+            planes.back()->Upload(host.data(), bytes, s);
+            mCommandList->Flush();                                      // `host` is reused for the next file
+            tex.push_back(crychic_texture{ static_cast<const uint8_t*>(planes.back()->Data()), w, h, levels });
+        }
+        const std::string cubePath = dir + "/snowcube1024.dds";
+        uint32_t dim = 0;
+        const int rc = crychic_load_dds_cube_rgba8(cubePath.c_str(), nullptr, 0, &dim);
+        if (rc == 0) {
+            host.resize((size_t)6 * dim * dim * 4);
+            CrychicThrowIfFailed(crychic_load_dds_cube_rgba8(cubePath.c_str(), host.data(), host.size(), &dim));
+            auto cube = std::make_unique<ID3D12Resource>(host.size(), ID3D12Resource::DEFAULT_HEAP);
+            cube->Upload(host.data(), host.size(), s);
+            mCommandList->Flush();
+            SetCubeMap(std::move(cube), dim);
+        } else if (requireCubeMap) {
+            CrychicThrowIfFailed(rc);
+        }
+        mTextures = std::move(tex);
+        mTexturePlanes = std::move(planes);
+    }
     ID3D12GraphicsCommandList* CommandList() { return mCommandList.get(); }
     ID3D12Device* Device() { return md3dDevice.get(); }
     float AspectRatio() const { return (float)mClientWidth / (float)mClientHeight; }
@@ -567,6 +608,7 @@ private:
     std::unordered_map<std::string, std::unique_ptr<MeshGeometry>> mGeometries;      // CRYCHIC.h:123-125
     std::unordered_map<std::string, std::unique_ptr<Material>> mMaterials;
     std::vector<crychic_texture> mTextures;                                           // gTextureMaps (row f4 loads the DDS files; empty = white / flat)
+    std::vector<std::unique_ptr<ID3D12Resource>> mTexturePlanes;                      // the device copies mTextures points into (LoadTextures)
     std::vector<std::unique_ptr<RenderItem>> mAllRitems;                              // CRYCHIC.h:132-135
     std::vector<RenderItem*> mRitemLayer[(int)RenderLayer::Count];
     std::vector<int> mInstanceCounts;                                                 // CRYCHIC.h:183

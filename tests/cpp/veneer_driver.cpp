@@ -54,6 +54,7 @@ int main(int argc, char** argv)
         auto cube = std::make_unique<ID3D12Resource>((size_t)6 * CD * CD * 4, ID3D12Resource::DEFAULT_HEAP);
         put(cube.get(), dir + "/cube.bin", s);
         app.SetCubeMap(std::move(cube), CD);
+        if (argc > 9) app.LoadTextures(argv[9], true);       // CRYCHIC::LoadTextures: six material textures + the sky cube map from a directory
 
         GameTimer gt;
         for (int frame = 0; frame < 5; ++frame) {  // cycles the 3-deep frame-resource ring and its fences

@@ -97,3 +97,49 @@ def test_veneer_full_scene_matches_oracle(built_lib, oracle, tmp_path):
         assert np.array_equal(np.fromfile(d + "/g%d_out.bin" % i, np.uint32).reshape(H, W, 4), ref[k].view(np.uint32)), k
     assert np.array_equal(np.fromfile(d + "/ao.bin", np.uint16).reshape(H // 2, W // 2), ref["ao"])
     assert np.array_equal(np.fromfile(d + "/out.bin", np.uint8).reshape(H, W, 4), ref["rgba8"])
+
+
+@pytest.mark.gpu
+def test_veneer_load_textures(built_lib, oracle, tmp_path):
+    """CRYCHIC::LoadTextures through the veneer: the six material textures (with their mip chains) and the sky cube map are read
+    from DDS files in a directory laid out like the reference's Textures/, and the frame the veneer then renders -- G-buffer
+    sampled anisotropically from those chains, sky and reflections from that cube map -- equals the all-CPU oracle frame fed with
+    the oracle's own decode of the same files."""
+    import ctypes as C
+    import raster_util
+    from test_textures import cube_header, mip_header, oracle_cube, oracle_load_mips
+    from crychic_renderer_amd import geometry as g, scene
+    exe = build_driver()
+    W, H, SD, CD, BC, NL = 160, 120, 256, 16, 2, 1
+    d = str(tmp_path)
+    tdir = tmp_path / "Textures"
+    tdir.mkdir()
+    names = ["bricks2.dds", "bricks2_nmap.dds", "tile.dds", "tile_nmap.dds", "white1x1.dds", "default_nmap.dds"]
+    procedural = g.procedural_textures(32)
+    masks = (0xFF0000, 0xFF00, 0xFF, 0xFF000000)                      # A8R8G8B8: memory order B, G, R, A
+    for name, t in zip(names, procedural):
+        levels = g.box_mips(t)
+        (tdir / name).write_bytes(mip_header(32, 32, len(levels), None, masks) + b"".join(np.ascontiguousarray(l[..., [2, 1, 0, 3]]).tobytes() for l in levels))
+    rng = np.random.default_rng(3)
+    faces = rng.integers(0, 256, (6, CD, CD, 4), dtype=np.uint8)
+    (tdir / "snowcube1024.dds").write_bytes(cube_header(CD, 1, None, masks) + faces.tobytes())
+    np.zeros((6, CD, CD, 4), np.uint8).tofile(d + "/cube.bin")        # what SetCubeMap installs first: LoadTextures must replace it
+    r = subprocess.run([exe, d, str(W), str(H), str(SD), str(CD), str(BC), str(NL), "scene", str(tdir)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    consts = raster_util.frame_constants(W, H, SD)
+    C.memmove(C.addressof(consts.ssao_cb), open(d + "/ssao_cb.bin", "rb").read(), C.sizeof(consts.ssao_cb))
+    C.memmove(C.addressof(consts.pass_cb), open(d + "/pass_cb.bin", "rb").read(), C.sizeof(consts.pass_cb))
+    cam = scene.default_camera(W, H)
+    items, shadow_items = g.cascade_scene_items(cull_camera=cam), g.cascade_scene_items(shadow_layer=True, cull_camera=cam)
+    tex = [oracle_load_mips(oracle, str(tdir / n)) for n in names]
+    cube = oracle_cube(oracle, str(tdir / "snowcube1024.dds"))
+    assert np.array_equal(cube, faces[..., [2, 1, 0, 3]])
+    ref = raster_util.oracle_frame(oracle, consts, items, shadow_items, g.reference_materials(), tex, W, H, SD, cube, BC, NL,
+                                   built_lib.lib.crychic_pcf_search_radius(SD, 1))
+    for i, k in enumerate(("g0", "g1", "g2")):
+        assert np.array_equal(np.fromfile(d + "/g%d_out.bin" % i, np.uint32).reshape(H, W, 4), ref[k].view(np.uint32)), k
+    assert np.array_equal(np.fromfile(d + "/out.bin", np.uint8).reshape(H, W, 4), ref["rgba8"])
+    # the textures do change the frame: the same scene without them (the previous test) has other albedo
+    flat = raster_util.oracle_frame(oracle, consts, items, shadow_items, g.reference_materials(), None, W, H, SD, cube, BC, NL,
+                                    built_lib.lib.crychic_pcf_search_radius(SD, 1))
+    assert not np.array_equal(flat["g1"], ref["g1"])
