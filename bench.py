@@ -384,6 +384,17 @@ def dump_scene(d, planes, args, pcf_radius):
     print("scene dumped to", d)
 
 
+def baseline_config_label(W, H, args, world):
+    """The BASELINE.json config whose size and pass counts this run matches, or a plain statement that it matches none."""
+    if args.point_lights:
+        return "BASELINE configs[4] (%dx%d + %d point lights)%s" % (W, H, args.point_lights ** 2, "" if (W, H) == (7680, 4320) else " at a non-BASELINE size")
+    if (W, H) == (3840, 2160) and args.blur_count == 4:
+        return "BASELINE configs[3]" if world > 1 else "BASELINE configs[2]"
+    if (W, H) == (1920, 1080) and args.blur_count == 1:
+        return "BASELINE configs[1]"
+    return "no BASELINE config (custom size / blur count)"
+
+
 def bench_camera(args):
     from crychic_renderer_amd import scene
     return scene.covered_camera(args.width, args.height) if args.camera == "covered" else scene.default_camera(args.width, args.height)
@@ -697,29 +708,23 @@ def main():
     nev = max(50, min(args.steps, 200))
     _, frame_ms_median = frame_stats(app, row0, rows, nev)
 
+    # ---- per-pass timing of the same workload (HIP events recorded by the library on the launch stream) ----
+    app.set_profiling(True)
+    app.mBackBuffer = planes["out"]
+    acc = {"ssao_ms": 0.0, "blur_ms": 0.0, "light_ms": 0.0, "total_ms": 0.0}
+    nprof = max(5, min(50, args.steps))
+    for _ in range(nprof):
+        app.Draw(row0, rows)
+        t = app.last_pass_times()
+        for k in acc:
+            acc[k] += t[k] / nprof
+    app.set_profiling(False)
+
     # ---- N = 1 informational legs (labelled; none of them is `value`) ----
     legs = {}
     if world == 1 and not args.strip and exchange is None and not args.no_legs and not args.point_lights:
-        nleg = max(20, min(args.steps, 100))
-        # (a) throughput: three frames in flight on three streams, every pipeline on its own copy of every input plane
-        if nflight == 1:
-            pipes = [app] + [new_app(own_inputs=True) for _ in range(2)]
-            pstreams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(2)]
-            pouts = [planes["out"]] + [torch.zeros_like(planes["out"]) for _ in range(2)]
-            for phase in range(2):
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for i in range(nleg * 3 if phase else 9):
-                    with torch.cuda.stream(pstreams[i % 3]):
-                        pipes[i % 3].mBackBuffer = pouts[i % 3]
-                        pipes[i % 3].Draw(row0, rows)
-                torch.cuda.synchronize()
-                t_thr = (time.perf_counter() - t1) / (nleg * 3) * 1e3
-            if not (torch.equal(pouts[0], pouts[1]) and torch.equal(pouts[0], pouts[2])):
-                raise SystemExit("bench.py: the frame pipelines disagree")      # same inputs, same kernels: must be the same bytes
-            legs["throughput_3_in_flight"] = dict(leg(t_thr, W * H), note="three pipelines on three streams, each with private copies of all input planes")
-            del pipes, pouts
-        # (b) the evidently intended PCF: 2.5-texel rotated Poisson disc, 16 distinct taps per cascade (Common.hlsl:305 with float division)
+        nleg = max(50, min(args.steps, 100))      # the legs are measurements in their own right: >= 50 frames whatever --steps is
+        # (b, first) the evidently intended PCF: 2.5-texel rotated Poisson disc, 16 distinct taps per cascade (Common.hlsl:305 with float division)
         if args.pcf == "literal":
             a2 = new_app(radius=lib.crychic_pcf_search_radius(args.shadow_dim, 0))
             a2.mBackBuffer = torch.zeros_like(planes["out"])
@@ -730,7 +735,7 @@ def main():
             a2.set_profiling(False)
             legs["pcf_intended"] = dict(leg(wall, W * H), frame_ms_median_hipevent=round(med, 4), light_ms=round(lt, 4))
             del a2
-        # (c) a camera pitched down until every pixel is covered: no sky, every G-buffer texel is read
+        # (c, second) a camera pitched down until every pixel is covered: no sky, every G-buffer texel is read
         if args.camera == "reference":
             args.camera = "covered"
             cplanes = scene.make_scene(W, H, shadow_dim=args.shadow_dim, cube_dim=args.cube_dim, device=str(dev),
@@ -752,18 +757,25 @@ def main():
                                           pass_ms={k: round(v, 4) for k, v in acc3.items()},
                                           light_hbm_frac=round(52.5 * W * H / (acc3["light_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4))
             del a3, cplanes
-
-    # ---- per-pass timing of the same workload (HIP events recorded by the library on the launch stream) ----
-    app.set_profiling(True)
-    app.mBackBuffer = planes["out"]
-    acc = {"ssao_ms": 0.0, "blur_ms": 0.0, "light_ms": 0.0, "total_ms": 0.0}
-    nprof = max(5, min(50, args.steps))
-    for _ in range(nprof):
-        app.Draw(row0, rows)
-        t = app.last_pass_times()
-        for k in acc:
-            acc[k] += t[k] / nprof
-    app.set_profiling(False)
+        # (a) throughput: three frames in flight on three streams, every pipeline on its own copy of every input plane (last: it
+        # leaves three streams' worth of work behind, and the one-at-a-time legs should not start in its wake)
+        if nflight == 1:
+            pipes = [app] + [new_app(own_inputs=True) for _ in range(2)]
+            pstreams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(device=dev) for _ in range(2)]
+            pouts = [planes["out"]] + [torch.zeros_like(planes["out"]) for _ in range(2)]
+            for phase in range(2):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(nleg * 3 if phase else 9):
+                    with torch.cuda.stream(pstreams[i % 3]):
+                        pipes[i % 3].mBackBuffer = pouts[i % 3]
+                        pipes[i % 3].Draw(row0, rows)
+                torch.cuda.synchronize()
+                t_thr = (time.perf_counter() - t1) / (nleg * 3) * 1e3
+            if not (torch.equal(pouts[0], pouts[1]) and torch.equal(pouts[0], pouts[2])):
+                raise SystemExit("bench.py: the frame pipelines disagree")      # same inputs, same kernels: must be the same bytes
+            legs["throughput_3_in_flight"] = dict(leg(t_thr, W * H), note="three pipelines on three streams, each with private copies of all input planes")
+            del pipes, pouts
 
     producer_ms = None
     if rank == 0 and not args.no_producers:
@@ -785,16 +797,19 @@ def main():
             row = {"kernel": name, "ms": round(ms, 4), "algorithmic_MB": round(alg / 1e6, 1),
                    "achieved_GBs": round(alg / (ms * 1e-3) / 1e9, 1) if ms > 0 else None,
                    "hbm_frac": round(alg / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None}
+            if ms > 0 and alg / (ms * 1e-3) / 1e9 > HBM_PEAK_GBS:
+                row["note"] = "hbm_frac > 1: algorithmic bytes (SURVEY 8d), not bytes moved -- the exits skip most of them; see hbm_frac_by_traffic"
             c = (pmc or {}).get(pmc_key)
             if c:
                 row.update({"traffic_MB": round(c["hbm_bytes_per_launch"] / 1e6, 1),
+                            "hbm_frac_by_traffic": round(c["hbm_bytes_per_launch"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms > 0 else None,
                             "traffic_over_algorithmic": round(c["hbm_bytes_per_launch"] / alg, 3),
                             "valu_issue_frac": c.get("valu_issue_frac"), "l2_read_GBs": c.get("l2_read_GBs"),
                             "bound": c.get("bound")})
             return row
 
         kernels = [kernel_row("SSAO pass (depth_pairs_kernel + ssao_kernel)", acc["ssao_ms"], 6.5, "ssao"),
-                   kernel_row("blur, %d sweeps (blur_pair_kernel + blur_replay_fused_kernel)" % (2 * bc), acc["blur_ms"], 7.0 * 2 * bc, "blur"),
+                   kernel_row("blur, %d sweeps (blur_pair_kernel + %d x blur_replay_kernel)" % (2 * bc, max(bc - 1, 0)), acc["blur_ms"], 7.0 * 2 * bc, "blur"),
                    kernel_row("light_kernel", acc["light_ms"], 52.5, "light")]
         traffic = None
         if pmc and all(k in pmc for k in ("ssao", "blur", "light")):
@@ -820,9 +835,9 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic" if not args.plan_rehearsal else "synthetic (PLAN REHEARSAL: all ranks on one GPU, no exchange -- not a measurement)",
-            "config": {"workload": "BASELINE configs[2]: %dx%d, box+grid scene, %d dir lights, 14-tap SSAO + %d-pass bilateral "
+            "config": {"workload": "%s: %dx%d, box+grid scene, %d dir lights, 14-tap SSAO + %d-pass bilateral "
                                    "blur + cascade PCF (%s radius), 4x%d^2 D24 shadow maps%s" % (
-                                       W, H, args.lights, args.blur_count, args.pcf, args.shadow_dim,
+                                       baseline_config_label(W, H, args, world), W, H, args.lights, args.blur_count, args.pcf, args.shadow_dim,
                                        "" if args.camera == "reference" else ", camera pitched down (no sky)"),
                        "launcher": os.environ.get("CRYCHIC_BENCH_LAUNCHER", "external (torch.distributed.run)" if world > 1 else "direct"),
                        "sharding": ("%s row strips x%d" % (args.partition, world)) if world > 1 else "single GPU",

@@ -83,7 +83,8 @@ public:
             mRenderTargetWidth, mRenderTargetHeight, blurCount, 0, mRenderTargetHeight / 2, cmdList->Stream()));
     }
 
-    // false (default): ComputeSsao is one crychic_ssao_compute call (SSAO pass + two blur launches: record, fused replay, exits);
+    // false (default): ComputeSsao is one crychic_ssao_compute call (depth pass + SSAO pass + one blur launch per iteration: blur_pair_kernel records
+    // iteration 0, blur_replay_kernel replays iterations 1 .. blurCount - 1; exits as in DESIGN.md 4);
     // true: the reference's literal sequence of one SSAO pass and 2 * blurCount single sweeps.  Same bits either way
     // (tests/cpp/veneer_driver.cpp renders both).
     bool mLiteralSequence = false;

@@ -266,7 +266,10 @@ def test_dark_light_skip_on_device(ctx, built_lib, oracle, seed):
     """The device twin of tests/test_hostsim_parity.py::test_dark_light_skip_is_exact: a zero-strength directional light is
     skipped, and the other lights take the shorter reciprocals, only on wavefronts whose every pixel is inside the input bounds
     (light_core.hpp "dark lights").  G-buffer values on both sides of every bound, in runs of whole wavefronts and pixel by
-    pixel; device == oracle (RGBA8 and radiance bits)."""
+    pixel; device == oracle: RGBA8 byte for byte; radiance by bits on every lane that is not NaN, and NaN lanes as NaN == NaN
+    (x86 and gfx950 generate NaNs of different sign / payload, 0xFFC00000 against 0x7FC00000; fuzz_util.same_floats).
+    The guard bounds the G-buffer, not EyePosW -- the shortcuts stay exact for any eye because every dot product with the view
+    vector goes through maxnn(): the last cases run a huge, an infinite and a NaN eye position against the oracle."""
     import copy
     import fuzz_util
     W, H = 256, 64
@@ -295,17 +298,22 @@ def test_dark_light_skip_on_device(ctx, built_lib, oracle, seed):
     dg0, dg1, dg2, dd, da = t(g0), t(g1), t(g2), t(depth), torch.from_numpy(amb.view(np.int16)).to(dev)
     out = torch.zeros((H, W, 4), dtype=torch.uint8, device=dev); rad = torch.zeros((H, W, 4), dtype=torch.float32, device=dev)
     cb = copy.deepcopy(c.consts.pass_cb)
-    for d, strength in (((0.0, -0.707, -0.707), (0.0, 0.0, 0.0)), ((0.0, -1.0004, 0.0), (-0.0, 0.0, -0.0)), ((0.0, -1.01, 0.0), (0.0, 0.0, 0.0)),
-                        ((0.0, -0.707, -0.707), (0.0, 1e-30, 0.0))):
+    eye0 = tuple(cb.EyePosW)
+    for d, strength, eye in (((0.0, -0.707, -0.707), (0.0, 0.0, 0.0), eye0), ((0.0, -1.0004, 0.0), (-0.0, 0.0, -0.0), eye0),
+                             ((0.0, -1.01, 0.0), (0.0, 0.0, 0.0), eye0), ((0.0, -0.707, -0.707), (0.0, 1e-30, 0.0), eye0),
+                             ((0.0, -0.707, -0.707), (0.0, 0.0, 0.0), (3.0e30, 2.0, -1.0e25)),
+                             ((0.0, -0.707, -0.707), (0.0, 0.0, 0.0), (float("inf"), 2.0, -15.0)),
+                             ((0.0, -0.707, -0.707), (0.0, 0.0, 0.0), (0.0, float("nan"), -15.0))):
         cb.Lights[2].Direction[:] = d
         cb.Lights[2].Strength[:] = strength
+        cb.EyePosW[:] = eye
         ocb = oracle_lib.as_oracle_cb(cb, oracle_lib.OrPassConstants)
         check(lib.crychic_deferred_light(ctx.handle, C.byref(cb), ptr(dg0), ptr(dg1), ptr(dg2), ptr(dd), ptr(da), c.shadow_ptrs, c.np["shadow"].shape[1],
                                          ptr(c.dev["cube"]), c.np["cube"].shape[1], ptr(out), ptr(rad), W, H, 0, H, 3, 0.0, 0, stream(ctx)))
         torch.cuda.synchronize()
         ref, rref = oracle.deferred_light(ocb, g0, g1, g2, depth, amb, c.np["shadow"], c.np["cube"], 3, 0.0, want_radiance=True)
-        assert np.array_equal(out.cpu().numpy(), ref), (d, strength)
-        assert fuzz_util.same_floats(rad.cpu().numpy(), rref), (d, strength)       # x86 and gfx950 differ in the payload of generated NaNs
+        assert np.array_equal(out.cpu().numpy(), ref), (d, strength, eye)
+        assert fuzz_util.same_floats(rad.cpu().numpy(), rref), (d, strength, eye)       # non-NaN lanes by bits, NaN == NaN
 
 
 @pytest.mark.parametrize("fixes,literal", [(0x100, 1), (0x200, 1), (0x400, 1), (0x700, 0)])

@@ -318,6 +318,17 @@ def test_dark_light_skip_is_exact(built_lib, oracle, hostsim, seed):
             got, rgot = hostsim.light(cb, g0, g1, g2, depth, amb, p["shadow"], p["cube"], 3, 0.0, want_radiance=True)
             assert np.array_equal(got, ref), (d, strength, int((got != ref).sum()))
             assert np.array_equal(rgot.view(np.uint32), rref.view(np.uint32)), (d, strength)
+    # the guard bounds the G-buffer, not the eye: a huge, an infinite and a NaN EyePosW (the view vector's dot products all pass
+    # through maxnn(), which is what keeps the skip and the short reciprocals exact there)
+    cb.Lights[2].Direction[:] = dirs[0]
+    cb.Lights[2].Strength[:] = (0.0, 0.0, 0.0)
+    for eye in ((3.0e30, 2.0, -1.0e25), (np.inf, 2.0, -15.0), (0.0, np.nan, -15.0)):
+        cb.EyePosW[:] = eye
+        ocb = oracle_lib.as_oracle_cb(cb, oracle_lib.OrPassConstants)
+        ref, rref = oracle.deferred_light(ocb, g0, g1, g2, depth, amb, p["shadow"], p["cube"], 3, 0.0, want_radiance=True)
+        got, rgot = hostsim.light(cb, g0, g1, g2, depth, amb, p["shadow"], p["cube"], 3, 0.0, want_radiance=True)
+        assert np.array_equal(got, ref), (eye, int((got != ref).sum()))
+        assert np.array_equal(rgot.view(np.uint32), rref.view(np.uint32)), eye
 
 
 @pytest.mark.parametrize("margin", [0, 8, 40])
