@@ -290,7 +290,7 @@ def kernel_source_hash():
     """Identifies the hot-path kernels a committed counter profile was taken on: sha256 over their sources + the build flags."""
     from crychic_renderer_amd import build
     h = hashlib.sha256()
-    for name in ("blur_tiles.hpp", "devmath.hpp", "kernels.hip", "kernels.hpp", "light_core.hpp", "ssao_core.hpp"):
+    for name in ("blur_tiles.hpp", "devmath.hpp", "gamma_pow.inc", "kernels.hip", "kernels.hpp", "light_core.hpp", "ssao_core.hpp"):
         with open(os.path.join(build.CSRC, name), "rb") as f:
             h.update(name.encode() + b"\0" + f.read())
     h.update(" ".join(build.FLAGS).encode())

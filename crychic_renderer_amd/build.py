@@ -14,7 +14,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libcrychic_hip.so")
 SOURCES = ["kernels.hip", "raster.hip", "api.cpp", "comm.cpp", "host_constants.cpp", "host_geometry.cpp", "host_textures.cpp"]
-HEADERS = ["devmath.hpp", "ssao_core.hpp", "blur_tiles.hpp", "light_core.hpp", "raster_core.hpp", "kernels.hpp", "internal.hpp"]
+HEADERS = ["devmath.hpp", "gamma_pow.inc", "ssao_core.hpp", "blur_tiles.hpp", "light_core.hpp", "raster_core.hpp", "kernels.hpp", "internal.hpp"]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-shared", "--offload-arch=gfx950", "-ffp-contract=off", "-fno-fast-math",
          # the SLP vectoriser packs scalar fp32 pairs into v_pk_* plus the v_mov that pairs their registers: measured 5 % slower
          # lighting / blur (profiles/r01_e_relaxed_math_probe.json); the SSAO tap loop is packed by hand where it pays

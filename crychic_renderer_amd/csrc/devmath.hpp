@@ -253,8 +253,6 @@ CRY_HD float det_pow(float x, float y)
     return normal ? r : ((x >= 0.0f) ? 0.0f : u2f(0x7FC00000u));
 }
 
-// det_pow for two values at once (the red and green channel of the tone map): the bit manipulation and the seeds are per
-// lane, the polynomial steps packed; each lane is bit-identical to det_pow.
 CRY_HD v2f rcp_normal2(v2f b)
 {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -264,23 +262,42 @@ CRY_HD v2f rcp_normal2(v2f b)
     return v2f{ rcp_normal(b.x), rcp_normal(b.y) };
 #endif
 }
-CRY_HD v2f det_pow2(v2f x, float y)
+
+// ---- the tone map's pow(x, 1 / 2.2)  (DeferredShading.hlsl:89-90) -----------------------------------------------------------
+// Oracle definition, version 3: with x = m 2^(E-127), m in [1, 2) read off the bit pattern,
+//     pow(x, 1/2.2) := SCALE[E] * P(m - 1),
+// SCALE[E] = RN(2^((E-127)/2.2)) from a 256-entry table indexed by the biased exponent field, P the degree-7 minimax
+// polynomial of (1 + u)^(1/2.2) on [0, 1) in Horner form, one mad per step (constants: gamma_pow.inc, generated by
+// tools/gen_gamma_pow.py; <= 3e-7 relative, tests/test_oracle_kat.py).  SCALE[0] = 0: zero and subnormal bases of either sign
+// give 0 (D3D flushes denormals); SCALE[255] = inf: pow(+inf) = inf; a negative normal base or NaN gives NaN.
+// Round 1-3 evaluated exp2(y * log2 x) with two range reductions, a reciprocal and nine mads per value (det_pow above, still the
+// definition of the general pow): 35 instructions per channel against 15 + one 4-byte load from a 1 KB table here.
+#include "gamma_pow.inc"
+static constexpr float kGammaPowCoef[8] = CRY_GAMMA_POW_COEFFS;
+static constexpr float kGammaPowScale[256] = CRY_GAMMA_POW_SCALE;
+CRY_HD float pow_inv_gamma(float x)
 {
-    const bool n0 = x.x >= 1.17549435e-38f, n1 = x.y >= 1.17549435e-38f;
-    const uint32_t u0 = f2u(n0 ? x.x : 1.0f) - 0x3F3504F3u, u1 = f2u(n1 ? x.y : 1.0f) - 0x3F3504F3u;
-    const v2f ef{ (float)((int32_t)u0 >> 23), (float)((int32_t)u1 >> 23) };
-    const v2f m{ u2f((u0 & 0x007FFFFFu) + 0x3F3504F3u), u2f((u1 & 0x007FFFFFu) + 0x3F3504F3u) };
-    const v2f s = (m - 1.0f) * rcp_normal2(m + 1.0f);
-    const v2f s2 = s * s;
-    const v2f p = fma2(fma2(fma2(splat(0.43174004554748535f), s2, splat(0.5767142176628113f)), s2, splat(0.9617988467216492f)), s2, splat(2.885390043258667f));
-    const v2f z = y * fma2(s, p, ef);
-    const v2f zc{ clampf(z.x, -125.0f, 127.0f), clampf(z.y, -125.0f, 127.0f) };
-    const v2f n{ __builtin_rintf(zc.x), __builtin_rintf(zc.y) };
-    const v2f f = zc - n;
-    const v2f q = fma2(fma2(fma2(fma2(fma2(fma2(splat(0.00015406982856802642f), f, splat(0.0013400138122960925f)), f, splat(0.009618260897696018f)), f,
-                                           splat(0.05550328269600868f)), f, splat(0.24022649228572845f)), f, splat(0.6931471824645996f)), f, splat(1.0f));
-    const float r0 = __builtin_ldexpf(q.x, (int)n.x), r1 = __builtin_ldexpf(q.y, (int)n.y);
-    return v2f{ n0 ? r0 : ((x.x >= 0.0f) ? 0.0f : u2f(0x7FC00000u)), n1 ? r1 : ((x.y >= 0.0f) ? 0.0f : u2f(0x7FC00000u)) };
+    const uint32_t b = f2u(x);
+    const float scale = kGammaPowScale[(b >> 23) & 255u];
+    const float u = u2f((b & 0x007FFFFFu) | 0x3F800000u) - 1.0f;       // exact
+    float p = kGammaPowCoef[7];
+#pragma unroll
+    for (int k = 6; k >= 0; --k) p = fma(p, u, kGammaPowCoef[k]);
+    const float r = scale * p;
+    return (x > -1.17549435e-38f) ? r : u2f(0x7FC00000u);              // false for negative normals and NaN
+}
+// two values at once (the red and green channel): bit manipulation and table lookups per lane, the polynomial packed; each lane
+// is bit-identical to pow_inv_gamma
+CRY_HD v2f pow_inv_gamma2(v2f x)
+{
+    const uint32_t b0 = f2u(x.x), b1 = f2u(x.y);
+    const v2f scale{ kGammaPowScale[(b0 >> 23) & 255u], kGammaPowScale[(b1 >> 23) & 255u] };
+    const v2f u = v2f{ u2f((b0 & 0x007FFFFFu) | 0x3F800000u), u2f((b1 & 0x007FFFFFu) | 0x3F800000u) } - 1.0f;
+    v2f p = splat(kGammaPowCoef[7]);
+#pragma unroll
+    for (int k = 6; k >= 0; --k) p = fma2(p, u, splat(kGammaPowCoef[k]));
+    const v2f r = scale * p;
+    return v2f{ (x.x > -1.17549435e-38f) ? r.x : u2f(0x7FC00000u), (x.y > -1.17549435e-38f) ? r.y : u2f(0x7FC00000u) };
 }
 
 // ---- bilinear addressing --------------------------------------------------------------

@@ -562,11 +562,10 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
     }
     pointLights(posW, albedo, roughness, metalness, normalW, view, direct, fixQ3, fixQ4);   // extension; a no-op in the reference configuration
 
-    const float invGamma = 1.0f / 2.2f;
     f4 lit;
     const v2f d2{ direct.x, direct.y };
-    const v2f tm = det_pow2(d2 * rcp2(d2 + 1.0f), invGamma) + v2f{ amb.x, amb.y };     // :89-92, red and green packed
-    lit.z = det_pow(divf(direct.z, direct.z + 1.0f), invGamma) + amb.z;
+    const v2f tm = pow_inv_gamma2(d2 * rcp2(d2 + 1.0f)) + v2f{ amb.x, amb.y };     // :89-92 pow(x / (x + 1), 1 / 2.2), red and green packed
+    lit.z = pow_inv_gamma(divf(direct.z, direct.z + 1.0f)) + amb.z;
 
     const f4 refl = cube_resolve<false>(cf);
     const float f0 = 1.0f - saturate(dot3(normalW, r));         // LightingUtil.hlsl:54-57

@@ -234,7 +234,7 @@ static void light_pixel(const or_pass_constants* cb, const float* g0, const floa
         pbr_point_light(&pointLights[i], posW, albedo, roughness, metalness, normalW, view, flags, direct);
     for (int c = 0; c < 3; ++c) {
         float d = or_div(direct[c], direct[c] + 1.0f);                /* :89 */
-        d = or_det_powf_(d, 1.0f / 2.2f);                             /* :90 */
+        d = or_pow_inv_gamma(d);                                      /* :90  pow(d, 1 / 2.2) */
         lit[c] = d + amb[c];                                          /* :92 */
     }
     /* w: directLight.w = 0 -> 0/(0+1) = 0 -> pow(0, 1/2.2) = 0 -> + ambient.a; then :99 overwrites with 1 */
@@ -321,7 +321,7 @@ float or_det_powf(float x, float y) { return or_det_powf_(x, y); }
 
 /* Batch evaluation of the scalar definitions (unit tests compare them with the product's device math compiled
  * for the host).  kind: 0 sin, 1 cos, 2 log2, 3 exp2, 4 pow(in, in2), 5 nrand(in, in2), 6 d24 decode (in = bits),
- * 7 unorm16 decode, 8 unorm8 decode, 9 half decode. */
+ * 7 unorm16 decode, 8 unorm8 decode, 9 half decode, 10 pow(in, 1/2.2) of the tone map. */
 void or_eval_array(int kind, size_t n, const float* in, const float* in2, float* out)
 {
     const uint32_t* bits = (const uint32_t*)in;
@@ -337,6 +337,7 @@ void or_eval_array(int kind, size_t n, const float* in, const float* in2, float*
         case 7: out[i] = or_unorm16((uint16_t)bits[i]); break;
         case 8: out[i] = or_unorm8((uint8_t)bits[i]); break;
         case 9: out[i] = or_half_bits_to_float((uint16_t)bits[i]); break;
+        case 10: out[i] = or_pow_inv_gamma(in[i]); break;
         default: out[i] = 0.0f;
         }
     }

@@ -11,7 +11,8 @@
  *                   tools/exact_math_probe.hip, tests/test_gpu_exact_math.py);
  *   - length(v)  := sqrtf(clamp(dot(v,v), 2^-100, 2^100)), normalize(v) := v * (1 / length): IEEE sqrt and division on
  *                   an argument clamped to a range where neither can meet a subnormal (NaN -> 2^-100);
- *   - pow(x, y)  := the fixed exp2(y * log2(x)) kernels below; sin / cos: fixed Cody-Waite + polynomial kernels.
+ *   - pow(x, y)  := the fixed exp2(y * log2(x)) kernels below; sin / cos: fixed Cody-Waite + polynomial kernels;
+ *   - pow(x, 1/2.2), the tone map's only pow (DeferredShading.hlsl:90), := SCALE[E] * P(m - 1) (or_pow_inv_gamma below, version 3).
  *
  * Version 1 (round 1) used unfused chains and IEEE division everywhere; version 2 exists because those choices cost the
  * GPU kernels ~40 % of their instruction issue without being any closer to what a D3D12 driver computes.  DESIGN.md
@@ -27,7 +28,8 @@
  *     the vertex shaders, the normal map is cleared to (0,0,1,0), CRYCHIC.cpp:2526; the G-buffer is lit only under covered
  *     pixels), reachable through the C ABI with hand-made planes.  tests/test_numpy_restatements.py::
  *     test_zero_normal_is_a_definition shows the two behaviours side by side.
- *   - pow(x, y) outside x > 0 (or_pow: x = 0 or subnormal -> 0, x < 0 or NaN -> NaN).  HLSL pow(x, y) = exp2(y * log2(x)) gives
+ *   - pow(x, y) outside x > 0 (or_pow: x = 0 or subnormal -> 0, x < 0 or NaN -> NaN; or_pow_inv_gamma: +-0 and subnormals of
+ *     either sign -> 0, as D3D's denormal flush gives, negative normals and NaN -> NaN).  HLSL pow(x, y) = exp2(y * log2(x)) gives
  *     NaN for x < 0 as well, 0 for x = 0 and is unspecified on subnormals; the only call with a computed base is the tone map
  *     pow(direct / (direct + 1), 1 / 2.2) (DeferredShading.hlsl:89-90), whose base is >= 0 unless an input is negative or NaN.
  * Both are shared bit for bit by the kernels (csrc/devmath.hpp) and pinned by the fuzz tests (tests/test_fuzz.py: zero, NaN and
@@ -179,6 +181,22 @@ static inline float or_det_powf_(float x, float y)
     if (!(x >= 1.17549435e-38f)) return 0.0f;
     float z = y * or_det_log2_normal(x);
     return or_det_exp2_clamped(fminf(fmaxf(z, -125.0f), 127.0f));
+}
+
+/* pow(x, 1/2.2), the tone map (DeferredShading.hlsl:89-90): x = m * 2^(E-127), m in [1, 2) read off the bit pattern;
+ * SCALE[E] = RN(2^((E-127)/2.2)) (table over the biased exponent field; [0] = 0, [255] = +inf), P = degree-7 minimax of
+ * (1 + u)^(1/2.2) on [0, 1), Horner, one mad per step.  Constants: or_gamma_pow.inc (tools/gen_gamma_pow.py).  <= 3e-7 relative. */
+#include "or_gamma_pow.inc"
+static inline float or_pow_inv_gamma(float x)
+{
+    static const float coef[8] = CRY_GAMMA_POW_COEFFS;
+    static const float scale[256] = CRY_GAMMA_POW_SCALE;
+    if (!(x > -1.17549435e-38f)) return or_bits_to_float(0x7FC00000u);      /* negative normal, NaN */
+    uint32_t b = or_float_to_bits(x);
+    float u = or_bits_to_float((b & 0x007FFFFFu) | 0x3F800000u) - 1.0f;
+    float p = coef[7];
+    for (int k = 6; k >= 0; --k) p = fmaf(p, u, coef[k]);
+    return scale[(b >> 23) & 255u] * p;
 }
 
 #endif

@@ -49,7 +49,8 @@ uint32_t hs_check_d24_threshold(void)
     return bad;
 }
 
-// kind: 0 sin, 1 cos, 2 log2, 3 exp2, 4 pow, 5 nrand, 6 d24, 7 unorm16, 8 unorm8, 9 half (same numbering as or_eval_array)
+// kind: 0 sin, 1 cos, 2 log2, 3 exp2, 4 pow, 5 nrand, 6 d24, 7 unorm16, 8 unorm8, 9 half, 10 pow(., 1/2.2) (same numbering as or_eval_array);
+// 11: pow(., 1/2.2) through the packed form
 void hs_eval_array(int kind, size_t n, const float* in, const float* in2, float* out)
 {
     const uint32_t* bits = (const uint32_t*)in;
@@ -65,6 +66,8 @@ void hs_eval_array(int kind, size_t n, const float* in, const float* in2, float*
         case 7: out[i] = unorm16_to_float(bits[i]); break;
         case 8: out[i] = unorm8_to_float(bits[i]); break;
         case 9: out[i] = half_to_float((uint16_t)bits[i]); break;
+        case 10: out[i] = pow_inv_gamma(in[i]); break;
+        case 11: out[i] = pow_inv_gamma2(v2f{ in2[i], in[i] }).y; break;      // the packed form's second lane
         default: out[i] = 0.0f;
         }
     }

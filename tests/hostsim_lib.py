@@ -32,7 +32,7 @@ def build_sanitized(name, sources, extra=()):
 def build():
     if SANITIZE:
         return build_sanitized("libhostsim.so", [SRC])
-    deps = [SRC] + [os.path.join(CSRC, f) for f in ("devmath.hpp", "ssao_core.hpp", "blur_tiles.hpp", "light_core.hpp", "raster_core.hpp")]
+    deps = [SRC] + [os.path.join(CSRC, f) for f in ("devmath.hpp", "gamma_pow.inc", "ssao_core.hpp", "blur_tiles.hpp", "light_core.hpp", "raster_core.hpp")]
     if not os.path.exists(LIB) or any(os.path.getmtime(d) > os.path.getmtime(LIB) for d in deps):
         subprocess.run([CLANG, "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-fno-fast-math", "-mfma",
                         "-I", os.path.join(ROOT, "include"), "-I", CSRC, SRC, "-o", LIB], check=True)

@@ -29,6 +29,11 @@ def test_unorm16_unorm8_half_exhaustive(hostsim, oracle):
     assert np.array_equal(bits(hostsim.eval_array(9, x.view(np.float32))), bits(oracle.eval_array(9, x.view(np.float32))))
 
 
+def same_bits_or_nan(a, b):
+    an, bn = np.isnan(a), np.isnan(b)
+    return bool(np.array_equal(an, bn) and np.array_equal(bits(a)[~an], bits(b)[~bn]))
+
+
 def test_transcendentals_bit_identical(hostsim, oracle):
     rng = np.random.default_rng(1)
     xs = np.concatenate([rng.uniform(-400, 400, 300000), rng.uniform(-1, 1, 100000), rng.normal(0, 1e5, 50000),
@@ -40,6 +45,11 @@ def test_transcendentals_bit_identical(hostsim, oracle):
     base = np.concatenate([rng.uniform(0, 1, 300000), rng.uniform(0, 50, 50000), [0.0, 1.0, np.nan, -0.5, np.inf]]).astype(np.float32)
     expo = np.full_like(base, np.float32(1.0 / 2.2))
     assert np.array_equal(bits(hostsim.eval_array(4, base, expo)), bits(oracle.eval_array(4, base, expo)))
+    # the tone map's pow(x, 1/2.2): scalar and packed forms of the kernels against the oracle, every exponent, both signs, specials
+    allx = np.concatenate([base, np.exp(rng.uniform(-104, 88, 300000)), -np.exp(rng.uniform(-104, 88, 20000)),
+                           [-0.0, 1e-45, -1e-45, 1e-38, -1e-38, 1.17549435e-38, -1.17549435e-38, -np.inf, 3.4028234e38]]).astype(np.float32)
+    assert same_bits_or_nan(hostsim.eval_array(10, allx), oracle.eval_array(10, allx))
+    assert same_bits_or_nan(hostsim.eval_array(11, allx, np.roll(allx, 7)), oracle.eval_array(10, allx))
     u = rng.uniform(-2, 3, 200000).astype(np.float32); v = rng.uniform(-2, 3, 200000).astype(np.float32)
     assert np.array_equal(bits(hostsim.eval_array(5, u, v)), bits(oracle.eval_array(5, u, v)))
 

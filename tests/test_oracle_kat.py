@@ -86,6 +86,29 @@ def test_detmath_accuracy(oracle):
     assert oracle.lib.or_det_powf(0.0, 0.4545) == 0.0
 
 
+def test_pow_inv_gamma_definition(oracle):
+    """The tone map's pow(x, 1/2.2) (DeferredShading.hlsl:90; oracle definition version 3, or_math.h or_pow_inv_gamma): table over
+    the exponent field x degree-7 polynomial over the mantissa.  Real x^(1/2.2) to 3e-7 relative over the whole normal range, the
+    stated special values, monotone, and both generated constant files are what tools/gen_gamma_pow.py prints."""
+    import subprocess, sys, os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.run([sys.executable, os.path.join(root, "tools", "gen_gamma_pow.py"), "--check"], check=True)
+    rng = np.random.default_rng(3)
+    x = np.concatenate([np.linspace(0.0, 1.0, 200001), np.exp(rng.uniform(-87.0, 88.0, 200000)), [1.0, 2.0, 0.5, 1.17549435e-38, 3.4028234e38]]).astype(np.float32)
+    g = oracle.eval_array(10, x).astype(np.float64)
+    ref = x.astype(np.float64) ** (1.0 / 2.2)
+    nz = x >= np.float32(1.17549435e-38)
+    assert np.max(np.abs(g[nz] / ref[nz] - 1.0)) < 3e-7
+    assert np.all(g[~nz] == 0.0)                                            # zero and subnormals -> 0
+    xs = np.sort(x[:200001]); gs = oracle.eval_array(10, xs)
+    assert np.all(np.diff(gs) >= 0.0)                                        # monotone on [0, 1]
+    special = np.array([0.0, -0.0, 1e-40, -1e-40, np.inf, 1.0], dtype=np.float32)
+    gsp = oracle.eval_array(10, special)
+    assert np.array_equal(gsp[:4], np.zeros(4, np.float32)) and gsp[4] == np.inf and gsp[5] == 1.0
+    bad = np.array([-1.0, -1.17549435e-38, -np.inf, np.nan], dtype=np.float32)
+    assert np.all(np.isnan(oracle.eval_array(10, bad)))
+
+
 def test_half_decode(oracle):
     bits = np.arange(65536, dtype=np.uint32)
     got = oracle.eval_array(9, bits.view(np.float32))
