@@ -143,6 +143,7 @@ int fill_light_params(cry::LightParams& P, const crychic_pass_constants* cb, con
     P.unitLights = cry::light_dark_lengths_ok(P.Lights, numDirLights) ? 1u : 0u;
     P.rcpW = cry::rcp((float)W);          // sky_pixel's pixel-centre uv: (x + 0.5) * rcp(W), the reciprocal taken once
     P.rcpH = cry::rcp((float)H);
+    cry::light_params_derive(P);
     return 0;
 }
 

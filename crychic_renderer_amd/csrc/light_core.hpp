@@ -29,7 +29,22 @@ struct LightParams {
     uint32_t darkLights;       // light_dark_mask(): bit i = directional light i has Strength (0, 0, 0) and a sane direction
     float rcpW, rcpH;          // rcp((float)W), rcp((float)H)
     uint32_t unitLights;       // light_dark_lengths_ok(): every directional light in use has a finite direction no longer than 1.001
+    // Interleaved copies of rows the kernels evaluate two at a time in packed fp32 (wave-uniform operands have to be adjacent
+    // scalar registers for v_pk_fma_f32): ShadowPairs[J][k] = { ShadowTransforms[J][k], ShadowTransforms[J + 1][k] } for the x, y
+    // and z rows (k < 12) of cascades J and J + 1, which every pixel nearer than 80 blends (cascade_fetch_uniform);
+    // ScreenPairs[k] = { ViewProjTex[k], ViewProjTex[4 + k] }, the x and y rows of the projection to the ambient map.
+    float ShadowPairs[3][12][2];
+    float ScreenPairs[4][2];
+    float halfDims[2];         // (float)(W / 2), (float)(H / 2)
 };
+CRY_HD void light_params_derive(LightParams& P)
+{
+    for (int J = 0; J < 3; ++J)
+        for (int k = 0; k < 12; ++k) { P.ShadowPairs[J][k][0] = P.ShadowTransforms[J][k]; P.ShadowPairs[J][k][1] = P.ShadowTransforms[J + 1][k]; }
+    for (int k = 0; k < 4; ++k) { P.ScreenPairs[k][0] = P.ViewProjTex[k]; P.ScreenPairs[k][1] = P.ViewProjTex[4 + k]; }
+    P.halfDims[0] = (float)(P.W / 2);
+    P.halfDims[1] = (float)(P.H / 2);
+}
 
 constexpr uint32_t kMaxPointLights = 1024;   // tile masks live in LDS: 32 words
 
@@ -312,27 +327,55 @@ CRY_HD CubeFetch cube_fetch(const uint32_t* __restrict__ cube, uint32_t dim, f3 
     const float rma = rcp(ma);
     const float u = fma(0.5f, sc * rma, 0.5f);      // 0.5 * (sc / ma + 1)
     const float v = fma(0.5f, tc * rma, 0.5f);
-    const Bilin b = bilinear_setup(u, v, dim, dim);
-    const uint32_t y0 = (uint32_t)clampi(b.j0, 0, (int)dim - 1), y1 = (uint32_t)clampi(b.j0 + 1, 0, (int)dim - 1);
     const uint32_t faceRow = mul24(face, dim);   // faces are stacked: row index face*dim + y
     CubeFetch f;
+    // Footprints in the interior of their face (floor(texel coordinate) in [0, dim - 2] on both axes, which a NaN fails), for the
+    // whole wavefront: bilinear_setup's non-finite rule and pair_at_clamped's edge selects cannot act, the rows are two 8-byte
+    // loads at (face * dim + j0) * dim + i0.  A wavefront with a footprint on a face edge takes the general sampler.
+    const float fd = (float)dim;
+    const float tx = fma(u, fd, -0.5f), ty = fma(v, fd, -0.5f);
+    const float flx = __builtin_floorf(tx), fly = __builtin_floorf(ty);
+    bool inside = (flx >= 0.0f) & (flx <= fd - 2.0f) & (fly >= 0.0f) & (fly <= fd - 2.0f);
+#if defined(__HIP_DEVICE_COMPILE__)
+    inside = __builtin_amdgcn_ballot_w64(!inside) == 0;
+#endif
+    if (inside) {
+        const uint32_t t0 = mul24(faceRow + (uint32_t)(int)fly, dim) + (uint32_t)(int)flx;
+        const RawPair r0 = load_pair(cube, t0), r1 = load_pair(cube, t0 + dim);
+        f.p0 = TexelPair{ r0.lo, r0.hi };
+        f.p1 = TexelPair{ r1.lo, r1.hi };
+        f.fx = tx - flx;
+        f.fy = ty - fly;
+        return f;
+    }
+    float us = u, vs = v;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(us), "+v"(vs));      // the general sampler's clamps stay on this side of the vote
+#endif
+    const Bilin b = bilinear_setup(us, vs, dim, dim);
+    const uint32_t y0 = (uint32_t)clampi(b.j0, 0, (int)dim - 1), y1 = (uint32_t)clampi(b.j0 + 1, 0, (int)dim - 1);
     f.p0 = pair_at_clamped(cube, faceRow + y0, dim, b.i0);
     f.p1 = pair_at_clamped(cube, faceRow + y1, dim, b.i0);
     f.fx = b.fx;
     f.fy = b.fy;
     return f;
 }
-// WANT_ALPHA = false (the reflection lookup of a lit pixel, which uses .rgb only): blue as scalars, .w = 0.
+// WANT_ALPHA = false (the reflection lookup of a lit pixel, which uses .rgb only): .w = 0.
+// Every channel is bilerp of the four decoded texels, bit for bit; the work is arranged in packed pairs: red + green of one texel
+// decode together (and blue + alpha), and without alpha the blue channel pairs the two texels of a COLUMN -- {b00, b01} and
+// {b10, b11} -- so that both row filters are one packed lerp.
+CRY_HD v2f unorm8_to_float2(uint32_t a, uint32_t b)
+{
+    const v2f t{ (float)a, (float)b };
+    return fma2(t, splat(u2f(0x3B808081u)), t * u2f(0xAF7EFEFFu));       // unorm_decode per lane
+}
 template <bool WANT_ALPHA = true>
 CRY_HD f4 cube_resolve(const CubeFetch& f)
 {
     const uint32_t t00 = f.p0.a, t10 = f.p0.b, t01 = f.p1.a, t11 = f.p1.b;
-    // red + green (and blue + alpha) as packed pairs: each lane is bilerp of the decoded texels, bit for bit
     auto pair = [&](uint32_t sh) {
-        const v2f a00{ unorm8_to_float((t00 >> sh) & 255u), unorm8_to_float((t00 >> (sh + 8u)) & 255u) };
-        const v2f a10{ unorm8_to_float((t10 >> sh) & 255u), unorm8_to_float((t10 >> (sh + 8u)) & 255u) };
-        const v2f a01{ unorm8_to_float((t01 >> sh) & 255u), unorm8_to_float((t01 >> (sh + 8u)) & 255u) };
-        const v2f a11{ unorm8_to_float((t11 >> sh) & 255u), unorm8_to_float((t11 >> (sh + 8u)) & 255u) };
+        const v2f a00 = unorm8_to_float2((t00 >> sh) & 255u, (t00 >> (sh + 8u)) & 255u), a10 = unorm8_to_float2((t10 >> sh) & 255u, (t10 >> (sh + 8u)) & 255u);
+        const v2f a01 = unorm8_to_float2((t01 >> sh) & 255u, (t01 >> (sh + 8u)) & 255u), a11 = unorm8_to_float2((t11 >> sh) & 255u, (t11 >> (sh + 8u)) & 255u);
         const v2f top = lerp2(a00, a10, splat(f.fx)), bot = lerp2(a01, a11, splat(f.fx));
         return lerp2(top, bot, splat(f.fy));
     };
@@ -341,9 +384,9 @@ CRY_HD f4 cube_resolve(const CubeFetch& f)
         const v2f ba = pair(16u);
         return f4{ rg.x, rg.y, ba.x, ba.y };
     }
-    const float b = bilerp(unorm8_to_float((t00 >> 16) & 255u), unorm8_to_float((t10 >> 16) & 255u), unorm8_to_float((t01 >> 16) & 255u),
-                           unorm8_to_float((t11 >> 16) & 255u), f.fx, f.fy);
-    return f4{ rg.x, rg.y, b, 0.0f };
+    const v2f left = unorm8_to_float2((t00 >> 16) & 255u, (t01 >> 16) & 255u), right = unorm8_to_float2((t10 >> 16) & 255u, (t11 >> 16) & 255u);
+    const v2f rows = lerp2(left, right, splat(f.fx));        // { top, bot }
+    return f4{ rg.x, rg.y, lerpf(rows.x, rows.y, f.fy), 0.0f };
 }
 CRY_HD f4 cube_linear(const uint32_t* __restrict__ cube, uint32_t dim, f3 r) { return cube_resolve(cube_fetch(cube, dim, r)); }
 
@@ -357,6 +400,39 @@ CRY_HD AmbientFetch ambient_fetch(const uint16_t* __restrict__ a, uint32_t w2, u
     const uint32_t r0 = mul24(y0, w2), r1 = mul24(y1, w2);
     return AmbientFetch{ load_at<uint16_t>(a, (r0 + x0) * 2u), load_at<uint16_t>(a, (r0 + x1) * 2u),
                          load_at<uint16_t>(a, (r1 + x0) * 2u), load_at<uint16_t>(a, (r1 + x1) * 2u), b.fx, b.fy };
+}
+// The lighting pass's own lookup (DeferredShading.hlsl:40-42): posW projected by gViewProjTex, x and y as one packed pair
+// (LightParams::ScreenPairs; each lane is mulcol1 / bilinear_setup bit for bit).  When the footprint of every pixel of the wavefront
+// lies inside the map (everything but the frame's rim and non-finite positions: a NaN fails the test) nothing is clamped and the
+// four texels are two 4-byte loads of {t(i0), t(i0 + 1)} (2-byte aligned); otherwise ambient_fetch on the same coordinates.
+// hasAO false: the 1 x 1 stand-in of light_pixel, always the general path.
+CRY_HD AmbientFetch ambient_fetch_projected(const LightParams& P, const uint16_t* __restrict__ a, bool hasAO, const uint16_t* __restrict__ standIn, f3 posW)
+{
+    const v2f c0{ P.ScreenPairs[0][0], P.ScreenPairs[0][1] }, c1{ P.ScreenPairs[1][0], P.ScreenPairs[1][1] };
+    const v2f c2{ P.ScreenPairs[2][0], P.ScreenPairs[2][1] }, c3{ P.ScreenPairs[3][0], P.ScreenPairs[3][1] };
+    const v2f s = fma2(splat(posW.z), c2, fma2(splat(posW.y), c1, splat(posW.x) * c0)) + c3;
+    const float rsw = rcp(mulcol1(posW.x, posW.y, posW.z, P.ViewProjTex + 12));
+    const v2f uv = s * rsw;
+    if (hasAO) {
+        const v2f dims{ P.halfDims[0], P.halfDims[1] };
+        const v2f t = fma2(uv, dims, -0.5f);
+        const v2f fl = floor2(t);
+        bool inside = (fl.x >= 0.0f) & (fl.x <= dims.x - 2.0f) & (fl.y >= 0.0f) & (fl.y <= dims.y - 2.0f);
+#if defined(__HIP_DEVICE_COMPILE__)
+        inside = __builtin_amdgcn_ballot_w64(!inside) == 0;
+#endif
+        if (inside) {
+            const uint32_t w2 = P.W / 2u, idx = mul24((uint32_t)(int)fl.y, w2) + (uint32_t)(int)fl.x;
+            const uint32_t d0 = load_at<uint32_t>(a, idx * 2u), d1 = load_at<uint32_t>(a, (idx + w2) * 2u);
+            const v2f fr = t - fl;
+            return AmbientFetch{ (uint16_t)(d0 & 0xFFFFu), (uint16_t)(d0 >> 16), (uint16_t)(d1 & 0xFFFFu), (uint16_t)(d1 >> 16), fr.x, fr.y };
+        }
+    }
+    float u = uv.x, v = uv.y;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(u), "+v"(v));      // the general sampler's clamps stay on this side of the vote
+#endif
+    return ambient_fetch(hasAO ? a : standIn, hasAO ? P.W / 2 : 1u, hasAO ? P.H / 2 : 1u, u, v);
 }
 CRY_HD float ambient_resolve(const AmbientFetch& f)
 {
@@ -466,9 +542,21 @@ CRY_HD float cascade_shadow(const LightParams& P, f3 posW, float distance, bool 
 // as written), orthographic light projections, the literal zero PCF radius.  The transforms are then wave-uniform (scalar
 // registers) and the footprints of both cascades are fetched together -- one memory round trip where cascade_shadow takes one
 // per lookup.  Same operations per pixel, so the same bits; returns false (nothing done) when the wavefront is not uniform.
-struct CascadePair { ShadowFetch f0, f1; float z0, z1; };
+//
+// Both lookups run as ONE packed evaluation -- lane .x cascade J, lane .y cascade J + 1 (LightParams::ShadowPairs holds the two
+// transforms interleaved): three matrix rows, the sampler's texel coordinates, the D24 decodes and the bilinear filter of the
+// comparison results are v_pk_*_f32, each lane the scalar expression bit for bit (mulcol1, bilinear_setup<true>, d24_to_float,
+// bilerp).  And when both footprints of every pixel of the wavefront lie inside their maps (everything but the rim of a
+// cascade: floor(texel coordinate) in [0, dim - 2] on both axes) nothing is clamped, selected or range-tested: the footprint's
+// rows are two 8-byte loads at (j0 * dim + i0), the BORDER colour cannot occur.  The rim takes shadow_fetch / shadow_resolve on
+// the same coordinates.
+CRY_HD v2f d24_to_float2(uint32_t a, uint32_t b)
+{
+    const v2f t{ (float)(a & 0x00FFFFFFu), (float)(b & 0x00FFFFFFu) };
+    return fma2(t, splat(u2f(0x33800001u)), t * u2f(0xA77FFFFFu));      // unorm_decode per lane
+}
 template <bool ZERO_RADIUS>
-CRY_HD bool cascade_fetch_uniform(const LightParams& P, f3 posW, float distance, bool fixQ1, CascadePair& c)
+CRY_HD bool cascade_shadow_uniform(const LightParams& P, f3 posW, float distance, bool fixQ1, float& shadow)
 {
     if (!ZERO_RADIUS || fixQ1 || !P.shadowWIsOne) return false;
     // |posW| < 1e15 with the transforms' entries below 1e12 (light_shadow_w_is_one): shadowPosH.w == 1, and the shadow
@@ -485,19 +573,54 @@ CRY_HD bool cascade_fetch_uniform(const LightParams& P, f3 posW, float distance,
 #else
     if (!ok) return false;
 #endif
-    const float* T0 = P.ShadowTransforms[J];
-    const float* T1 = P.ShadowTransforms[J + 1];
-    c.f0 = shadow_fetch<true>(P.shadow[J], P.shadowDim, mulcol1(posW.x, posW.y, posW.z, T0 + 0), mulcol1(posW.x, posW.y, posW.z, T0 + 4));
-    c.f1 = shadow_fetch<true>(P.shadow[J + 1], P.shadowDim, mulcol1(posW.x, posW.y, posW.z, T1 + 0), mulcol1(posW.x, posW.y, posW.z, T1 + 4));
-    c.z0 = mulcol1(posW.x, posW.y, posW.z, T0 + 8);
-    c.z1 = mulcol1(posW.x, posW.y, posW.z, T1 + 8);
+    const float (*S)[2] = P.ShadowPairs[J];
+    auto row = [&](int r) {        // mulcol1 of both cascades: fma(z, c2, fma(y, c1, x * c0)) + c3 per lane
+        const v2f c0{ S[4 * r][0], S[4 * r][1] }, c1{ S[4 * r + 1][0], S[4 * r + 1][1] }, c2{ S[4 * r + 2][0], S[4 * r + 2][1] }, c3{ S[4 * r + 3][0], S[4 * r + 3][1] };
+        return fma2(splat(posW.z), c2, fma2(splat(posW.y), c1, splat(posW.x) * c0)) + c3;
+    };
+    const v2f u = row(0), v = row(1), z = row(2);
+    const float fd = (float)P.shadowDim;
+    const v2f tx = fma2(u, fd, -0.5f), ty = fma2(v, fd, -0.5f);      // bilinear_setup<true>
+    const v2f flx = floor2(tx), fly = floor2(ty);
+    const float lo = __builtin_fminf(__builtin_fminf(flx.x, flx.y), __builtin_fminf(fly.x, fly.y));
+    const float hi = __builtin_fmaxf(__builtin_fmaxf(flx.x, flx.y), __builtin_fmaxf(fly.x, fly.y));
+    bool inside = (lo >= 0.0f) & (hi <= fd - 2.0f);                   // all four finite (above)
+#if defined(__HIP_DEVICE_COMPILE__)
+    inside = __builtin_amdgcn_ballot_w64(!inside) == 0;
+#endif
+    float a, b;
+    if (inside) {
+        const uint32_t ta = mul24((uint32_t)(int)fly.x, P.shadowDim) + (uint32_t)(int)flx.x;
+        const uint32_t tb = mul24((uint32_t)(int)fly.y, P.shadowDim) + (uint32_t)(int)flx.y;
+        const RawPair a0 = load_pair(P.shadow[J], ta), a1 = load_pair(P.shadow[J], ta + P.shadowDim);          // rows j0, j0 + 1: texels i0, i0 + 1
+        const RawPair b0 = load_pair(P.shadow[J + 1], tb), b1 = load_pair(P.shadow[J + 1], tb + P.shadowDim);
+        const v2f fx = tx - flx, fy = ty - fly;
+        const v2f one = splat(1.0f), zero = splat(0.0f);
+        const v2f c00 = select2(z <= d24_to_float2(a0.lo, b0.lo), one, zero), c10 = select2(z <= d24_to_float2(a0.hi, b0.hi), one, zero);
+        const v2f c01 = select2(z <= d24_to_float2(a1.lo, b1.lo), one, zero), c11 = select2(z <= d24_to_float2(a1.hi, b1.hi), one, zero);
+        const v2f t = lerp2(lerp2(c00, c10, fx), lerp2(c01, c11, fx), fy);      // bilerp per lane
+        a = t.x;
+        b = t.y;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // pcf_zero_radius, both lookups under one vote: fully lit / fully shadowed footprints come out of the 16 additions unchanged
+        if (__builtin_amdgcn_ballot_w64(!(((a == 0.0f) | (a == 1.0f)) & ((b == 0.0f) | (b == 1.0f)))) == 0) {
+            shadow = 0.5f * (a + b);
+            return true;
+        }
+#endif
+    } else {
+        float ua = u.x, va = v.x, ub = u.y, vb = v.y;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(ua), "+v"(va), "+v"(ub), "+v"(vb));      // keeps the rim's clamps and selects inside this branch (the
+                                                                         // optimiser would otherwise compute them ahead of the vote)
+#endif
+        const ShadowFetch f0 = shadow_fetch<true>(P.shadow[J], P.shadowDim, ua, va);
+        const ShadowFetch f1 = shadow_fetch<true>(P.shadow[J + 1], P.shadowDim, ub, vb);
+        a = shadow_resolve<true>(f0, P.shadowDim, z.x);
+        b = shadow_resolve<true>(f1, P.shadowDim, z.y);
+    }
+    shadow = 0.5f * (pcf_zero_radius(a) + pcf_zero_radius(b));     // :66
     return true;
-}
-CRY_HD float cascade_resolve_uniform(const LightParams& P, const CascadePair& c)
-{
-    const float a = pcf_zero_radius(shadow_resolve<true>(c.f0, P.shadowDim, c.z0));
-    const float b = pcf_zero_radius(shadow_resolve<true>(c.f1, P.shadowDim, c.z1));
-    return 0.5f * (a + b);                                      // :66
 }
 
 // DeferredShading.hlsl:23-101 for one covered pixel.  Every gather of the pixel -- ambient map, cubemap, shadow cascades -- is
@@ -523,19 +646,15 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
     // :40-42; without an ambient map the fetch still runs, on a 1 x 1 stand-in (the cubemap's first bytes), so that no branch
     // separates it from the other gathers
     const bool hasAO = ambient != nullptr;
-    const float sx = mulcol1(posW.x, posW.y, posW.z, P.ViewProjTex + 0);
-    const float sy = mulcol1(posW.x, posW.y, posW.z, P.ViewProjTex + 4);
-    const float rsw = rcp(mulcol1(posW.x, posW.y, posW.z, P.ViewProjTex + 12));
-    const AmbientFetch af = ambient_fetch(hasAO ? ambient : (const uint16_t*)cube, hasAO ? P.W / 2 : 1u, hasAO ? P.H / 2 : 1u, sx * rsw, sy * rsw);
+    const AmbientFetch af = ambient_fetch_projected(P, ambient, hasAO, (const uint16_t*)cube, posW);
     const f3 r = reflect3(f3{ -view.x, -view.y, -view.z }, normalW);  // :94
     const CubeFetch cf = cube_fetch(cube, P.cubeDim, r);        // :95
 
     // :53-76  cascade selection and shadow factor of light 0
     const float d2Eye = dot3(toEye, toEye);
     const float distance = len_from_sq(d2Eye);
-    CascadePair cp;
-    const float shadow0 = cascade_fetch_uniform<ZERO_RADIUS>(P, posW, distance, fixQ1, cp) ? cascade_resolve_uniform(P, cp)
-                                                                                          : cascade_shadow<ZERO_RADIUS>(P, posW, distance, fixQ1);
+    float shadow0;
+    if (!cascade_shadow_uniform<ZERO_RADIUS>(P, posW, distance, fixQ1, shadow0)) shadow0 = cascade_shadow<ZERO_RADIUS>(P, posW, distance, fixQ1);
 
     const float ambientAccess = hasAO ? ambient_resolve(af) : 1.0f;
     const f3 amb{ ambientAccess * P.AmbientLight[0] * albedo.x, ambientAccess * P.AmbientLight[1] * albedo.y,

@@ -304,6 +304,7 @@ void hs_light(const crychic_pass_constants* cb, const float* g0, const float* g1
     P.darkLights = light_dark_mask(P.Lights, numDirLights);
     P.unitLights = light_dark_lengths_ok(P.Lights, numDirLights) ? 1u : 0u;
     P.rcpW = rcp((float)W); P.rcpH = rcp((float)H);
+    light_params_derive(P);
     const AllPointLights pl{ pointLights, numPointLights };
     const f4a* G0 = (const f4a*)g0; const f4a* G1 = (const f4a*)g1; const f4a* G2 = (const f4a*)g2;
     for (uint32_t y = row0; y < row0 + rows; ++y)

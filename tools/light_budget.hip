@@ -33,9 +33,7 @@ SECTION(ambient)        // :40-42: projection to the ambient map, four texel loa
 {
     IDX;
     const f4a G0 = in[idx], b = in[idx + 1000000u], c = in[idx + 2000000u];
-    const float sx = mulcol1(G0.x, G0.y, G0.z, P.ViewProjTex + 0), sy = mulcol1(G0.x, G0.y, G0.z, P.ViewProjTex + 4);
-    const float rsw = rcp(mulcol1(G0.x, G0.y, G0.z, P.ViewProjTex + 12));
-    const AmbientFetch af = ambient_fetch(ambient, P.W / 2, P.H / 2, sx * rsw, sy * rsw);
+    const AmbientFetch af = ambient_fetch_projected(P, ambient, true, (const uint16_t*)cube, f3{ G0.x, G0.y, G0.z });
     const float a = ambient_resolve(af);
     out[idx] = f4a{ a * P.AmbientLight[0] * b.x, a * P.AmbientLight[1] * b.y, a * P.AmbientLight[2] * b.z, c.x };
 }
@@ -64,9 +62,8 @@ SECTION(cascade)        // :53-76 on the wave-uniform path: two cascade lookups 
 {
     IDX;
     const f4a G0 = in[idx], b = in[idx + 1000000u], c = in[idx + 2000000u];
-    CascadePair cp;
     float s = 1.0f;
-    if (cascade_fetch_uniform<true>(P, f3{ G0.x, G0.y, G0.z }, b.x, false, cp)) s = cascade_resolve_uniform(P, cp);
+    cascade_shadow_uniform<true>(P, f3{ G0.x, G0.y, G0.z }, b.x, false, s);
     out[idx] = f4a{ s, b.y, c.x, c.y };
 }
 SECTION(guard)          // "dark lights": the input bounds of the wavefront
@@ -98,10 +95,9 @@ SECTION(tone_map)       // :89-92: x / (x + 1), pow(., 1 / 2.2), three channels
 {
     IDX;
     const f4a d = in[idx], a = in[idx + 1000000u], c = in[idx + 2000000u];
-    const float invGamma = 1.0f / 2.2f;
     const v2f d2{ d.x, d.y };
-    const v2f tm = det_pow2(d2 * rcp2(d2 + 1.0f), invGamma) + v2f{ a.x, a.y };
-    const float z = det_pow(divf(d.z, d.z + 1.0f), invGamma) + a.z;
+    const v2f tm = pow_inv_gamma2(d2 * rcp2(d2 + 1.0f)) + v2f{ a.x, a.y };
+    const float z = pow_inv_gamma(divf(d.z, d.z + 1.0f)) + a.z;
     out[idx] = f4a{ tm.x, tm.y, z, c.x };
 }
 SECTION(pack)           // RGBA8 quantisation of the result
