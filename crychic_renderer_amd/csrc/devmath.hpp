@@ -64,6 +64,10 @@ CRY_HD float rcp_normal(float b)
     const float r0 = __builtin_amdgcn_rcpf(b);
     return fma(fma(-b, r0, 1.0f), r0, r0);
 #else
+    // host simulation: an argument outside the promise is answered with NaN, so that a caller whose guard does not cover it shows
+    // up in the CPU tier (the device's v_rcp_f32 + Newton step returns NaN or garbage there: +inf gives fma(-inf, 0, 1) = NaN)
+    const float ab = __builtin_fabsf(b);
+    if (!(ab >= 1.17549435e-38f && ab <= 8.50705917e37f)) return u2f(0x7FC00000u);
     return 1.0f / b;
 #endif
 }

@@ -458,7 +458,8 @@ CRY_HD float ambient_linear_clamp(const uint16_t* __restrict__ a, uint32_t w2, u
 //     both vectors are normalised), D <= 400; k = (r + 1)^2 / 8 <= 15.2 keeps GeometrySchlickGGX's denominators positive for
 //     nDotl <= 1.002, G <= 1e6;
 //   |albedo|, |metalness| <= 16: f0, F <= 512, so F * fs <= 512 * (0.25 * 400 * 1e6 * 512 * 1e6) ~ 3e19;
-//   G-buffer position and normal finite (bounded position: the normalised view vector is finite), light direction finite with
+//   G-buffer position and normal finite, |EyePosW - posW|^2 < 1e30 (light_pixel adds that test to the guard: the normalised view
+//     vector is then finite and at most unit length -- the G-buffer bounds alone do not bound the eye), light direction finite with
 //     length in [0.5, 1.001] (host): every dot product is finite, nDotl <= 1.002.
 // A wavefront skips a dark light only if all its pixels pass the guard; otherwise it evaluates the light like any other.
 CRY_HD uint32_t light_dark_mask(const crychic_light* L, int n)
@@ -666,7 +667,10 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
     // skipped and the others -- whose directions light_dark_lengths_ok() vouches for -- take the shorter reciprocals
     bool bounded = false;
     if (P.darkLights) {
-        bounded = light_dark_guard(G0, G1, G2);
+        // ... and a finite view vector: |toEye|^2 < 1e30 (false for NaN) bounds EyePosW - posW, so `view` is finite and no longer than
+        // 1 + ulps.  Without it an infinite EyePosW makes hDotv = +inf, and rcp_normal(+inf) is NaN where rcp(+inf) is 0 (found by
+        // tests/test_gpu_parity.py::test_dark_light_skip_on_device's eye cases, round 4).
+        bounded = light_dark_guard(G0, G1, G2) & (d2Eye < 1.0e30f);
 #if defined(__HIP_DEVICE_COMPILE__)
         bounded = __builtin_amdgcn_ballot_w64(!bounded) == 0;   // wave-uniform: the loop below stays converged
 #endif
