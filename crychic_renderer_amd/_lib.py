@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libcrychic_hip.so")
+# CRYCHIC_LIB: a probe build of the same library (tools/probes/variants.sh builds them with extra -D flags); never set in tests or bench runs
+LIB_PATH = os.environ.get("CRYCHIC_LIB") or os.path.join(HERE, "libcrychic_hip.so")
 
 MAX_LIGHTS = 16
 LIGHT_SKY = 1

@@ -230,9 +230,13 @@ CRY_HD float pow5(float x) { float x2 = x * x, x4 = x2 * x2; return x4 * x; }
 // BOUNDED: a promise that the pixel passed light_dark_guard() and that the light direction is no longer than 1.001 (light_dark_mask's
 // test) -- then every reciprocal below has a normal argument with a normal result (the Smith denominators lie in [0.13, 15.2],
 // nDotl * nDotv in [1e-6, 1.01], pi * tt^2 in [2.5e-6, 3.2e4]: see "dark lights"), where rcp_normal IS rcp, two instructions shorter.
+// ... in two steps, so that a caller can evaluate a light before its shadow factor is known (light_pixel: the BRDF of light 0
+// runs while the shadow cascades' texels are in flight): pbr_light_eval computes brdf and strength * nDotl (* att), pbr_light_add
+// applies result = mad(scale * brdf, lightStrength, result) -- the shader's own operations in the shader's own order.
+struct LightTerm { v2f brdfRG, lsRG; float brdfB, lsB; };
 template <bool POINT, bool BOUNDED = false>
-CRY_HD void pbr_light(f3 lightDir, const float* strength, float att, f3 albedo, float roughness, float metalness, f3 normal,
-                      f3 view, float scale, f3& result, bool fixQ3 = false, bool fixQ4 = false)
+CRY_HD LightTerm pbr_light_eval(f3 lightDir, const float* strength, float att, f3 albedo, float roughness, float metalness, f3 normal,
+                                f3 view, bool fixQ3 = false, bool fixQ4 = false)
 {
     auto rcpB = [](float b) { return BOUNDED ? rcp_normal(b) : rcp(b); };
     const f3 halfVec = normalize3(f3{ view.x + lightDir.x, view.y + lightDir.y, view.z + lightDir.z });
@@ -258,6 +262,7 @@ CRY_HD void pbr_light(f3 lightDir, const float* strength, float att, f3 albedo, 
     // The three colour channels run the same expression tree: red and green as one packed pair (v_pk_*_f32: two channels per
     // issue slot), blue as scalars.  Every lane is the scalar expression bit for bit (devmath.hpp "two-wide packed fp32").
     const float c025DG = 0.25f * D * G;
+    LightTerm t;
     {
         const v2f alb{ albedo.x, albedo.y }, str{ strength[0], strength[1] };
         const v2f f0 = fma2(splat(metalness), alb - 0.04f, splat(0.04f));       // lerp(0.04, albedo, metalness)
@@ -266,12 +271,9 @@ CRY_HD void pbr_light(f3 lightDir, const float* strength, float att, f3 albedo, 
         fs = fs * rdenom;
         const v2f fd = alb * invPi;
         const v2f kd = (1.0f - F) * oneMinusMetal;
-        const v2f brdf = fixQ4 ? kd * fd + fs : fma2(F, fs, kd * fd);           // ks = F (Q4)
-        v2f lightStrength = str * nDotl;                                         // :104 / :118
-        if (POINT) lightStrength = lightStrength * att;                          // :120
-        const v2f res = fma2(scale * brdf, lightStrength, v2f{ result.x, result.y });   // :105 / :122
-        result.x = res.x;
-        result.y = res.y;
+        t.brdfRG = fixQ4 ? kd * fd + fs : fma2(F, fs, kd * fd);                 // ks = F (Q4)
+        t.lsRG = str * nDotl;                                                    // :104 / :118
+        if (POINT) t.lsRG = t.lsRG * att;                                        // :120
     }
     {
         const float f0 = lerpf(0.04f, albedo.z, metalness);
@@ -280,14 +282,34 @@ CRY_HD void pbr_light(f3 lightDir, const float* strength, float att, f3 albedo, 
         fs = fs * rdenom;
         const float fd = albedo.z * invPi;
         const float kd = (1.0f - F) * oneMinusMetal;
-        const float brdf = fixQ4 ? kd * fd + fs : fma(F, fs, kd * fd);
-        float lightStrength = strength[2] * nDotl;
-        if (POINT) lightStrength = lightStrength * att;
-        result.z = fma(scale * brdf, lightStrength, result.z);
+        t.brdfB = fixQ4 ? kd * fd + fs : fma(F, fs, kd * fd);
+        t.lsB = strength[2] * nDotl;
+        if (POINT) t.lsB = t.lsB * att;
     }
+    return t;
+}
+CRY_HD void pbr_light_add(const LightTerm& t, float scale, f3& result)
+{
+    const v2f res = fma2(scale * t.brdfRG, t.lsRG, v2f{ result.x, result.y });   // :105 / :122
+    result.x = res.x;
+    result.y = res.y;
+    result.z = fma(scale * t.brdfB, t.lsB, result.z);
+}
+template <bool POINT, bool BOUNDED = false>
+CRY_HD void pbr_light(f3 lightDir, const float* strength, float att, f3 albedo, float roughness, float metalness, f3 normal,
+                      f3 view, float scale, f3& result, bool fixQ3 = false, bool fixQ4 = false)
+{
+    pbr_light_add(pbr_light_eval<POINT, BOUNDED>(lightDir, strength, att, albedo, roughness, metalness, normal, view, fixQ3, fixQ4), scale, result);
 }
 
 // One directional light of PBRShading (PBR.hlsl:99-106).
+template <bool BOUNDED = false>
+CRY_HD LightTerm pbr_dir_light_eval(const crychic_light& L, f3 albedo, float roughness, float metalness, f3 normal, f3 view, bool fixQ3 = false,
+                                    bool fixQ4 = false)
+{
+    return pbr_light_eval<false, BOUNDED>(f3{ -L.Direction[0], -L.Direction[1], -L.Direction[2] }, L.Strength, 1.0f, albedo, roughness, metalness, normal,
+                                          view, fixQ3, fixQ4);
+}
 template <bool BOUNDED = false>
 CRY_HD void pbr_dir_light(const crychic_light& L, f3 albedo, float roughness, float metalness, f3 normal, f3 view,
                           float shadow, f3& result, bool fixQ3 = false, bool fixQ4 = false)
@@ -313,7 +335,10 @@ CRY_HD void pbr_point_light(const crychic_light& L, f3 pos, f3 albedo, float rou
 // TextureCube.Sample(gsamLinearWrap, r): D3D major-axis face selection (ties x >= y >= z), bilinear inside the
 // face with clamp-to-edge.  Faces +X,-X,+Y,-Y,+Z,-Z, RGBA8.
 struct CubeFetch { TexelPair p0, p1; float fx, fy; };
-CRY_HD CubeFetch cube_fetch(const uint32_t* __restrict__ cube, uint32_t dim, f3 r)
+// The two rows of a footprint as loaded, before pair_at_clamped's picks: texels (cx, cx + 1) of rows y0, y1, and the column index
+// i0 the picks need (cube_pick).  cube_fetch issues the loads and nothing else touches them until cube_resolve.
+struct CubeRows { RawPair r0, r1; float fx, fy; int i0; };
+CRY_HD CubeRows cube_fetch(const uint32_t* __restrict__ cube, uint32_t dim, f3 r)
 {
     const float ax = __builtin_fabsf(r.x), ay = __builtin_fabsf(r.y), az = __builtin_fabsf(r.z);
     // major axis (ties x >= y >= z) and the face's (sc, tc) by selects: a wave whose lanes look at different faces stays converged
@@ -328,10 +353,10 @@ CRY_HD CubeFetch cube_fetch(const uint32_t* __restrict__ cube, uint32_t dim, f3 
     const float u = fma(0.5f, sc * rma, 0.5f);      // 0.5 * (sc / ma + 1)
     const float v = fma(0.5f, tc * rma, 0.5f);
     const uint32_t faceRow = mul24(face, dim);   // faces are stacked: row index face*dim + y
-    CubeFetch f;
     // Footprints in the interior of their face (floor(texel coordinate) in [0, dim - 2] on both axes, which a NaN fails), for the
-    // whole wavefront: bilinear_setup's non-finite rule and pair_at_clamped's edge selects cannot act, the rows are two 8-byte
-    // loads at (face * dim + j0) * dim + i0.  A wavefront with a footprint on a face edge takes the general sampler.
+    // whole wavefront: bilinear_setup's non-finite rule and the CLAMP of rows and columns cannot act, the rows are at
+    // (face * dim + j0) * dim + i0.  A wavefront with a footprint on a face edge takes the general sampler's indices.  As in
+    // ambient_fetch_projected the vote chooses how the ADDRESSES are computed; the loads follow the merge.
     const float fd = (float)dim;
     const float tx = fma(u, fd, -0.5f), ty = fma(v, fd, -0.5f);
     const float flx = __builtin_floorf(tx), fly = __builtin_floorf(ty);
@@ -339,25 +364,41 @@ CRY_HD CubeFetch cube_fetch(const uint32_t* __restrict__ cube, uint32_t dim, f3 
 #if defined(__HIP_DEVICE_COMPILE__)
     inside = __builtin_amdgcn_ballot_w64(!inside) == 0;
 #endif
+    CubeRows f;
+    uint32_t t0, t1;
     if (inside) {
-        const uint32_t t0 = mul24(faceRow + (uint32_t)(int)fly, dim) + (uint32_t)(int)flx;
-        const RawPair r0 = load_pair(cube, t0), r1 = load_pair(cube, t0 + dim);
-        f.p0 = TexelPair{ r0.lo, r0.hi };
-        f.p1 = TexelPair{ r1.lo, r1.hi };
+        f.i0 = (int)flx;
+        t0 = mul24(faceRow + (uint32_t)(int)fly, dim) + (uint32_t)f.i0;
+        t1 = t0 + dim;
         f.fx = tx - flx;
         f.fy = ty - fly;
-        return f;
-    }
-    float us = u, vs = v;
+    } else {
+        float us = u, vs = v;
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(us), "+v"(vs));      // the general sampler's clamps stay on this side of the vote
+        asm volatile("" : "+v"(us), "+v"(vs));      // the general sampler's clamps stay on this side of the vote
 #endif
-    const Bilin b = bilinear_setup(us, vs, dim, dim);
-    const uint32_t y0 = (uint32_t)clampi(b.j0, 0, (int)dim - 1), y1 = (uint32_t)clampi(b.j0 + 1, 0, (int)dim - 1);
-    f.p0 = pair_at_clamped(cube, faceRow + y0, dim, b.i0);
-    f.p1 = pair_at_clamped(cube, faceRow + y1, dim, b.i0);
-    f.fx = b.fx;
-    f.fy = b.fy;
+        const Bilin b = bilinear_setup(us, vs, dim, dim);
+        const uint32_t y0 = (uint32_t)clampi(b.j0, 0, (int)dim - 1), y1 = (uint32_t)clampi(b.j0 + 1, 0, (int)dim - 1);
+        const uint32_t cx = (uint32_t)clampi(b.i0, 0, (int)dim - 2);
+        t0 = mul24(faceRow + y0, dim) + cx;
+        t1 = mul24(faceRow + y1, dim) + cx;
+        f.i0 = b.i0;
+        f.fx = b.fx;
+        f.fy = b.fy;
+    }
+    f.r0 = load_pair(cube, t0);
+    f.r1 = load_pair(cube, t1);
+    return f;
+}
+// pair_at_clamped's picks: texels clamp(i0) and clamp(i0 + 1) out of the loaded pair (cx, cx + 1), cx = clamp(i0, 0, dim - 2)
+CRY_HD CubeFetch cube_pick(const CubeRows& c, uint32_t dim)
+{
+    const bool hiA = c.i0 > (int)dim - 2, loB = c.i0 < 0;
+    CubeFetch f;
+    f.p0 = TexelPair{ hiA ? c.r0.hi : c.r0.lo, loB ? c.r0.lo : c.r0.hi };
+    f.p1 = TexelPair{ hiA ? c.r1.hi : c.r1.lo, loB ? c.r1.lo : c.r1.hi };
+    f.fx = c.fx;
+    f.fy = c.fy;
     return f;
 }
 // WANT_ALPHA = false (the reflection lookup of a lit pixel, which uses .rgb only): .w = 0.
@@ -388,7 +429,7 @@ CRY_HD f4 cube_resolve(const CubeFetch& f)
     const v2f rows = lerp2(left, right, splat(f.fx));        // { top, bot }
     return f4{ rg.x, rg.y, lerpf(rows.x, rows.y, f.fy), 0.0f };
 }
-CRY_HD f4 cube_linear(const uint32_t* __restrict__ cube, uint32_t dim, f3 r) { return cube_resolve(cube_fetch(cube, dim, r)); }
+CRY_HD f4 cube_linear(const uint32_t* __restrict__ cube, uint32_t dim, f3 r) { return cube_resolve(cube_pick(cube_fetch(cube, dim, r), dim)); }
 
 // gsamLinearClamp on the half-res R16_UNORM ambient map  (CRYCHIC.cpp:2624-2629)
 struct AmbientFetch { uint16_t t00, t10, t01, t11; float fx, fy; };
@@ -402,37 +443,72 @@ CRY_HD AmbientFetch ambient_fetch(const uint16_t* __restrict__ a, uint32_t w2, u
                          load_at<uint16_t>(a, (r1 + x0) * 2u), load_at<uint16_t>(a, (r1 + x1) * 2u), b.fx, b.fy };
 }
 // The lighting pass's own lookup (DeferredShading.hlsl:40-42): posW projected by gViewProjTex, x and y as one packed pair
-// (LightParams::ScreenPairs; each lane is mulcol1 / bilinear_setup bit for bit).  When the footprint of every pixel of the wavefront
-// lies inside the map (everything but the frame's rim and non-finite positions: a NaN fails the test) nothing is clamped and the
-// four texels are two 4-byte loads of {t(i0), t(i0 + 1)} (2-byte aligned); otherwise ambient_fetch on the same coordinates.
-// hasAO false: the 1 x 1 stand-in of light_pixel, always the general path.
-CRY_HD AmbientFetch ambient_fetch_projected(const LightParams& P, const uint16_t* __restrict__ a, bool hasAO, const uint16_t* __restrict__ standIn, f3 posW)
+// (LightParams::ScreenPairs; each lane is mulcol1 / bilinear_setup bit for bit), and the four texels as TWO 4-byte loads of
+// {t(cx), t(cx + 1)} (2-byte aligned) from rows y0, y1.  When the footprint of every pixel of the wavefront lies inside the map
+// (everything but the frame's rim and non-finite positions: a NaN fails the test) cx = i0 and nothing is clamped; otherwise the
+// general sampler's indices (non-finite rule, CLAMP) with cx = clamp(i0, 0, w - 2), and the texels are picked from the loaded
+// pairs afterwards.  The vote only chooses how ADDRESSES are computed: the loads themselves sit behind the merge, so that no wait
+// for them is needed before the other gathers of the pixel have been issued (a branch that returns loaded data makes the
+// compiler wait inside it: three serialised round trips per pixel, measured -- profiles/r04_experiments.txt).
+// hasAO false: the 1 x 1 stand-in of light_pixel (the cubemap's first bytes): w = h = 1, both picks take the low half.
+struct AmbientPairs { uint32_t d0, d1; float fx, fy; bool x0lo, x1lo; };      // t00 = x0lo ? lo(d0) : hi(d0), t10 = x1lo ? lo(d0) : hi(d0), ...
+CRY_HD AmbientPairs ambient_fetch_projected(const LightParams& P, const uint16_t* __restrict__ a, bool hasAO, const uint16_t* __restrict__ standIn, f3 posW)
 {
     const v2f c0{ P.ScreenPairs[0][0], P.ScreenPairs[0][1] }, c1{ P.ScreenPairs[1][0], P.ScreenPairs[1][1] };
     const v2f c2{ P.ScreenPairs[2][0], P.ScreenPairs[2][1] }, c3{ P.ScreenPairs[3][0], P.ScreenPairs[3][1] };
     const v2f s = fma2(splat(posW.z), c2, fma2(splat(posW.y), c1, splat(posW.x) * c0)) + c3;
     const float rsw = rcp(mulcol1(posW.x, posW.y, posW.z, P.ViewProjTex + 12));
     const v2f uv = s * rsw;
-    if (hasAO) {
-        const v2f dims{ P.halfDims[0], P.halfDims[1] };
-        const v2f t = fma2(uv, dims, -0.5f);
-        const v2f fl = floor2(t);
-        bool inside = (fl.x >= 0.0f) & (fl.x <= dims.x - 2.0f) & (fl.y >= 0.0f) & (fl.y <= dims.y - 2.0f);
+    // A one-texel-wide map (W = 2) has no pair to load -- its last row's dword would leave the plane: such a frame reads the
+    // stand-in here (valid memory, never looked at) and samples the map in ambient_resolve, from the coordinates kept in fx, fy.
+    const bool tiny = hasAO && P.W < 4u;
+    if (tiny) hasAO = false;
+    const uint32_t w2 = hasAO ? P.W / 2u : 1u, h2 = hasAO ? P.H / 2u : 1u;
+    const v2f dims{ hasAO ? P.halfDims[0] : 1.0f, hasAO ? P.halfDims[1] : 1.0f };
+    const v2f t = fma2(uv, dims, -0.5f);
+    const v2f fl = floor2(t);
+    bool inside = (fl.x >= 0.0f) & (fl.x <= dims.x - 2.0f) & (fl.y >= 0.0f) & (fl.y <= dims.y - 2.0f);
 #if defined(__HIP_DEVICE_COMPILE__)
-        inside = __builtin_amdgcn_ballot_w64(!inside) == 0;
+    inside = __builtin_amdgcn_ballot_w64(!inside) == 0;
 #endif
-        if (inside) {
-            const uint32_t w2 = P.W / 2u, idx = mul24((uint32_t)(int)fl.y, w2) + (uint32_t)(int)fl.x;
-            const uint32_t d0 = load_at<uint32_t>(a, idx * 2u), d1 = load_at<uint32_t>(a, (idx + w2) * 2u);
-            const v2f fr = t - fl;
-            return AmbientFetch{ (uint16_t)(d0 & 0xFFFFu), (uint16_t)(d0 >> 16), (uint16_t)(d1 & 0xFFFFu), (uint16_t)(d1 >> 16), fr.x, fr.y };
-        }
+    AmbientPairs f;
+    uint32_t o0, o1;
+    if (inside) {
+        o0 = mul24((uint32_t)(int)fl.y, w2) + (uint32_t)(int)fl.x;
+        o1 = o0 + w2;
+        const v2f fr = t - fl;
+        f.fx = fr.x; f.fy = fr.y; f.x0lo = true; f.x1lo = false;
+    } else {
+        float u = uv.x, v = uv.y;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(u), "+v"(v));      // the general sampler's clamps stay on this side of the vote
+#endif
+        const Bilin b = bilinear_setup(u, v, w2, h2);
+        const int x0 = clampi(b.i0, 0, (int)w2 - 1), x1 = clampi(b.i0 + 1, 0, (int)w2 - 1);
+        const int cx = clampi(b.i0, 0, (int)w2 - 2 > 0 ? (int)w2 - 2 : 0);
+        const uint32_t y0 = (uint32_t)clampi(b.j0, 0, (int)h2 - 1), y1 = (uint32_t)clampi(b.j0 + 1, 0, (int)h2 - 1);
+        o0 = mul24(y0, w2) + (uint32_t)cx;
+        o1 = mul24(y1, w2) + (uint32_t)cx;
+        f.fx = b.fx; f.fy = b.fy; f.x0lo = x0 == cx; f.x1lo = x1 == cx;
     }
-    float u = uv.x, v = uv.y;
+    const uint16_t* src = hasAO ? a : standIn;
+    f.d0 = load_at<uint32_t>(src, o0 * 2u);
+    f.d1 = load_at<uint32_t>(src, o1 * 2u);
+    if (tiny) { f.fx = uv.x; f.fy = uv.y; }
+    return f;
+}
+CRY_HD float ambient_linear_clamp(const uint16_t* __restrict__ a, uint32_t w2, uint32_t h2, float u, float v);
+CRY_HD float ambient_resolve(const LightParams& P, const uint16_t* __restrict__ a, const AmbientPairs& f)
+{
+    if (P.W < 4u) return ambient_linear_clamp(a, P.W / 2u, P.H / 2u, f.fx, f.fy);      // the one-texel-wide map (see the fetch)
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("" : "+v"(u), "+v"(v));      // the general sampler's clamps stay on this side of the vote
+    // a wavefront over unoccluded ground (most of them): texels of 65535 decode to 1.0 and lerp(1, 1, t) = mad(t, 0, 1) = 1 for the
+    // finite weights bilinear_setup returns (both halves of both pairs all ones: the four texels, whichever halves they are)
+    if (__builtin_amdgcn_ballot_w64((f.d0 & f.d1) != 0xFFFFFFFFu) == 0) return 1.0f;
 #endif
-    return ambient_fetch(hasAO ? a : standIn, hasAO ? P.W / 2 : 1u, hasAO ? P.H / 2 : 1u, u, v);
+    const uint32_t l0 = f.d0 & 0xFFFFu, h0 = f.d0 >> 16, l1 = f.d1 & 0xFFFFu, h1 = f.d1 >> 16;
+    return bilerp(unorm16_to_float(f.x0lo ? l0 : h0), unorm16_to_float(f.x1lo ? l0 : h0), unorm16_to_float(f.x0lo ? l1 : h1),
+                  unorm16_to_float(f.x1lo ? l1 : h1), f.fx, f.fy);
 }
 CRY_HD float ambient_resolve(const AmbientFetch& f)
 {
@@ -445,7 +521,8 @@ CRY_HD float ambient_resolve(const AmbientFetch& f)
 }
 CRY_HD float ambient_linear_clamp(const uint16_t* __restrict__ a, uint32_t w2, uint32_t h2, float u, float v)
 {
-    return ambient_resolve(ambient_fetch(a, w2, h2, u, v));
+    const AmbientFetch f = ambient_fetch(a, w2, h2, u, v);
+    return bilerp(unorm16_to_float(f.t00), unorm16_to_float(f.t10), unorm16_to_float(f.t01), unorm16_to_float(f.t11), f.fx, f.fy);
 }
 
 // ---- dark lights -------------------------------------------------------------------------------------------------------
@@ -533,10 +610,25 @@ CRY_HD float cascade_shadow(const LightParams& P, f3 posW, float distance, bool 
 #endif
         return pcf_poisson<ZERO_RADIUS, false>(P.shadow[k], P.shadowDim, spx, spy, spz, spw, P.pcfSearchRadius);
     };
-    const float a = cascade(j);
     const float radiusJ = j == 0 ? 30.0f : (j == 1 ? 50.0f : (j == 2 ? 80.0f : 100.0f));
     const bool blend = j < 3 && (!fixQ1 || __builtin_fabsf(distance - radiusJ) < 5.0f);   // Q1: as written, every j < 3 blends
-    return blend ? 0.5f * (a + cascade(j + 1)) : a;              // :66 / :73
+    // The cascades a pixel needs -- j, and j + 1 when it blends -- visited in a WAVE-UNIFORM loop over k: the transform and the map
+    // of cascade k are then scalar operands (a per-lane k costs sixteen vector registers per matrix and per-lane map pointers), and
+    // a wavefront whose pixels agree on j runs exactly the two lookups it ran before.  Same lookups per pixel, so the same bits.
+    float a = 0.0f, b = 0.0f;
+#pragma unroll 1
+    for (int k = 0; k < 4; ++k) {
+        const bool mine = j == k, next = blend & (j + 1 == k);
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (__builtin_amdgcn_ballot_w64(mine | next) == 0) continue;
+#endif
+        if (mine | next) {
+            const float v = cascade(k);
+            a = mine ? v : a;
+            b = next ? v : b;
+        }
+    }
+    return blend ? 0.5f * (a + b) : a;              // :66 / :73
 }
 
 // The common case of cascade_shadow for a whole wavefront: every pixel in the same cascade J <= 2 (so J and J + 1 are blended,
@@ -556,74 +648,123 @@ CRY_HD v2f d24_to_float2(uint32_t a, uint32_t b)
     const v2f t{ (float)(a & 0x00FFFFFFu), (float)(b & 0x00FFFFFFu) };
     return fma2(t, splat(u2f(0x33800001u)), t * u2f(0xA77FFFFFu));      // unorm_decode per lane
 }
+// In two halves: cascade_uniform_fetch issues the loads (or declines: the wavefront is not uniform), cascade_uniform_resolve turns
+// the texels into the factor -- so that the caller can issue every gather of the pixel before anything waits for one.
+struct CascadeTexels {
+    RawPair a0, a1, b0, b1;        // rows y0, y1 of cascade J (a) and J + 1 (b): texels (cx, cx + 1)
+    v2f fx, fy, z;                 // filter weights and reference depths, lane .x = J, .y = J + 1
+    bool inside;                   // wave-uniform on the device: every footprint inside its map (cx = i0, no BORDER texel)
+    int ia, ja, ib, jb;            // rim only: the footprints' top-left texel indices (pair_at's picks, BORDER tests)
+};
+// cascade_uniform_test: may this wavefront take the packed path, and with which cascade J (wave-uniform)?  Asked before anything
+// else of the pixel is computed, so that a wavefront that may not runs the general lookups (cascade_shadow) while little is live.
 template <bool ZERO_RADIUS>
-CRY_HD bool cascade_shadow_uniform(const LightParams& P, f3 posW, float distance, bool fixQ1, float& shadow)
+CRY_HD bool cascade_uniform_test(const LightParams& P, f3 posW, float distance, bool fixQ1, int& J)
 {
+    J = 0;
     if (!ZERO_RADIUS || fixQ1 || !P.shadowWIsOne) return false;
     // |posW| < 1e15 with the transforms' entries below 1e12 (light_shadow_w_is_one): shadowPosH.w == 1, and the shadow
     // coordinates stay below 4e27, so the sampler's texel coordinates (x 16384 at most) are finite: bilinear_setup<FINITE>
     const float pmax = 1.0e15f;
     const int j = cascade_index(distance);
-    int J = j;
+    J = j;
 #if defined(__HIP_DEVICE_COMPILE__)
     J = __builtin_amdgcn_readfirstlane(J);
 #endif
     const bool ok = j == J && J <= 2 && __builtin_fabsf(posW.x) < pmax && __builtin_fabsf(posW.y) < pmax && __builtin_fabsf(posW.z) < pmax;
 #if defined(__HIP_DEVICE_COMPILE__)
-    if (__builtin_amdgcn_ballot_w64(!ok) != 0) return false;
+    return __builtin_amdgcn_ballot_w64(!ok) == 0;
 #else
-    if (!ok) return false;
+    return ok;
 #endif
+}
+CRY_HD void cascade_uniform_fetch(const LightParams& P, f3 posW, int J, CascadeTexels& c)
+{
     const float (*S)[2] = P.ShadowPairs[J];
     auto row = [&](int r) {        // mulcol1 of both cascades: fma(z, c2, fma(y, c1, x * c0)) + c3 per lane
         const v2f c0{ S[4 * r][0], S[4 * r][1] }, c1{ S[4 * r + 1][0], S[4 * r + 1][1] }, c2{ S[4 * r + 2][0], S[4 * r + 2][1] }, c3{ S[4 * r + 3][0], S[4 * r + 3][1] };
         return fma2(splat(posW.z), c2, fma2(splat(posW.y), c1, splat(posW.x) * c0)) + c3;
     };
-    const v2f u = row(0), v = row(1), z = row(2);
-    const float fd = (float)P.shadowDim;
-    const v2f tx = fma2(u, fd, -0.5f), ty = fma2(v, fd, -0.5f);      // bilinear_setup<true>
+    const v2f u = row(0), v = row(1);
+    c.z = row(2);
+    const uint32_t dim = P.shadowDim;
+    const float fd = (float)dim;
+    const v2f tx = fma2(u, fd, -0.5f), ty = fma2(v, fd, -0.5f);      // bilinear_setup<true>: fx = tx - floor(tx), no non-finite case
     const v2f flx = floor2(tx), fly = floor2(ty);
+    c.fx = tx - flx;
+    c.fy = ty - fly;
     const float lo = __builtin_fminf(__builtin_fminf(flx.x, flx.y), __builtin_fminf(fly.x, fly.y));
     const float hi = __builtin_fmaxf(__builtin_fmaxf(flx.x, flx.y), __builtin_fmaxf(fly.x, fly.y));
     bool inside = (lo >= 0.0f) & (hi <= fd - 2.0f);                   // all four finite (above)
 #if defined(__HIP_DEVICE_COMPILE__)
     inside = __builtin_amdgcn_ballot_w64(!inside) == 0;
 #endif
-    float a, b;
+    c.inside = inside;
+    // The vote chooses how the ADDRESSES are computed (ambient_fetch_projected explains why the loads follow the merge).
+    uint32_t a0, a1, b0, b1;
     if (inside) {
-        const uint32_t ta = mul24((uint32_t)(int)fly.x, P.shadowDim) + (uint32_t)(int)flx.x;
-        const uint32_t tb = mul24((uint32_t)(int)fly.y, P.shadowDim) + (uint32_t)(int)flx.y;
-        const RawPair a0 = load_pair(P.shadow[J], ta), a1 = load_pair(P.shadow[J], ta + P.shadowDim);          // rows j0, j0 + 1: texels i0, i0 + 1
-        const RawPair b0 = load_pair(P.shadow[J + 1], tb), b1 = load_pair(P.shadow[J + 1], tb + P.shadowDim);
-        const v2f fx = tx - flx, fy = ty - fly;
+        a0 = mul24((uint32_t)(int)fly.x, dim) + (uint32_t)(int)flx.x;
+        b0 = mul24((uint32_t)(int)fly.y, dim) + (uint32_t)(int)flx.y;
+        a1 = a0 + dim;
+        b1 = b0 + dim;
+        c.ia = c.ja = c.ib = c.jb = 0;
+    } else {
+        v2f fxs = flx, fys = fly;
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("" : "+v"(fxs), "+v"(fys));      // keeps the rim's clamps inside this branch (the optimiser would otherwise
+                                                      // compute them ahead of the vote)
+#endif
+        c.ia = texel_index(fxs.x, dim); c.ja = texel_index(fys.x, dim);          // bilinear_setup<true>'s indices; shadow_fetch's rows, pair_at's column
+        c.ib = texel_index(fxs.y, dim); c.jb = texel_index(fys.y, dim);
+        const uint32_t ca = (uint32_t)clampi(c.ia, 0, (int)dim - 2), cb = (uint32_t)clampi(c.ib, 0, (int)dim - 2);
+        a0 = mul24((uint32_t)clampi(c.ja, 0, (int)dim - 1), dim) + ca;
+        a1 = mul24((uint32_t)clampi(c.ja + 1, 0, (int)dim - 1), dim) + ca;
+        b0 = mul24((uint32_t)clampi(c.jb, 0, (int)dim - 1), dim) + cb;
+        b1 = mul24((uint32_t)clampi(c.jb + 1, 0, (int)dim - 1), dim) + cb;
+    }
+    c.a0 = load_pair(P.shadow[J], a0);
+    c.a1 = load_pair(P.shadow[J], a1);
+    c.b0 = load_pair(P.shadow[J + 1], b0);
+    c.b1 = load_pair(P.shadow[J + 1], b1);
+}
+// pair_at's picks out of a loaded pair (cx, cx + 1), cx = clamp(i0, 0, dim - 2)
+CRY_HD TexelPair pair_pick(RawPair v, int i0, uint32_t dim)
+{
+    const int cx = clampi(i0, 0, (int)dim - 2);
+    return TexelPair{ (i0 == cx) ? v.lo : v.hi, (i0 + 1 == cx) ? v.lo : v.hi };
+}
+CRY_HD float cascade_uniform_resolve(const LightParams& P, const CascadeTexels& c)
+{
+    float a, b;
+    if (c.inside) {
         const v2f one = splat(1.0f), zero = splat(0.0f);
-        const v2f c00 = select2(z <= d24_to_float2(a0.lo, b0.lo), one, zero), c10 = select2(z <= d24_to_float2(a0.hi, b0.hi), one, zero);
-        const v2f c01 = select2(z <= d24_to_float2(a1.lo, b1.lo), one, zero), c11 = select2(z <= d24_to_float2(a1.hi, b1.hi), one, zero);
-        const v2f t = lerp2(lerp2(c00, c10, fx), lerp2(c01, c11, fx), fy);      // bilerp per lane
+        const v2f c00 = select2(c.z <= d24_to_float2(c.a0.lo, c.b0.lo), one, zero), c10 = select2(c.z <= d24_to_float2(c.a0.hi, c.b0.hi), one, zero);
+        const v2f c01 = select2(c.z <= d24_to_float2(c.a1.lo, c.b1.lo), one, zero), c11 = select2(c.z <= d24_to_float2(c.a1.hi, c.b1.hi), one, zero);
+        const v2f t = lerp2(lerp2(c00, c10, c.fx), lerp2(c01, c11, c.fx), c.fy);      // bilerp per lane
         a = t.x;
         b = t.y;
-#if defined(__HIP_DEVICE_COMPILE__)
-        // pcf_zero_radius, both lookups under one vote: fully lit / fully shadowed footprints come out of the 16 additions unchanged
-        if (__builtin_amdgcn_ballot_w64(!(((a == 0.0f) | (a == 1.0f)) & ((b == 0.0f) | (b == 1.0f)))) == 0) {
-            shadow = 0.5f * (a + b);
-            return true;
-        }
-#endif
     } else {
-        float ua = u.x, va = v.x, ub = u.y, vb = v.y;
-#if defined(__HIP_DEVICE_COMPILE__)
-        asm volatile("" : "+v"(ua), "+v"(va), "+v"(ub), "+v"(vb));      // keeps the rim's clamps and selects inside this branch (the
-                                                                         // optimiser would otherwise compute them ahead of the vote)
-#endif
-        const ShadowFetch f0 = shadow_fetch<true>(P.shadow[J], P.shadowDim, ua, va);
-        const ShadowFetch f1 = shadow_fetch<true>(P.shadow[J + 1], P.shadowDim, ub, vb);
-        a = shadow_resolve<true>(f0, P.shadowDim, z.x);
-        b = shadow_resolve<true>(f1, P.shadowDim, z.y);
+        const ShadowFetch f0{ pair_pick(c.a0, c.ia, P.shadowDim), pair_pick(c.a1, c.ia, P.shadowDim), Bilin{ c.ia, c.ja, c.fx.x, c.fy.x } };
+        const ShadowFetch f1{ pair_pick(c.b0, c.ib, P.shadowDim), pair_pick(c.b1, c.ib, P.shadowDim), Bilin{ c.ib, c.jb, c.fx.y, c.fy.y } };
+        a = shadow_resolve<true>(f0, P.shadowDim, c.z.x);
+        b = shadow_resolve<true>(f1, P.shadowDim, c.z.y);
     }
-    shadow = 0.5f * (pcf_zero_radius(a) + pcf_zero_radius(b));     // :66
-    return true;
+#if defined(__HIP_DEVICE_COMPILE__)
+    // pcf_zero_radius, both lookups under one vote: fully lit / fully shadowed footprints come out of the 16 additions unchanged
+    if (__builtin_amdgcn_ballot_w64(!(((a == 0.0f) | (a == 1.0f)) & ((b == 0.0f) | (b == 1.0f)))) == 0) return 0.5f * (a + b);
+#endif
+    return 0.5f * (pcf_zero_radius(a) + pcf_zero_radius(b));     // :66
 }
 
+#if defined(CRY_PROBE_TIMING) && defined(__HIPCC__)
+static __device__ unsigned long long g_probe[8 * 140000];      // probe build only (tools/probes/variants.sh): stage time stamps per wavefront (4K: 129600)
+static __device__ uint32_t g_probe_wave;                       // set by the kernel before light_pixel: this wavefront's slot
+#endif
+#if defined(CRY_PROBE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+#define CRY_STAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); probe_t[k] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
+#else
+#define CRY_STAMP(k) do { } while (0)
+#endif
 // DeferredShading.hlsl:23-101 for one covered pixel.  Every gather of the pixel -- ambient map, cubemap, shadow cascades -- is
 // issued before the first is waited for (one memory round trip instead of one per lookup).
 // FIX: a compile-time promise that P.flags may carry CRYCHIC_FIX_* bits; false = the reference as written, with no trace of
@@ -633,6 +774,11 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
                       const uint32_t* __restrict__ cube, PointLights pointLights = PointLights())
 {
     const bool fixQ1 = FIX && (P.flags & CRYCHIC_FIX_Q1), fixQ3 = FIX && (P.flags & CRYCHIC_FIX_Q3), fixQ4 = FIX && (P.flags & CRYCHIC_FIX_Q4);
+#if defined(CRY_PROBE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long probe_t[8];
+    const uint32_t probe_slot = (blockIdx.y * gridDim.x + blockIdx.x) * 4u + (threadIdx.x >> 6);
+#endif
+    CRY_STAMP(0);                                              // G-buffer texels arrived
     const f3 posW{ G0.x, G0.y, G0.z };                         // GBuffer.hlsl:37-41
     const float metalness = G0.w;
     const f3 albedo{ G1.x, G1.y, G1.z };
@@ -640,6 +786,19 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
     const f3 normalW = normalize3(f3{ G2.x, G2.y, G2.z });
 
     const f3 toEye{ P.EyePosW[0] - posW.x, P.EyePosW[1] - posW.y, P.EyePosW[2] - posW.z };
+    // :53-76  cascade selection and shadow factor of light 0: a wavefront that cannot take the packed lookup settles the factor here
+    const float d2Eye = dot3(toEye, toEye);
+    const float distance = len_from_sq(d2Eye);
+    float shadow0 = 1.0f;
+    int cascadeJ;
+#if defined(CRY_PROBE_NOGATHER) || defined(CRY_PROBE_NO_SHADOW)
+    const bool packedCascades = false;
+    cascadeJ = 0;
+    shadow0 = saturate(distance * 0.01f);
+#else
+    const bool packedCascades = cascade_uniform_test<ZERO_RADIUS>(P, posW, distance, fixQ1, cascadeJ);
+    if (!packedCascades) shadow0 = cascade_shadow<ZERO_RADIUS>(P, posW, distance, fixQ1);
+#endif
     const f3 view = normalize3(toEye);                          // :32
     const f3 R0{ lerpf(0.04f, albedo.x, metalness), lerpf(0.04f, albedo.y, metalness),
                  lerpf(0.04f, albedo.z, metalness) };           // :35
@@ -647,17 +806,33 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
     // :40-42; without an ambient map the fetch still runs, on a 1 x 1 stand-in (the cubemap's first bytes), so that no branch
     // separates it from the other gathers
     const bool hasAO = ambient != nullptr;
-    const AmbientFetch af = ambient_fetch_projected(P, ambient, hasAO, (const uint16_t*)cube, posW);
+#if defined(CRY_PROBE_NOGATHER) || defined(CRY_PROBE_NO_AMBIENT)
+    AmbientPairs af{ 0xFFFFFFFFu, 0xFFFFFFFFu, 0.5f, 0.5f, true, false };
+#else
+    const AmbientPairs af = ambient_fetch_projected(P, ambient, hasAO, (const uint16_t*)cube, posW);
+#endif
     const f3 r = reflect3(f3{ -view.x, -view.y, -view.z }, normalW);  // :94
-    const CubeFetch cf = cube_fetch(cube, P.cubeDim, r);        // :95
+#if defined(CRY_PROBE_NOGATHER) || defined(CRY_PROBE_NO_CUBE)
+    CubeRows cf; cf.r0 = RawPair{ f2u(r.x), f2u(r.y) }; cf.r1 = RawPair{ f2u(r.z), f2u(r.x) }; cf.fx = 0.25f; cf.fy = 0.5f; cf.i0 = 3;
+#else
+    const CubeRows cf = cube_fetch(cube, P.cubeDim, r);         // :95
+#endif
+    CRY_STAMP(1);                                               // ambient + cube gathers arrived (decode, two fetch set-ups)
 
-    // :53-76  cascade selection and shadow factor of light 0
-    const float d2Eye = dot3(toEye, toEye);
-    const float distance = len_from_sq(d2Eye);
-    float shadow0;
-    if (!cascade_shadow_uniform<ZERO_RADIUS>(P, posW, distance, fixQ1, shadow0)) shadow0 = cascade_shadow<ZERO_RADIUS>(P, posW, distance, fixQ1);
+    CascadeTexels ct;
+    if (packedCascades) {
+        cascade_uniform_fetch(P, posW, cascadeJ, ct);             // texels in flight with the ambient map's and the cubemap's
+#if !defined(CRY_PROBE_EARLY_LIGHTS)
+        shadow0 = cascade_uniform_resolve(P, ct);
+#endif
+    }
 
-    const float ambientAccess = hasAO ? ambient_resolve(af) : 1.0f;
+    const float ambientAccess = hasAO ? ambient_resolve(P, ambient, af) : 1.0f;
+    // the reflection lookup is filtered here as well -- every gather of the pixel has arrived with the cascades' texels -- so that
+    // what stays live across the lights is three colours and one Fresnel factor, not two texel pairs, weights and the vector
+    const f4 refl = cube_resolve<false>(cube_pick(cf, P.cubeDim));
+    const float f0 = 1.0f - saturate(dot3(normalW, r));         // LightingUtil.hlsl:54-57
+    const float f5 = f0 * f0 * f0 * f0 * f0;
     const f3 amb{ ambientAccess * P.AmbientLight[0] * albedo.x, ambientAccess * P.AmbientLight[1] * albedo.y,
                   ambientAccess * P.AmbientLight[2] * albedo.z };  // :44
 
@@ -678,27 +853,47 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
     const uint32_t dark = bounded ? P.darkLights : 0u;
     const bool shortRcp = bounded && P.unitLights;
     f3 direct{ 0.0f, 0.0f, 0.0f };
-    for (int i = 0; i < P.numDirLights; ++i) {                  // PBR.hlsl:99-106; shadowFactors[i>0] == 1 (:46-51)
+    // Lights 0 and 1 are evaluated while the cascades' texels are in flight and added once the shadow factor of light 0 is
+    // resolved: the same operations in the same accumulation order (PBR.hlsl:104-105), only earlier in time.
+#if defined(CRY_PROBE_EARLY_LIGHTS)
+    const bool first = P.numDirLights > 0 && !(dark & 1u), second = P.numDirLights > 1 && !(dark & 2u);
+    LightTerm t0{}, t1{};
+    if (first) t0 = shortRcp ? pbr_dir_light_eval<true>(P.Lights[0], albedo, roughness, metalness, normalW, view, fixQ3, fixQ4)
+                             : pbr_dir_light_eval<false>(P.Lights[0], albedo, roughness, metalness, normalW, view, fixQ3, fixQ4);
+    if (second) t1 = shortRcp ? pbr_dir_light_eval<true>(P.Lights[1], albedo, roughness, metalness, normalW, view, fixQ3, fixQ4)
+                              : pbr_dir_light_eval<false>(P.Lights[1], albedo, roughness, metalness, normalW, view, fixQ3, fixQ4);
+    if (packedCascades) shadow0 = cascade_uniform_resolve(P, ct);
+    if (first) pbr_light_add(t0, pow5(shadow0), direct);
+    if (second) pbr_light_add(t1, pow5(1.0f), direct);          // shadowFactors[1] == 1 (:46-51); 1 * x == x
+    for (int i = 2; i < P.numDirLights; ++i) {
+#else
+    for (int i = 0; i < P.numDirLights; ++i) {
+#endif                  // PBR.hlsl:99-106; shadowFactors[i>0] == 1 (:46-51)
         if ((dark >> i) & 1u) continue;
         if (shortRcp) pbr_dir_light<true>(P.Lights[i], albedo, roughness, metalness, normalW, view, i == 0 ? shadow0 : 1.0f, direct, fixQ3, fixQ4);
         else pbr_dir_light<false>(P.Lights[i], albedo, roughness, metalness, normalW, view, i == 0 ? shadow0 : 1.0f, direct, fixQ3, fixQ4);
     }
     pointLights(posW, albedo, roughness, metalness, normalW, view, direct, fixQ3, fixQ4);   // extension; a no-op in the reference configuration
 
+    CRY_STAMP(3);                                               // lights done
     f4 lit;
     const v2f d2{ direct.x, direct.y };
     const v2f tm = pow_inv_gamma2(d2 * rcp2(d2 + 1.0f)) + v2f{ amb.x, amb.y };     // :89-92 pow(x / (x + 1), 1 / 2.2), red and green packed
     lit.z = pow_inv_gamma(divf(direct.z, direct.z + 1.0f)) + amb.z;
 
-    const f4 refl = cube_resolve<false>(cf);
-    const float f0 = 1.0f - saturate(dot3(normalW, r));         // LightingUtil.hlsl:54-57
-    const float f5 = f0 * f0 * f0 * f0 * f0;
     const v2f R02{ R0.x, R0.y };
     const v2f spec = fma2(shininess * fma2(1.0f - R02, splat(f5), R02), v2f{ refl.x, refl.y }, tm);  // :97
     lit.x = spec.x;
     lit.y = spec.y;
     lit.z = fma(shininess * fma(1.0f - R0.z, f5, R0.z), refl.z, lit.z);
     lit.w = 1.0f;                                               // :99
+    CRY_STAMP(4);                                               // tone map (table loads) + reflection done
+#if defined(CRY_PROBE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
+    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) {
+        unsigned long long* slot = g_probe + 8ull * probe_slot;
+        for (int k = 0; k < 5; ++k) slot[2 + k] = probe_t[k];
+    }
+#endif
     return lit;
 }
 

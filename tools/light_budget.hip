@@ -33,8 +33,8 @@ SECTION(ambient)        // :40-42: projection to the ambient map, four texel loa
 {
     IDX;
     const f4a G0 = in[idx], b = in[idx + 1000000u], c = in[idx + 2000000u];
-    const AmbientFetch af = ambient_fetch_projected(P, ambient, true, (const uint16_t*)cube, f3{ G0.x, G0.y, G0.z });
-    const float a = ambient_resolve(af);
+    const AmbientPairs af = ambient_fetch_projected(P, ambient, true, (const uint16_t*)cube, f3{ G0.x, G0.y, G0.z });
+    const float a = ambient_resolve(P, ambient, af);
     out[idx] = f4a{ a * P.AmbientLight[0] * b.x, a * P.AmbientLight[1] * b.y, a * P.AmbientLight[2] * b.z, c.x };
 }
 SECTION(cube_fetch)     // :94-95 reflect + face selection + footprint addresses + two 8-byte loads
@@ -42,16 +42,16 @@ SECTION(cube_fetch)     // :94-95 reflect + face selection + footprint addresses
     IDX;
     const f4a v = in[idx], n = in[idx + 1000000u], c = in[idx + 2000000u];
     const f3 r = reflect3(f3{ -v.x, -v.y, -v.z }, f3{ n.x, n.y, n.z });
-    const CubeFetch cf = cube_fetch(cube, P.cubeDim, r);
-    out[idx] = f4a{ u2f(cf.p0.a), u2f(cf.p0.b ^ cf.p1.a), u2f(cf.p1.b), cf.fx + cf.fy + c.x };
+    const CubeRows cf = cube_fetch(cube, P.cubeDim, r);
+    out[idx] = f4a{ u2f(cf.r0.lo), u2f(cf.r0.hi ^ cf.r1.lo), u2f(cf.r1.hi), cf.fx + cf.fy + c.x + (float)cf.i0 };
 }
 SECTION(cube_resolve)   // :95-97 decode + filter of the footprint, Schlick fresnel, the specular mad
 {
     IDX;
     const f4a t = in[idx], n = in[idx + 1000000u], r = in[idx + 2000000u];
-    CubeFetch cf;
-    cf.p0 = TexelPair{ f2u(t.x), f2u(t.y) }; cf.p1 = TexelPair{ f2u(t.z), f2u(t.w) }; cf.fx = n.w; cf.fy = r.w;
-    const f4 refl = cube_resolve<false>(cf);
+    CubeRows cf;
+    cf.r0 = RawPair{ f2u(t.x), f2u(t.y) }; cf.r1 = RawPair{ f2u(t.z), f2u(t.w) }; cf.fx = n.w; cf.fy = r.w; cf.i0 = (int)threadIdx.x;
+    const f4 refl = cube_resolve<false>(cube_pick(cf, P.cubeDim));
     const float f0 = 1.0f - saturate(dot3(f3{ n.x, n.y, n.z }, f3{ r.x, r.y, r.z }));
     const float f5 = f0 * f0 * f0 * f0 * f0;
     const float sh = 1.0f - t.w;
@@ -63,7 +63,9 @@ SECTION(cascade)        // :53-76 on the wave-uniform path: two cascade lookups 
     IDX;
     const f4a G0 = in[idx], b = in[idx + 1000000u], c = in[idx + 2000000u];
     float s = 1.0f;
-    cascade_shadow_uniform<true>(P, f3{ G0.x, G0.y, G0.z }, b.x, false, s);
+    CascadeTexels ct;
+    int J;
+    if (cascade_uniform_test<true>(P, f3{ G0.x, G0.y, G0.z }, b.x, false, J)) { cascade_uniform_fetch(P, f3{ G0.x, G0.y, G0.z }, J, ct); s = cascade_uniform_resolve(P, ct); }
     out[idx] = f4a{ s, b.y, c.x, c.y };
 }
 SECTION(guard)          // "dark lights": the input bounds of the wavefront
