@@ -282,11 +282,7 @@ static constexpr float kGammaPowScale[256] = CRY_GAMMA_POW_SCALE;
 CRY_HD float pow_inv_gamma(float x)
 {
     const uint32_t b = f2u(x);
-#if defined(CRY_PROBE_POW_FIXED)
-    const float scale = kGammaPowScale[100];
-#else
     const float scale = kGammaPowScale[(b >> 23) & 255u];
-#endif
     const float u = u2f((b & 0x007FFFFFu) | 0x3F800000u) - 1.0f;       // exact
     float p = kGammaPowCoef[7];
 #pragma unroll
@@ -299,11 +295,7 @@ CRY_HD float pow_inv_gamma(float x)
 CRY_HD v2f pow_inv_gamma2(v2f x)
 {
     const uint32_t b0 = f2u(x.x), b1 = f2u(x.y);
-#if defined(CRY_PROBE_POW_FIXED)
-    const v2f scale{ kGammaPowScale[100], kGammaPowScale[101] };
-#else
     const v2f scale{ kGammaPowScale[(b0 >> 23) & 255u], kGammaPowScale[(b1 >> 23) & 255u] };
-#endif
     const v2f u = v2f{ u2f((b0 & 0x007FFFFFu) | 0x3F800000u), u2f((b1 & 0x007FFFFFu) | 0x3F800000u) } - 1.0f;
     v2f p = splat(kGammaPowCoef[7]);
 #pragma unroll

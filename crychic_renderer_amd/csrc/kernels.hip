@@ -4,7 +4,6 @@
 // wavefront so every plane access is a contiguous 64-lane burst (16 B/lane on the fp32 G-buffer planes,
 // 8 B/lane on the fp16 normal plane and the depth row pairs), 4 rows per 256-thread workgroup.
 #include <hip/hip_runtime.h>
-#include <cstdlib>
 #include "kernels.hpp"
 #include "ssao_core.hpp"
 #include "blur_tiles.hpp"
@@ -346,13 +345,8 @@ __global__ __launch_bounds__(512) void blur_replay_kernel(crychic_ssao_constants
 
 // ---- deferred lighting -----------------------------------------------------------------------------------------
 // Shaders/DeferredShading.hlsl:23-101 as a full-screen pass over rows [row0, row1), masked by depth < 1.
-#if defined(CRY_PROBE_WAVES8)
-#define CRY_LIGHT_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
-#else
-#define CRY_LIGHT_ATTR
-#endif
 template <bool ZERO_RADIUS, bool FIX>
-__global__ __launch_bounds__(256) CRY_LIGHT_ATTR void light_kernel(LightParams P, const f4a* __restrict__ g0,
+__global__ __launch_bounds__(256) void light_kernel(LightParams P, const f4a* __restrict__ g0,
                                                     const f4a* __restrict__ g1, const f4a* __restrict__ g2,
                                                     const uint32_t* __restrict__ depth,
                                                     const uint16_t* __restrict__ ambient,
@@ -366,28 +360,10 @@ __global__ __launch_bounds__(256) CRY_LIGHT_ATTR void light_kernel(LightParams P
     if (x >= P.W || y >= row1) return;
     const uint32_t idx = y * P.W + x;
     f4 lit;
-#if defined(CRY_PROBE_TIMING)
-    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
-    const uint32_t dprobe = depth[idx];
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    const unsigned long long t_depth = __builtin_amdgcn_s_memtime();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    if ((threadIdx.x & 63u) == 0) { unsigned long long* slot = g_probe + 8ull * ((blockIdx.y * gridDim.x + blockIdx.x) * 4u + (threadIdx.x >> 6)); slot[0] = t_entry; slot[1] = t_depth; slot[2] = 0ull; }
-#endif
-#if defined(CRY_PROBE_SPEC_G)
-    const f4a sG0 = g0[idx], sG1 = g1[idx], sG2 = g2[idx];
-#define CRY_G(k) sG##k
-#else
-#define CRY_G(k) g##k[idx]
-#endif
     // coverage: the reference re-rasterises the opaque items with LESS against depth cleared to 1.0
     // (CRYCHIC.cpp:248,273) -- exactly the pixels whose normal/depth pass depth is below the clear value.
     if ((depth[idx] & 0x00FFFFFFu) < 0x00FFFFFFu) {
-#if defined(CRY_PROBE_STREAM)
-        { const f4a a = CRY_G(0), b = CRY_G(1), c = CRY_G(2); lit = f4{ a.x + b.x + c.x, a.y + b.y + c.y, a.z + b.z + c.z, a.w + b.w + c.w }; }
-#else
-        lit = light_pixel<ZERO_RADIUS, NoPointLights, FIX>(P, CRY_G(0), CRY_G(1), CRY_G(2), ambient, cube);
-#endif
+        lit = light_pixel<ZERO_RADIUS, NoPointLights, FIX>(P, g0[idx], g1[idx], g2[idx], ambient, cube);
     } else if (P.flags & CRYCHIC_LIGHT_SKY) {
         lit = sky_pixel(P, cube, x, y);
     } else {
@@ -395,58 +371,6 @@ __global__ __launch_bounds__(256) CRY_LIGHT_ATTR void light_kernel(LightParams P
     }
     if (radiance) radiance[idx] = f4a{ lit.x, lit.y, lit.z, lit.w };
     out[idx] = pack_rgba8(lit);
-}
-#if defined(CRY_PROBE_TIMING)
-extern "C" int crychic_probe_read(unsigned long long* out, int nwaves)
-{
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_probe), sizeof(unsigned long long) * 8 * (size_t)nwaves) == hipSuccess ? 0 : -1;
-}
-#endif
-
-// The same pass, RPW rows per wavefront (the benchmark's lighting kernel).  A lit wavefront of light_kernel lives through four
-// dependent memory round trips -- depth, G-buffer, the gathers (ambient map, cubemap, two shadow cascades), the tone map's table --
-// around ~500 VALU instructions, 5.8 us in all, and the pass takes (wavefronts / resident slots) x that lifetime: the gathers
-// alone cost 25 of its 76 us although they move almost nothing (tools/probes: a build without them runs in 51 us, a build with no
-// arithmetic at all in 46; profiles/r04_experiments.txt).  Here a wavefront owns a 64-pixel column segment of RPW consecutive
-// rows: the depth texels of all its rows are one burst of loads, and the G-buffer texels of row k + 1 are requested before row k
-// is lit, so that per row only the gathers' round trip is still exposed.  Same light_pixel, same operands: the same bits.
-template <bool ZERO_RADIUS, bool FIX, int RPW>
-__global__ __launch_bounds__(256) void light_rows_kernel(LightParams P, const f4a* __restrict__ g0, const f4a* __restrict__ g1,
-                                                         const f4a* __restrict__ g2, const uint32_t* __restrict__ depth,
-                                                         const uint16_t* __restrict__ ambient, const uint32_t* __restrict__ cube,
-                                                         uint32_t* __restrict__ out, f4a* __restrict__ radiance, uint32_t row0, uint32_t row1)
-{
-    const uint32_t x = blockIdx.x * 64u + (threadIdx.x & 63u);
-    const uint32_t y0 = row0 + (blockIdx.y * 4u + (threadIdx.x >> 6)) * (uint32_t)RPW;
-    if (x >= P.W || y0 >= row1) return;
-    const uint32_t nrows = (row1 - y0) < (uint32_t)RPW ? (row1 - y0) : (uint32_t)RPW;      // wave-uniform
-    uint32_t idx = y0 * P.W + x;
-    uint32_t d[RPW];
-#pragma unroll
-    for (int r = 0; r < RPW; ++r) d[r] = (uint32_t)r < nrows ? depth[idx + (uint32_t)r * P.W] : 0x00FFFFFFu;
-    // coverage: the reference re-rasterises the opaque items with LESS against depth cleared to 1.0 (CRYCHIC.cpp:248,273) -- exactly
-    // the pixels whose normal/depth pass depth is below the clear value
-    f4a n0{ 0, 0, 0, 0 }, n1{ 0, 0, 0, 0 }, n2{ 0, 0, 0, 0 };
-    if ((d[0] & 0x00FFFFFFu) < 0x00FFFFFFu) { n0 = g0[idx]; n1 = g1[idx]; n2 = g2[idx]; }
-#pragma unroll 1
-    for (uint32_t r = 0; r < nrows; ++r, idx += P.W) {
-        const bool covered = (d[0] & 0x00FFFFFFu) < 0x00FFFFFFu;
-        const f4a G0 = n0, G1 = n1, G2 = n2;
-#pragma unroll
-        for (int k = 0; k + 1 < RPW; ++k) d[k] = d[k + 1];       // d[0] = the next row's texel (rows past the strip: the clear depth)
-        if (RPW > 1) d[RPW - 1] = 0x00FFFFFFu;
-        if (RPW > 1 && (d[0] & 0x00FFFFFFu) < 0x00FFFFFFu) { n0 = g0[idx + P.W]; n1 = g1[idx + P.W]; n2 = g2[idx + P.W]; }      // in flight while this row is lit
-        f4 lit;
-        if (covered) {
-            lit = light_pixel<ZERO_RADIUS, NoPointLights, FIX>(P, G0, G1, G2, ambient, cube);
-        } else if (P.flags & CRYCHIC_LIGHT_SKY) {
-            lit = sky_pixel(P, cube, x, y0 + r);
-        } else {
-            lit = f4{ 0.690196097f, 0.768627524f, 0.870588303f, 1.0f };  // Colors::LightSteelBlue, CRYCHIC.cpp:247
-        }
-        if (radiance) radiance[idx] = f4a{ lit.x, lit.y, lit.z, lit.w };
-        out[idx] = pack_rgba8(lit);
-    }
 }
 
 // ---- deferred lighting with point lights (extension, BASELINE configs[4]) ------------------------------------------
@@ -665,28 +589,7 @@ hipError_t launch_light(const LightParams& P, const float* g0, const float* g1, 
         return hipGetLastError();
     }
     const bool fix = (P.flags & (CRYCHIC_FIX_Q1 | CRYCHIC_FIX_Q3 | CRYCHIC_FIX_Q4)) != 0;
-#if defined(CRY_PROBE_RPW)
-    {
-#if defined(CRY_PROBE_RPW)
-        constexpr int RPW = CRY_PROBE_RPW;
-#else
-        constexpr int RPW = 4;
-#endif
-        const dim3 rgrid((P.W + 63u) / 64u, (rows + 4u * RPW - 1u) / (4u * RPW), 1);
-#define CRY_LAUNCH_ROWS(K) hipLaunchKernelGGL(K, rgrid, dim3(256), 0, stream, P, (const f4a*)g0, (const f4a*)g1, (const f4a*)g2, depth, ambient, \
-                                              (const uint32_t*)cube, (uint32_t*)out, (f4a*)radiance, row0, row0 + rows)
-        if (P.pcfSearchRadius == 0.0f) { if (fix) CRY_LAUNCH_ROWS((light_rows_kernel<true, true, RPW>)); else CRY_LAUNCH_ROWS((light_rows_kernel<true, false, RPW>)); }
-        else { if (fix) CRY_LAUNCH_ROWS((light_rows_kernel<false, true, RPW>)); else CRY_LAUNCH_ROWS((light_rows_kernel<false, false, RPW>)); }
-#undef CRY_LAUNCH_ROWS
-        return hipGetLastError();
-    }
-#endif
-#if defined(CRY_PROBE_LDS_CAP)
-    static const unsigned probeLds = getenv("CRY_PROBE_LDS") ? (unsigned)atoi(getenv("CRY_PROBE_LDS")) : 0u;
-#else
-    const unsigned probeLds = 0u;
-#endif
-#define CRY_LAUNCH_LIGHT(K) hipLaunchKernelGGL(K, grid, dim3(256), probeLds, stream, P, (const f4a*)g0, (const f4a*)g1, (const f4a*)g2, depth, ambient, \
+#define CRY_LAUNCH_LIGHT(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, P, (const f4a*)g0, (const f4a*)g1, (const f4a*)g2, depth, ambient, \
                                                (const uint32_t*)cube, (uint32_t*)out, (f4a*)radiance, row0, row0 + rows)
     if (P.pcfSearchRadius == 0.0f) { if (fix) CRY_LAUNCH_LIGHT((light_kernel<true, true>)); else CRY_LAUNCH_LIGHT((light_kernel<true, false>)); }
     else { if (fix) CRY_LAUNCH_LIGHT((light_kernel<false, true>)); else CRY_LAUNCH_LIGHT((light_kernel<false, false>)); }

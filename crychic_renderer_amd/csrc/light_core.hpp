@@ -230,9 +230,9 @@ CRY_HD float pow5(float x) { float x2 = x * x, x4 = x2 * x2; return x4 * x; }
 // BOUNDED: a promise that the pixel passed light_dark_guard() and that the light direction is no longer than 1.001 (light_dark_mask's
 // test) -- then every reciprocal below has a normal argument with a normal result (the Smith denominators lie in [0.13, 15.2],
 // nDotl * nDotv in [1e-6, 1.01], pi * tt^2 in [2.5e-6, 3.2e4]: see "dark lights"), where rcp_normal IS rcp, two instructions shorter.
-// ... in two steps, so that a caller can evaluate a light before its shadow factor is known (light_pixel: the BRDF of light 0
-// runs while the shadow cascades' texels are in flight): pbr_light_eval computes brdf and strength * nDotl (* att), pbr_light_add
-// applies result = mad(scale * brdf, lightStrength, result) -- the shader's own operations in the shader's own order.
+// ... in two steps: pbr_light_eval computes brdf and strength * nDotl (* att), pbr_light_add applies
+// result = mad(scale * brdf, lightStrength, result) -- the shader's own operations in the shader's own order.  (Evaluating
+// lights ahead of the shadow factor's resolve, to hide the cascades' round trip, was measured and lost: profiles/r04_experiments.txt.)
 struct LightTerm { v2f brdfRG, lsRG; float brdfB, lsB; };
 template <bool POINT, bool BOUNDED = false>
 CRY_HD LightTerm pbr_light_eval(f3 lightDir, const float* strength, float att, f3 albedo, float roughness, float metalness, f3 normal,
@@ -303,13 +303,6 @@ CRY_HD void pbr_light(f3 lightDir, const float* strength, float att, f3 albedo, 
 }
 
 // One directional light of PBRShading (PBR.hlsl:99-106).
-template <bool BOUNDED = false>
-CRY_HD LightTerm pbr_dir_light_eval(const crychic_light& L, f3 albedo, float roughness, float metalness, f3 normal, f3 view, bool fixQ3 = false,
-                                    bool fixQ4 = false)
-{
-    return pbr_light_eval<false, BOUNDED>(f3{ -L.Direction[0], -L.Direction[1], -L.Direction[2] }, L.Strength, 1.0f, albedo, roughness, metalness, normal,
-                                          view, fixQ3, fixQ4);
-}
 template <bool BOUNDED = false>
 CRY_HD void pbr_dir_light(const crychic_light& L, f3 albedo, float roughness, float metalness, f3 normal, f3 view,
                           float shadow, f3& result, bool fixQ3 = false, bool fixQ4 = false)
@@ -756,15 +749,6 @@ CRY_HD float cascade_uniform_resolve(const LightParams& P, const CascadeTexels& 
     return 0.5f * (pcf_zero_radius(a) + pcf_zero_radius(b));     // :66
 }
 
-#if defined(CRY_PROBE_TIMING) && defined(__HIPCC__)
-static __device__ unsigned long long g_probe[8 * 140000];      // probe build only (tools/probes/variants.sh): stage time stamps per wavefront (4K: 129600)
-static __device__ uint32_t g_probe_wave;                       // set by the kernel before light_pixel: this wavefront's slot
-#endif
-#if defined(CRY_PROBE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
-#define CRY_STAMP(k) do { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); probe_t[k] = __builtin_amdgcn_s_memtime(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } while (0)
-#else
-#define CRY_STAMP(k) do { } while (0)
-#endif
 // DeferredShading.hlsl:23-101 for one covered pixel.  Every gather of the pixel -- ambient map, cubemap, shadow cascades -- is
 // issued before the first is waited for (one memory round trip instead of one per lookup).
 // FIX: a compile-time promise that P.flags may carry CRYCHIC_FIX_* bits; false = the reference as written, with no trace of
@@ -774,11 +758,6 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
                       const uint32_t* __restrict__ cube, PointLights pointLights = PointLights())
 {
     const bool fixQ1 = FIX && (P.flags & CRYCHIC_FIX_Q1), fixQ3 = FIX && (P.flags & CRYCHIC_FIX_Q3), fixQ4 = FIX && (P.flags & CRYCHIC_FIX_Q4);
-#if defined(CRY_PROBE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
-    unsigned long long probe_t[8];
-    const uint32_t probe_slot = (blockIdx.y * gridDim.x + blockIdx.x) * 4u + (threadIdx.x >> 6);
-#endif
-    CRY_STAMP(0);                                              // G-buffer texels arrived
     const f3 posW{ G0.x, G0.y, G0.z };                         // GBuffer.hlsl:37-41
     const float metalness = G0.w;
     const f3 albedo{ G1.x, G1.y, G1.z };
@@ -791,14 +770,8 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
     const float distance = len_from_sq(d2Eye);
     float shadow0 = 1.0f;
     int cascadeJ;
-#if defined(CRY_PROBE_NOGATHER) || defined(CRY_PROBE_NO_SHADOW)
-    const bool packedCascades = false;
-    cascadeJ = 0;
-    shadow0 = saturate(distance * 0.01f);
-#else
     const bool packedCascades = cascade_uniform_test<ZERO_RADIUS>(P, posW, distance, fixQ1, cascadeJ);
     if (!packedCascades) shadow0 = cascade_shadow<ZERO_RADIUS>(P, posW, distance, fixQ1);
-#endif
     const f3 view = normalize3(toEye);                          // :32
     const f3 R0{ lerpf(0.04f, albedo.x, metalness), lerpf(0.04f, albedo.y, metalness),
                  lerpf(0.04f, albedo.z, metalness) };           // :35
@@ -806,25 +779,14 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
     // :40-42; without an ambient map the fetch still runs, on a 1 x 1 stand-in (the cubemap's first bytes), so that no branch
     // separates it from the other gathers
     const bool hasAO = ambient != nullptr;
-#if defined(CRY_PROBE_NOGATHER) || defined(CRY_PROBE_NO_AMBIENT)
-    AmbientPairs af{ 0xFFFFFFFFu, 0xFFFFFFFFu, 0.5f, 0.5f, true, false };
-#else
     const AmbientPairs af = ambient_fetch_projected(P, ambient, hasAO, (const uint16_t*)cube, posW);
-#endif
     const f3 r = reflect3(f3{ -view.x, -view.y, -view.z }, normalW);  // :94
-#if defined(CRY_PROBE_NOGATHER) || defined(CRY_PROBE_NO_CUBE)
-    CubeRows cf; cf.r0 = RawPair{ f2u(r.x), f2u(r.y) }; cf.r1 = RawPair{ f2u(r.z), f2u(r.x) }; cf.fx = 0.25f; cf.fy = 0.5f; cf.i0 = 3;
-#else
     const CubeRows cf = cube_fetch(cube, P.cubeDim, r);         // :95
-#endif
-    CRY_STAMP(1);                                               // ambient + cube gathers arrived (decode, two fetch set-ups)
 
     CascadeTexels ct;
     if (packedCascades) {
         cascade_uniform_fetch(P, posW, cascadeJ, ct);             // texels in flight with the ambient map's and the cubemap's
-#if !defined(CRY_PROBE_EARLY_LIGHTS)
         shadow0 = cascade_uniform_resolve(P, ct);
-#endif
     }
 
     const float ambientAccess = hasAO ? ambient_resolve(P, ambient, af) : 1.0f;
@@ -853,29 +815,12 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
     const uint32_t dark = bounded ? P.darkLights : 0u;
     const bool shortRcp = bounded && P.unitLights;
     f3 direct{ 0.0f, 0.0f, 0.0f };
-    // Lights 0 and 1 are evaluated while the cascades' texels are in flight and added once the shadow factor of light 0 is
-    // resolved: the same operations in the same accumulation order (PBR.hlsl:104-105), only earlier in time.
-#if defined(CRY_PROBE_EARLY_LIGHTS)
-    const bool first = P.numDirLights > 0 && !(dark & 1u), second = P.numDirLights > 1 && !(dark & 2u);
-    LightTerm t0{}, t1{};
-    if (first) t0 = shortRcp ? pbr_dir_light_eval<true>(P.Lights[0], albedo, roughness, metalness, normalW, view, fixQ3, fixQ4)
-                             : pbr_dir_light_eval<false>(P.Lights[0], albedo, roughness, metalness, normalW, view, fixQ3, fixQ4);
-    if (second) t1 = shortRcp ? pbr_dir_light_eval<true>(P.Lights[1], albedo, roughness, metalness, normalW, view, fixQ3, fixQ4)
-                              : pbr_dir_light_eval<false>(P.Lights[1], albedo, roughness, metalness, normalW, view, fixQ3, fixQ4);
-    if (packedCascades) shadow0 = cascade_uniform_resolve(P, ct);
-    if (first) pbr_light_add(t0, pow5(shadow0), direct);
-    if (second) pbr_light_add(t1, pow5(1.0f), direct);          // shadowFactors[1] == 1 (:46-51); 1 * x == x
-    for (int i = 2; i < P.numDirLights; ++i) {
-#else
-    for (int i = 0; i < P.numDirLights; ++i) {
-#endif                  // PBR.hlsl:99-106; shadowFactors[i>0] == 1 (:46-51)
+    for (int i = 0; i < P.numDirLights; ++i) {                  // PBR.hlsl:99-106; shadowFactors[i>0] == 1 (:46-51)
         if ((dark >> i) & 1u) continue;
         if (shortRcp) pbr_dir_light<true>(P.Lights[i], albedo, roughness, metalness, normalW, view, i == 0 ? shadow0 : 1.0f, direct, fixQ3, fixQ4);
         else pbr_dir_light<false>(P.Lights[i], albedo, roughness, metalness, normalW, view, i == 0 ? shadow0 : 1.0f, direct, fixQ3, fixQ4);
     }
     pointLights(posW, albedo, roughness, metalness, normalW, view, direct, fixQ3, fixQ4);   // extension; a no-op in the reference configuration
-
-    CRY_STAMP(3);                                               // lights done
     f4 lit;
     const v2f d2{ direct.x, direct.y };
     const v2f tm = pow_inv_gamma2(d2 * rcp2(d2 + 1.0f)) + v2f{ amb.x, amb.y };     // :89-92 pow(x / (x + 1), 1 / 2.2), red and green packed
@@ -887,13 +832,6 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
     lit.y = spec.y;
     lit.z = fma(shininess * fma(1.0f - R0.z, f5, R0.z), refl.z, lit.z);
     lit.w = 1.0f;                                               // :99
-    CRY_STAMP(4);                                               // tone map (table loads) + reflection done
-#if defined(CRY_PROBE_TIMING) && defined(__HIP_DEVICE_COMPILE__)
-    if (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) == 0) {
-        unsigned long long* slot = g_probe + 8ull * probe_slot;
-        for (int k = 0; k < 5; ++k) slot[2 + k] = probe_t[k];
-    }
-#endif
     return lit;
 }
 
