@@ -78,8 +78,7 @@ using cry::clamp_rows;
 
 int ssao_compute_impl(const crychic_ssao_constants* cb, const void* normal, const uint32_t* depth,
                       const uint8_t* randvec, uint16_t* ambient0, uint16_t* ambient1, void* edge, uint32_t W,
-                      uint32_t H, int blurCount, uint32_t row0, uint32_t rows, hipStream_t stream, hipEvent_t afterSsao,
-                      cry::LightHints* hints = nullptr)
+                      uint32_t H, int blurCount, uint32_t row0, uint32_t rows, hipStream_t stream, hipEvent_t afterSsao)
 {
     const uint32_t h2 = H / 2;
     if (row0 > h2 || rows > h2 - row0) return fail(CRYCHIC_E_INVALID_ARG, "rows [%u,+%u) outside the %u-row ambient map", row0, rows, h2);
@@ -97,13 +96,6 @@ int ssao_compute_impl(const crychic_ssao_constants* cb, const void* normal, cons
     // SSAO kernel gains 15: the pairs plane stays)
     const bool usePairs = edge != nullptr;
     if (edge) CRY_HIP(cry::launch_depth_pairs(*cb, depth, edge, W, H, stamp, usePairs, r0, rn, stream));
-    if (edge && hints) {      // what the depth pass just wrote about this depth plane, for the lighting pass of the same frame (kernels.hpp)
-        uint32_t c0, cn;
-        cry::depth_pass_cell_rows(H, r0, rn, &c0, &cn);
-        const int y0 = 8 * (int)c0 - 2, y1 = 8 * (int)(c0 + cn) - 2;
-        *hints = cry::LightHints{ cry::edge_plane_carve(edge, W, H).geo, stamp, y0 < 0 ? 0 : y0, y1 > (int)H ? (int)H : y1 };
-        if (cn == 0) hints->geo = nullptr;
-    }
     CRY_HIP(cry::launch_ssao(*cb, normal, depth, randvec, planes[cry::blur_chain_ssao_plane(blurCount)], edge, W, H, r0, rn, true, usePairs,
                              edge ? stamp : 0u, stream));
     if (afterSsao) CRY_HIP(hipEventRecord(afterSsao, stream));
@@ -320,7 +312,6 @@ int crychic_draw_hot_path(crychic_ctx* ctx, const crychic_ssao_constants* ssaoCB
     P.pointLights = f->point_lights_dev;
     P.numPointLights = f->numPointLights;
     const bool prof = ctx->profiling;
-    cry::LightHints hints{ nullptr, 0u, 0, 0 };
     if (prof) { ctx->times_valid = false; CRY_HIP(hipEventRecord(ctx->ev[0], stream)); }
     if (ssaoOn) {
         // The lighting pass filters the half-res AO map bilinearly at (about) its own pixel centre
@@ -329,13 +320,13 @@ int crychic_draw_hot_path(crychic_ctx* ctx, const crychic_ssao_constants* ssaoCB
         clamp_rows(H / 2, (int64_t)(f->row0 / 2) - 2, (int64_t)((f->row0 + f->rows + 1) / 2) + 2, &a0, &an);
         if (int rc = ssao_compute_impl(ssaoCB, f->normal_dev, f->depth_dev, f->randvec_dev, f->ambient0_dev,
                                        f->ambient1_dev, f->edge_dev, W, H, f->blurCount, a0, an, stream,
-                                       prof ? ctx->ev[1] : nullptr, &hints)) return rc;
+                                       prof ? ctx->ev[1] : nullptr)) return rc;
     } else if (prof) {
         CRY_HIP(hipEventRecord(ctx->ev[1], stream));
     }
     if (prof) CRY_HIP(hipEventRecord(ctx->ev[2], stream));
     CRY_HIP(cry::launch_light(P, f->g0_dev, f->g1_dev, f->g2_dev, f->depth_dev, ssaoOn ? f->ambient0_dev : nullptr,
-                              f->cube_dev, f->out_rgba8_dev, nullptr, f->row0, f->rows, stream, hints));
+                              f->cube_dev, f->out_rgba8_dev, nullptr, f->row0, f->rows, stream));
     if (prof) { CRY_HIP(hipEventRecord(ctx->ev[3], stream)); ctx->times_valid = true; }
     return 0;
 }

@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void light_kernel(LightParams P, const f4a* __
                                                     const uint32_t* __restrict__ depth,
                                                     const uint16_t* __restrict__ ambient,
                                                     const uint32_t* __restrict__ cube, uint32_t* __restrict__ out,
-                                                    f4a* __restrict__ radiance, uint32_t row0, uint32_t row1, LightHints hints)
+                                                    f4a* __restrict__ radiance, uint32_t row0, uint32_t row1)
 {
     uint32_t bx, by;
     tile_origin<0>(bx, by);
@@ -359,27 +359,7 @@ __global__ __launch_bounds__(256) void light_kernel(LightParams P, const f4a* __
     const uint32_t y = row0 + by * 4u + (threadIdx.x >> 6);
     if (x >= P.W || y >= row1) return;
     const uint32_t idx = y * P.W + x;
-    // Coverage hint (kernels.hpp LightHints): the 64 pixels of this wavefront lie in one row of the coarse geometry map and in at most
-    // two of its cells (a cell covers texel columns [128 c - 2, 128 c + 126)); if the depth pass of this frame visited that cell
-    // row completely and stamped neither cell, every texel here holds the clear depth: no pixel is covered, and the wavefront
-    // does not wait for the depth plane to learn it (a sky wavefront's whole life is that one round trip).
-    bool knownSky = false;
-    if (hints.geo) {
-        const uint32_t wy = (uint32_t)__builtin_amdgcn_readfirstlane((int)y), cy = wy >> 5;
-        const int cellEnd = (int)(32u * cy + 32u) < (int)P.H ? (int)(32u * cy + 32u) : (int)P.H;
-        if ((int)(32u * cy) >= hints.y0 && cellEnd <= hints.y1) {
-            const uint32_t xl = bx * 64u + 63u < P.W ? bx * 64u + 63u : P.W - 1u;
-            const uint32_t c0 = (bx * 64u + 2u) >> 7, c1 = (xl + 2u) >> 7, pitch = geo_map_cols(P.W);
-            knownSky = hints.geo[cy * pitch + c0] != hints.stamp && hints.geo[cy * pitch + c1] != hints.stamp;
-        }
-    }
     f4 lit;
-    if (knownSky) {
-        lit = (P.flags & CRYCHIC_LIGHT_SKY) ? sky_pixel(P, cube, x, y) : f4{ 0.690196097f, 0.768627524f, 0.870588303f, 1.0f };
-        if (radiance) radiance[idx] = f4a{ lit.x, lit.y, lit.z, lit.w };
-        out[idx] = pack_rgba8(lit);
-        return;
-    }
     // coverage: the reference re-rasterises the opaque items with LESS against depth cleared to 1.0
     // (CRYCHIC.cpp:248,273) -- exactly the pixels whose normal/depth pass depth is below the clear value.
     if ((depth[idx] & 0x00FFFFFFu) < 0x00FFFFFFu) {
@@ -595,7 +575,7 @@ hipError_t launch_blur_replay(const crychic_ssao_constants& cb, const void* edge
 
 hipError_t launch_light(const LightParams& P, const float* g0, const float* g1, const float* g2,
                         const uint32_t* depth, const uint16_t* ambient, const uint8_t* cube, uint8_t* out,
-                        float* radiance, uint32_t row0, uint32_t rows, hipStream_t stream, const LightHints& hints)
+                        float* radiance, uint32_t row0, uint32_t rows, hipStream_t stream)
 {
     if (rows == 0) return hipSuccess;
     const dim3 grid = grid_for(P.W, rows);
@@ -610,7 +590,7 @@ hipError_t launch_light(const LightParams& P, const float* g0, const float* g1, 
     }
     const bool fix = (P.flags & (CRYCHIC_FIX_Q1 | CRYCHIC_FIX_Q3 | CRYCHIC_FIX_Q4)) != 0;
 #define CRY_LAUNCH_LIGHT(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, P, (const f4a*)g0, (const f4a*)g1, (const f4a*)g2, depth, ambient, \
-                                               (const uint32_t*)cube, (uint32_t*)out, (f4a*)radiance, row0, row0 + rows, hints)
+                                               (const uint32_t*)cube, (uint32_t*)out, (f4a*)radiance, row0, row0 + rows)
     if (P.pcfSearchRadius == 0.0f) { if (fix) CRY_LAUNCH_LIGHT((light_kernel<true, true>)); else CRY_LAUNCH_LIGHT((light_kernel<true, false>)); }
     else { if (fix) CRY_LAUNCH_LIGHT((light_kernel<false, true>)); else CRY_LAUNCH_LIGHT((light_kernel<false, false>)); }
 #undef CRY_LAUNCH_LIGHT

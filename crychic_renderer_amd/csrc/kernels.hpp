@@ -34,14 +34,9 @@ hipError_t launch_blur_pair(const crychic_ssao_constants& cb, const void* edge_b
 hipError_t launch_blur_replay(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out, uint32_t W, uint32_t H,
                               uint32_t row0, uint32_t rows, uint32_t stamp, hipStream_t stream);
 
-// Coverage hints for the lighting pass from the SSAO depth pass of the SAME frame over the SAME depth plane (launch_depth_pairs with
-// `stamp`): the coarse geometry map (ssao_core.hpp: one word per 128 x 32 depth texels, = stamp when the cell holds a texel below
-// the clear depth) for the depth texel rows [y0, y1).  A lighting wavefront whose cells are all known and unstamped shades no
-// pixel -- every texel there is at the clear depth -- and does not read the depth plane at all.  geo == nullptr: no hints.
-struct LightHints { const uint32_t* geo; uint32_t stamp; int y0, y1; };
 hipError_t launch_light(const LightParams& P, const float* g0, const float* g1, const float* g2,
                         const uint32_t* depth, const uint16_t* ambient, const uint8_t* cube, uint8_t* out,
-                        float* radiance, uint32_t row0, uint32_t rows, hipStream_t stream, const LightHints& hints = LightHints{ nullptr, 0u, 0, 0 });
+                        float* radiance, uint32_t row0, uint32_t rows, hipStream_t stream);
 
 
 // ---- producer passes (raster.hip) ----

@@ -562,58 +562,6 @@ def test_sky_shortcut_on_device(ctx, built_lib, oracle, seed):
         assert np.array_equal(dev_u16(a0), oracle.compute_ssao(scb, normal2, depth2, randvec, blur_count)), blur_count
 
 
-@pytest.mark.parametrize("seed", [0, 3, 12, 13, 14])
-def test_light_coverage_hints_on_device(ctx, built_lib, oracle, seed):
-    """The lighting pass's coverage hints (kernels.hpp LightHints: wavefronts whose cells of the SSAO depth pass's coarse geometry map
-    are unstamped skip the depth plane) through crychic_draw_hot_path, on the sky-probe frames -- small patches of geometry in a
-    sky field, for seeds >= 12 hugging the corners of the map's 128 x 32 cells (columns offset by -2) -- with and without the sky
-    fill, whole and in strips whose depth pass visits only part of the frame, and again on the same workspace with sky and geometry
-    swapped (stale stamps may only cost the shortcut): RGBA8 == the oracle's frame."""
-    import fuzz_util
-    from crychic_renderer_amd import Crychic, LIGHT_SKY
-    W, H, cc, scb, depth, normal, randvec = fuzz_util.sky_probe_case(seed)
-    base = get_case(ctx, built_lib, 256, 256)                       # shadow cascades + cube map of the reference scene
-    SD = base.np["shadow"].shape[1]
-    from crychic_renderer_amd import scene
-    consts = scene.Constants(W, H, shadow_dim=SD)
-    pcb = oracle_lib.as_oracle_cb(consts.pass_cb, oracle_lib.OrPassConstants)
-    oscb = oracle_lib.as_oracle_cb(consts.ssao_cb, oracle_lib.OrSsaoConstants)
-    rng = np.random.default_rng(4000 + seed)
-    dev = ctx.device
-    app = Crychic(ctx, W, H, torch.from_numpy(randvec).to(dev), base.dev["cube"], shadow_dim=SD)
-    for flip in (False, True):
-        d = np.ascontiguousarray(depth[:, ::-1]) if flip else depth
-        n = np.ascontiguousarray(normal[:, ::-1]) if flip else normal
-        cov = (d & 0xFFFFFF) < 0xFFFFFF
-        g0 = np.zeros((H, W, 4), np.float32); g1 = np.zeros_like(g0); g2 = np.zeros_like(g0)
-        k = int(cov.sum())
-        g0[cov] = np.concatenate([rng.uniform(-20, 20, (k, 3)), np.full((k, 1), 0.5)], axis=1).astype(np.float32)
-        g1[cov] = np.concatenate([rng.uniform(0.2, 1.0, (k, 3)), rng.uniform(0.1, 0.9, (k, 1))], axis=1).astype(np.float32)
-        g2[cov] = np.concatenate([rng.standard_normal((k, 3)), np.ones((k, 1))], axis=1).astype(np.float32)
-        planes = {"depth": torch.from_numpy(d.view(np.int32)).to(dev), "normal": torch.from_numpy(n).to(dev), "g0": torch.from_numpy(g0).to(dev),
-                  "g1": torch.from_numpy(g1).to(dev), "g2": torch.from_numpy(g2).to(dev), "shadow": base.dev["shadow"], "cube": base.dev["cube"],
-                  "randvec": torch.from_numpy(randvec).to(dev), "consts": consts}
-        app.load_scene(planes)
-        app.blurCount, app.numDirLights = 2, 3
-        amb = oracle.compute_ssao(oscb, n, d, randvec, 2)
-        for flags in (0, LIGHT_SKY):
-            app.flags = flags
-            ref = oracle.deferred_light(pcb, g0, g1, g2, d, amb, base.np["shadow"], base.np["cube"], 3, app.pcfSearchRadius, sky=bool(flags))
-            app.mBackBuffer.zero_()
-            app.Draw()
-            torch.cuda.synchronize()
-            assert np.array_equal(app.mBackBuffer.cpu().numpy(), ref), (seed, flip, flags, "whole frame")
-            for nranks in (2, 5):
-                app.mBackBuffer.zero_()
-                for rank in range(nranks):
-                    r0, rn = C.c_uint32(), C.c_uint32()
-                    built_lib.check(built_lib.lib.crychic_strip_rows(H, nranks, rank, C.byref(r0), C.byref(rn)))
-                    app.Draw(r0.value, rn.value)
-                torch.cuda.synchronize()
-                assert np.array_equal(app.mBackBuffer.cpu().numpy(), ref), (seed, flip, flags, nranks)
-    assert cov.any() and not cov.all()
-
-
 def test_flat_wall_ssao_is_unoccluded(ctx, built_lib):
     """a flat plane facing the camera has distZ = 0 <= eps for every tap => access = 1."""
     W, H = 128, 128
