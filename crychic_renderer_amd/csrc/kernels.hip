@@ -4,6 +4,7 @@
 // wavefront so every plane access is a contiguous 64-lane burst (16 B/lane on the fp32 G-buffer planes,
 // 8 B/lane on the fp16 normal plane and the depth row pairs), 4 rows per 256-thread workgroup.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "kernels.hpp"
 #include "ssao_core.hpp"
 #include "blur_tiles.hpp"
@@ -462,6 +463,14 @@ __global__ __launch_bounds__(256) void light_points_kernel(LightParams P, const 
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------
+// Margin (depth texel rows) of a row-limited depth pass around the rows of the call (ssao_core.hpp depth_pass_cell_rows).  Any value
+// gives the same pixels (tests: margins 0, 8, 40 with everything unvisited poisoned); CRYCHIC_DEPTH_MARGIN is the tuning knob the
+// strips rehearsal sweeps (tools/strips_rehearsal.sh), unset = the default rule (H / 11, at least 64).
+static int depth_margin()
+{
+    static const int m = [] { const char* e = getenv("CRYCHIC_DEPTH_MARGIN"); return e ? atoi(e) : -1; }();
+    return m;
+}
 static inline dim3 grid_for(uint32_t width, uint32_t rows, uint32_t rows_per_block = 4u)
 {
     return dim3((width + 63u) / 64u, (rows + rows_per_block - 1u) / rows_per_block, 1);
@@ -472,7 +481,7 @@ hipError_t launch_depth_pairs(const crychic_ssao_constants& cb, const uint32_t* 
 {
     const EdgePlane e = edge_plane_carve(edge_base, W, H);
     uint32_t c0, cn;
-    depth_pass_cell_rows(H, row0, rows, &c0, &cn);
+    depth_pass_cell_rows(H, row0, rows, &c0, &cn, depth_margin());
     if (cn == 0) return hipSuccess;
     // a wavefront per 128 entry columns x 8 entry rows (= one row of 16 cells of the nearest-depth map), four wavefronts per workgroup
     const uint32_t segs = (depth_pairs_pitch(W) / 2u + 63u) / 64u;
@@ -510,7 +519,7 @@ hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, con
     const int cull = (maps && ssao_cull_params(cb).enabled) ? 1 : 0;
     // what launch_depth_pairs prepared for these rows: everything, or footprint rows j0 with 8 c0 <= j0 + 2 < 8 (c0 + cn)
     uint32_t c0, cn;
-    depth_pass_cell_rows(H, row0, rows, &c0, &cn);
+    depth_pass_cell_rows(H, row0, rows, &c0, &cn, depth_margin());
     const bool limited = maps && use_pairs && (c0 > 0u || c0 + cn < zmin_map_rows(H));
     const PrepRows prep{ 8 * (int)c0 - 2, 8u * cn };
     if (limited) {                      // geometry-map cells are known for the texel rows the pass visited (8 entry rows per cell row)
