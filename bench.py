@@ -619,6 +619,8 @@ def main():
     for _ in range(150):
         app.Draw(row0, rows)
     torch.cuda.synchronize()
+    if app.blur_chain_timed_out():
+        raise SystemExit("bench.py rank %d: the single-launch blur chain reported a timed-out wait (crychic_blur_chain_status)" % rank)
 
     def warm_and_check():
         """W warm-up frames, then: every rank must hold the same complete frame, and it must be the frame one GPU renders alone
@@ -676,6 +678,8 @@ def main():
         step(i)
     fence()
     dt = time.perf_counter() - t0
+    if any(a.blur_chain_timed_out() for a in apps):
+        raise SystemExit("bench.py rank %d: the single-launch blur chain reported a timed-out wait inside the timed region" % rank)
     if exchange is None and nflight > 1 and not torch.equal(outs[0][row0:row0 + rows], outs[1][row0:row0 + rows]):
         raise SystemExit("bench.py: the frame pipelines disagree")      # same inputs, same kernels: must be the same bytes
     if use_dist:

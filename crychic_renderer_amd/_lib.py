@@ -123,6 +123,7 @@ PROTOTYPES = {
     "crychic_save_ppm": (_i, [C.c_char_p, _vp, _u32, _u32]),
     "crychic_raster_workspace_bytes": (_sz, [C.c_uint64, _u32, _u32]),
     "crychic_raster_status": (_i, [_vp, _vp, _P(_u32)]),
+    "crychic_blur_chain_status": (_i, [_vp, _vp, _P(_u32)]),
     "crychic_draw_scene_to_shadow_map": (_i, [_vp, _P(PassConstants), _P(DrawItem), _u32, _vp, _u32, _i, _f, _vp, _sz, _vp]),
     "crychic_draw_scene_to_shadow_maps": (_i, [_vp, _vp, _u32, _P(DrawItem), _u32, _vp, _u32, _i, _f, _vp, _sz, _vp]),
     "crychic_draw_normals_and_depth": (_i, [_vp, _P(PassConstants), _P(DrawItem), _u32, _vp, _vp, _u32, _u32, _vp, _sz, _vp]),

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <atomic>
 #include <cstring>
 #include <utility>
@@ -78,7 +79,7 @@ using cry::clamp_rows;
 
 int ssao_compute_impl(const crychic_ssao_constants* cb, const void* normal, const uint32_t* depth,
                       const uint8_t* randvec, uint16_t* ambient0, uint16_t* ambient1, void* edge, uint32_t W,
-                      uint32_t H, int blurCount, uint32_t row0, uint32_t rows, hipStream_t stream, hipEvent_t afterSsao)
+                      uint32_t H, int blurCount, uint32_t row0, uint32_t rows, hipStream_t stream, hipEvent_t afterSsao, crychic_ctx* ctx)
 {
     const uint32_t h2 = H / 2;
     if (row0 > h2 || rows > h2 - row0) return fail(CRYCHIC_E_INVALID_ARG, "rows [%u,+%u) outside the %u-row ambient map", row0, rows, h2);
@@ -99,12 +100,21 @@ int ssao_compute_impl(const crychic_ssao_constants* cb, const void* normal, cons
     CRY_HIP(cry::launch_ssao(*cb, normal, depth, randvec, planes[cry::blur_chain_ssao_plane(blurCount)], edge, W, H, r0, rn, true, usePairs,
                              edge ? stamp : 0u, stream));
     if (afterSsao) CRY_HIP(hipEventRecord(afterSsao, stream));
+    static const bool perIteration = getenv("CRYCHIC_BLUR_PER_ITERATION") != nullptr;      // the round-3 launch plan, kept for A / B runs
     for (int i = 0; i < cry::blur_chain_launches(blurCount); ++i) {
         const cry::BlurStep s = cry::blur_chain_step(blurCount, row0, rows, h2, i);
         if (i == 0)      // a pixel's value after the frame's sweeps depends on inputs within 5 pixels per iteration
             CRY_HIP(cry::launch_blur_pair(*cb, edge, planes[s.in], planes[s.out], W, H, s.row0, s.rows, blurCount > 1, stamp, 5 * blurCount, r0, rn, stream));
-        else
+        else if (perIteration || blurCount - 1 > 8)
             CRY_HIP(cry::launch_blur_replay(*cb, edge, planes[s.in], planes[s.out], W, H, s.row0, s.rows, stamp, stream));
+        else {           // iterations 1 .. blurCount - 1 as one launch with per-tile dependencies
+            CRY_HIP(cry::launch_blur_replay_chain(*cb, edge, planes[0], planes[1], W, H, blurCount, row0, rows, stamp, stream));
+            if (ctx) {
+                ctx->chainStatus = cry::edge_plane_carve(edge, W, H).progress + (size_t)cry::blur_tiles_x(W) * cry::blur_tiles_y(H);
+                ctx->chainTag = ((unsigned long long)stamp << 8) | 255ull;
+            }
+            break;
+        }
     }
     return 0;
 }
@@ -175,6 +185,8 @@ int crychic_ctx_create(int device_ordinal, crychic_ctx** out)
     ctx->profiling = false;
     ctx->times_valid = false;
     ctx->rasterStatus = nullptr;
+    ctx->chainStatus = nullptr;
+    ctx->chainTag = 0ull;
     for (auto& ev : ctx->ev) {
         hipError_t ee = hipEventCreate(&ev);
         if (ee != hipSuccess) { delete ctx; return fail(CRYCHIC_E_HIP, "hipEventCreate failed: %s", hipGetErrorString(ee)); }
@@ -245,7 +257,7 @@ int crychic_ssao_compute(crychic_ctx* ctx, const crychic_ssao_constants* cb, con
     if (int rc = check_dims(W, H)) return rc;
     if (!cb || !normal_dev || !depth_dev || !randvec_dev || !ambient0_dev) return fail(CRYCHIC_E_INVALID_ARG, "null argument");
     return ssao_compute_impl(cb, normal_dev, depth_dev, randvec_dev, ambient0_dev, ambient1_dev, edge_dev, W, H,
-                             blurCount, row0, rows, (hipStream_t)stream, nullptr);
+                             blurCount, row0, rows, (hipStream_t)stream, nullptr, ctx);
 }
 
 int crychic_deferred_light(crychic_ctx* ctx, const crychic_pass_constants* cb, const float* g0_dev, const float* g1_dev,
@@ -320,7 +332,7 @@ int crychic_draw_hot_path(crychic_ctx* ctx, const crychic_ssao_constants* ssaoCB
         clamp_rows(H / 2, (int64_t)(f->row0 / 2) - 2, (int64_t)((f->row0 + f->rows + 1) / 2) + 2, &a0, &an);
         if (int rc = ssao_compute_impl(ssaoCB, f->normal_dev, f->depth_dev, f->randvec_dev, f->ambient0_dev,
                                        f->ambient1_dev, f->edge_dev, W, H, f->blurCount, a0, an, stream,
-                                       prof ? ctx->ev[1] : nullptr)) return rc;
+                                       prof ? ctx->ev[1] : nullptr, ctx)) return rc;
     } else if (prof) {
         CRY_HIP(hipEventRecord(ctx->ev[1], stream));
     }
@@ -388,6 +400,19 @@ int crychic_raster_status(crychic_ctx* ctx, void* stream, uint32_t* flags)
     if (!ctx->rasterStatus) return fail(CRYCHIC_E_INVALID_ARG, "no producer pass has been issued on this context");
     CRY_HIP(hipMemcpyAsync(flags, ctx->rasterStatus, sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)stream));
     CRY_HIP(hipStreamSynchronize((hipStream_t)stream));
+    return 0;
+}
+
+int crychic_blur_chain_status(crychic_ctx* ctx, void* stream, uint32_t* timed_out)
+{
+    if (int rc = bind(ctx)) return rc;
+    if (!timed_out) return fail(CRYCHIC_E_INVALID_ARG, "timed_out is null");
+    *timed_out = 0;
+    if (!ctx->chainStatus) return 0;             // no single-launch chain has run on this context
+    unsigned long long word = 0;
+    CRY_HIP(hipMemcpyAsync(&word, ctx->chainStatus, sizeof word, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    CRY_HIP(hipStreamSynchronize((hipStream_t)stream));
+    *timed_out = word == ctx->chainTag ? 1u : 0u;
     return 0;
 }
 

@@ -89,6 +89,9 @@ struct BlockSeq {
     CRY_HD bool wave_all(bool p) const { return p; }
     CRY_HD bool wave_leader() const { return true; }
     CRY_HD void wave_sync() const {}         // device: orders a wavefront's LDS writes before its other lanes' reads of them
+    // accesses to the ambient planes of a replay iteration (kernels.hip: device-coherent in the single-launch chain)
+    CRY_HD uint32_t amb_load(const uint16_t* p) const { return *p; }
+    CRY_HD void amb_store(uint16_t* p, uint32_t v) const { *p = (uint16_t)v; }
 };
 
 struct BlurTileArgs {
@@ -260,7 +263,7 @@ CRY_HD void blur_replay_tile(const Block& blk, const BlurTileArgs& a, uint32_t s
                 for (int h = 0; h < 2; ++h) {
                     const int lx = h ? 64 + (l < 10 ? l : 9) : l;
                     const uint32_t p = (uint32_t)cy * (uint32_t)a.w2 + (uint32_t)clampi(a.x0 - R + lx, 0, a.w2 - 1);   // ambient: point / CLAMP
-                    raw[m][h][s] = a.in[p];
+                    raw[m][h][s] = blk.amb_load(a.in + p);
                     mk[m][h][s] = a.e.masks[p];
                 }
             }
@@ -324,7 +327,7 @@ CRY_HD void blur_replay_tile(const Block& blk, const BlurTileArgs& a, uint32_t s
                     const float* col = s_mid + ty * kBlurTileW + l;
                     v = blur_pixel_replay(a.w, mv, [&](int i) { return col[i * kBlurTileW]; });
                 }
-                a.out[(uint32_t)y * (uint32_t)a.w2 + (uint32_t)x] = (uint16_t)v;
+                blk.amb_store(a.out + ((uint32_t)y * (uint32_t)a.w2 + (uint32_t)x), v);
             }
         });
     }

@@ -10,6 +10,8 @@ struct crychic_ctx {
     bool times_valid;
     hipEvent_t ev[4];  // start, after ssao, after blur, after light
     const uint32_t* rasterStatus;   // device status word of the most recent producer pass (crychic_raster_status)
+    const unsigned long long* chainStatus;      // error word of the most recent single-launch blur chain (crychic_blur_chain_status)
+    unsigned long long chainTag;                // (its frame stamp << 8) | 255: what the word holds if a workgroup gave up waiting
 };
 
 namespace cry {

@@ -268,8 +268,10 @@ __global__ __launch_bounds__(256) void blur_kernel(crychic_ssao_constants cb, Ed
     }
 }
 
-// The workgroup behind the tile bodies of blur_tiles.hpp.
-struct BlockDev {
+// The workgroup behind the tile bodies of blur_tiles.hpp.  COHERENT: the ambient planes are read and written with agent-scope
+// (device-coherent) accesses -- the single-launch chain, whose tiles hand values to workgroups on other XCDs inside one kernel.
+template <bool COHERENT = false>
+struct BlockDevT {
     static constexpr int kLanes = 1;
     __device__ int tid() const { return (int)threadIdx.x; }
     __device__ int size() const { return (int)blockDim.x; }
@@ -289,7 +291,18 @@ struct BlockDev {
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
+    __device__ uint32_t amb_load(const uint16_t* p) const
+    {
+        if (COHERENT) return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return *p;
+    }
+    __device__ void amb_store(uint16_t* p, uint32_t v) const
+    {
+        if (COHERENT) __hip_atomic_store(p, (uint16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else *p = (uint16_t)v;
+    }
 };
+using BlockDev = BlockDevT<false>;
 
 // Tiles of the blur launches lie on an absolute 64 x 16 grid of the half-res map (so that the flags one launch leaves per tile
 // mean the same tile to the next); a launch covers the tile rows that intersect its rows [row0, row1).
@@ -342,6 +355,82 @@ __global__ __launch_bounds__(512) void blur_replay_kernel(crychic_ssao_constants
     __shared__ uint32_t s_rows[kBlurMaxWaves];
     const BlurTileArgs a = blur_tile_args(cb, edge, in, out, W, H, row0, row1);
     blur_replay_tile(BlockDev{}, a, stamp, onesShortcut != 0, s_in, s_mask, s_mid, s_rows);
+}
+
+// Iterations 1 .. blurCount - 1 of the chain in ONE launch: workgroup (x, y, z) replays iteration z + 1 of tile (x, y).  What the
+// per-iteration launches get from the kernel boundary -- iteration j reads what iteration j - 1 wrote, and may overwrite the plane
+// iteration j - 1 read -- is a per-tile dependency here: a tile's iteration j needs its own and its eight neighbours' iteration
+// j - 1 COMPLETE (their outputs are its apron; their inputs are the plane it writes).  Every tile publishes its count of completed
+// iterations, tagged with the frame stamp (a stale or uninitialised word never matches), with agent-scope release; a workgroup
+// polls its up to nine predecessors with agent-scope acquire before it stages.  Forward progress: workgroups are dispatched in
+// increasing (z, y, x) order and a workgroup only ever waits for workgroups of the layer below, which were dispatched before it
+// and wait for nothing above them.  The poll is bounded all the same: a workgroup that gives up sets EdgePlane::progress's error
+// word and goes on (wrong pixels, never a hang).  Tiles the pair launch settled neither work nor publish nor are waited for.
+// Same tile body as blur_replay_kernel (blur_tiles.hpp blur_replay_tile): same bits.  What it buys is the launch boundaries: two
+// of the chain's four drain-and-refill gaps, and a tile's iteration j + 1 can start while other tiles are still in iteration j.
+struct BlurChainPlan {
+    uint16_t* plane[2];
+    uint32_t row0[8], row1[8];      // half-res rows of its output iteration z + 1 owes
+    uint32_t in[8];                 // plane index it reads (writes the other)
+    uint32_t tileRow0;              // first tile row of the grid (absolute 64 x 16 grid)
+};
+__global__ __launch_bounds__(512) void blur_replay_chain_kernel(crychic_ssao_constants cb, EdgePlane edge, BlurChainPlan plan, uint32_t W, uint32_t H,
+                                                                uint32_t stamp, uint32_t exitStamp, int onesShortcut)
+{
+    __shared__ float s_in[kBlurPairSW * kBlurPairSH];
+    __shared__ uint32_t s_mask[kBlurPairSW * kBlurPairSH];
+    __shared__ float s_mid[kBlurTileW * kBlurPairSH];
+    __shared__ uint32_t s_rows[kBlurMaxWaves];
+    const uint32_t it = blockIdx.z, tx = blockIdx.x, ty = plan.tileRow0 + blockIdx.y, ntx = blur_tiles_x(W);
+    const uint32_t tile = ty * ntx + tx;
+    if (exitStamp != 0u && edge.tiles[tile] == exitStamp) return;                     // settled: 65535 in both planes, for good
+    const unsigned long long tag = (unsigned long long)stamp << 8;
+    if (it > 0u) {
+        // wait for the 3 x 3 neighbourhood's iteration `it` (count >= it), lanes 0..8 of the first wavefront one tile each
+        if (threadIdx.x < 9u) {
+            const int nx = (int)tx + (int)(threadIdx.x % 3u) - 1, ny = (int)ty + (int)(threadIdx.x / 3u) - 1;
+            const bool inGrid = nx >= 0 && nx < (int)ntx && ny >= (int)plan.tileRow0 && ny < (int)(plan.tileRow0 + gridDim.y);
+            if (inGrid) {
+                const uint32_t n = (uint32_t)ny * ntx + (uint32_t)nx;
+                if (!(exitStamp != 0u && edge.tiles[n] == exitStamp)) {
+                    bool ok = false;
+                    for (int spin = 0; spin < (1 << 16) && !ok; ++spin) {
+                        // relaxed polls (a coherent load, no cache invalidation per poll: an acquire here flushed the caches under the
+                        // workgroups that were doing the work -- 14x slower); ONE acquire fence after the wait, below
+                        const unsigned long long v = __hip_atomic_load(edge.progress + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = (v >> 8) == (tag >> 8) && (v & 255ull) >= (unsigned long long)it;
+                        if (!ok) __builtin_amdgcn_s_sleep(16);
+                    }
+                    if (!ok) edge.progress[(size_t)ntx * blur_tiles_y(H)] = tag | 255ull;      // the error word (one past the tiles)
+                }
+            }
+        }
+        __syncthreads();          // the staging loads below are device-coherent themselves: nothing to invalidate
+    }
+    const uint32_t row0 = plan.row0[it], row1 = plan.row1[it];
+    const bool mine = ty * (uint32_t)kBlurTileH < row1 && (ty + 1u) * (uint32_t)kBlurTileH > row0;
+    if (mine) {
+        BlurTileArgs a;
+        a.w = &cb.BlurWeights[0][0];
+        a.e = edge;
+        a.in = plan.plane[plan.in[it]];
+        a.out = plan.plane[plan.in[it] ^ 1u];
+        a.w2 = (int)(W / 2);
+        a.h2 = (int)(H / 2);
+        a.x0 = (int)tx * kBlurTileW;
+        a.y0 = (int)ty * kBlurTileH;
+        a.row0 = (int)row0;
+        a.row1 = (int)row1;
+        a.borderZ = ndc_to_view(cb, 1.0f);
+        a.tileIndex = tile;
+        blur_replay_tile(BlockDevT<true>{}, a, 0u, onesShortcut != 0, s_in, s_mask, s_mid, s_rows);
+    }
+    // The tile's outputs were device-coherent stores: once every wavefront's stores are acknowledged (workgroup-scope release:
+    // s_waitcnt) they are visible to every XCD, and the count may be published -- no L2 write-back (an agent-scope release fence
+    // per workgroup writes back the XCD's whole L2: measured 390 us for the launch)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(edge.progress + tile, tag | (unsigned long long)(it + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- deferred lighting -----------------------------------------------------------------------------------------
@@ -579,6 +668,33 @@ hipError_t launch_blur_replay(const crychic_ssao_constants& cb, const void* edge
     const int ones = blur_weights_positive(cb) ? 1 : 0;
     if (!ones) stamp = 0u;             // the pair launch settled no tile either
     hipLaunchKernelGGL(blur_replay_kernel, blur_tile_grid(W, row0, rows), dim3(512), 0, stream, cb, e, in, out, W, H, row0, row0 + rows, stamp, ones);
+    return hipGetLastError();
+}
+
+hipError_t launch_blur_replay_chain(const crychic_ssao_constants& cb, const void* edge_base, uint16_t* plane0, uint16_t* plane1, uint32_t W, uint32_t H,
+                                    int blurCount, uint32_t row0, uint32_t rows, uint32_t stamp, hipStream_t stream)
+{
+    const int n = blurCount - 1;                       // replay iterations 1 .. blurCount - 1
+    if (n <= 0 || rows == 0) return hipSuccess;
+    if (n > 8) return hipErrorInvalidValue;
+    const EdgePlane e = edge_plane_carve(const_cast<void*>(edge_base), W, H);
+    BlurChainPlan plan;
+    plan.plane[0] = plane0;
+    plan.plane[1] = plane1;
+    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
+    for (int i = 1; i <= n; ++i) {
+        const BlurStep st = blur_chain_step(blurCount, row0, rows, H / 2u, i);
+        plan.row0[i - 1] = st.row0;
+        plan.row1[i - 1] = st.row0 + st.rows;
+        plan.in[i - 1] = (uint32_t)st.in;
+        if (st.rows) { lo = st.row0 < lo ? st.row0 : lo; hi = st.row0 + st.rows > hi ? st.row0 + st.rows : hi; }
+    }
+    for (int i = n; i < 8; ++i) { plan.row0[i] = plan.row1[i] = 0u; plan.in[i] = 0u; }
+    if (hi <= lo) return hipSuccess;
+    const dim3 g = blur_tile_grid(W, lo, hi - lo);
+    plan.tileRow0 = lo / (uint32_t)kBlurTileH;
+    const int ones = blur_weights_positive(cb) ? 1 : 0;
+    hipLaunchKernelGGL(blur_replay_chain_kernel, dim3(g.x, g.y, (unsigned)n), dim3(512), 0, stream, cb, e, plan, W, H, stamp, ones ? stamp : 0u, ones);
     return hipGetLastError();
 }
 

@@ -34,6 +34,12 @@ hipError_t launch_blur_pair(const crychic_ssao_constants& cb, const void* edge_b
 hipError_t launch_blur_replay(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out, uint32_t W, uint32_t H,
                               uint32_t row0, uint32_t rows, uint32_t stamp, hipStream_t stream);
 
+// Iterations 1 .. blurCount - 1 of the chain in one launch (kernels.hip blur_replay_chain_kernel: per-tile dependencies instead of
+// kernel boundaries); plane0 / plane1 = ambient0 / ambient1, rows = what the caller is owed of the final map, stamp = the frame's
+// (the one launch_blur_pair ran with).  Same pixels as blurCount - 1 calls of launch_blur_replay along blur_chain_step.
+hipError_t launch_blur_replay_chain(const crychic_ssao_constants& cb, const void* edge_base, uint16_t* plane0, uint16_t* plane1, uint32_t W, uint32_t H,
+                                    int blurCount, uint32_t row0, uint32_t rows, uint32_t stamp, hipStream_t stream);
+
 hipError_t launch_light(const LightParams& P, const float* g0, const float* g1, const float* g2,
                         const uint32_t* depth, const uint16_t* ambient, const uint8_t* cube, uint8_t* out,
                         float* radiance, uint32_t row0, uint32_t rows, hipStream_t stream);

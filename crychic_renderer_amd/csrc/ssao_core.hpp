@@ -29,6 +29,7 @@ struct EdgePlane {
     uint32_t* ones;    // unoccluded-wavefront map (below "unoccluded tiles"), ones_map_bytes(W, H)
     float* zcull;      // nearest-depth map per 9 x 9 texel cell (below "tap culling"): what a tap looks up, zmin_map_bytes(W, H)
     uint32_t* tiles;   // unoccluded-tile flags of the blur launches (blur_tiles.hpp), blur_tile_map_bytes(W, H)
+    unsigned long long* progress;      // per tile: (frame stamp << 8) | replay iterations completed (kernels.hip blur_replay_chain_kernel), 2 x blur_tile_map_bytes
 };
 
 // ---- depth pairs -----------------------------------------------------------------------------------------------------
@@ -71,7 +72,8 @@ CRY_HD uint32_t blur_tiles_x(uint32_t W) { return (W / 2u + 63u) / 64u; }
 CRY_HD uint32_t blur_tiles_y(uint32_t H) { return (H / 2u + 15u) / 16u; }
 CRY_HD size_t blur_tile_map_bytes(uint32_t W, uint32_t H) { return (size_t)blur_tiles_x(W) * blur_tiles_y(H) * 4u; }
 CRY_HD size_t edge_plane_tiles_offset(uint32_t W, uint32_t H) { return (edge_plane_zcull_offset(W, H) + zmin_map_bytes(W, H) + 15) & ~(size_t)15; }
-CRY_HD size_t edge_plane_bytes(uint32_t W, uint32_t H) { return edge_plane_tiles_offset(W, H) + blur_tile_map_bytes(W, H); }
+CRY_HD size_t edge_plane_progress_offset(uint32_t W, uint32_t H) { return (edge_plane_tiles_offset(W, H) + blur_tile_map_bytes(W, H) + 15) & ~(size_t)15; }
+CRY_HD size_t edge_plane_bytes(uint32_t W, uint32_t H) { return edge_plane_progress_offset(W, H) + 2u * blur_tile_map_bytes(W, H) + 16u; }      // + the chain's error word
 // Entries (x, y) and (x + 1, y) of the pairs plane from the D24 plane; x even (so the two texels of a row are one 8-byte load).
 CRY_HD f4a depth_pairs_entry2(const uint32_t* __restrict__ depth, uint32_t W, uint32_t H, int x, int y)
 {
@@ -97,6 +99,7 @@ CRY_HD EdgePlane edge_plane_carve(void* base, uint32_t W, uint32_t H)
     e.ones = (uint32_t*)(b + edge_plane_ones_offset(W, H));
     e.zcull = (float*)(b + edge_plane_zcull_offset(W, H));
     e.tiles = (uint32_t*)(b + edge_plane_tiles_offset(W, H));
+    e.progress = (unsigned long long*)(b + edge_plane_progress_offset(W, H));
     return e;
 }
 

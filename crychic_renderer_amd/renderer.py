@@ -237,6 +237,13 @@ class Crychic:
     def set_profiling(self, enabled):
         check(lib.crychic_ctx_set_profiling(self.ctx.handle, 1 if enabled else 0))
 
+    def blur_chain_timed_out(self):
+        """crychic_blur_chain_status: True if a workgroup of the most recent single-launch blur chain gave up waiting for a neighbour
+        (synchronises the stream; the frame's ambient map would be wrong)."""
+        flag = C.c_uint32(0)
+        check(lib.crychic_blur_chain_status(self.ctx.handle, _stream(self.ctx.device), C.byref(flag)))
+        return bool(flag.value)
+
     def last_pass_times(self):
         t = PassTimes()
         check(lib.crychic_ctx_last_pass_times(self.ctx.handle, C.byref(t)))

@@ -362,6 +362,14 @@ int crychic_draw_gbuffer(crychic_ctx* ctx, const crychic_pass_constants* passCB,
 #define CRYCHIC_RASTER_BAD_INDEX 2u        /* an index pointed outside the item's vertex buffer: triangle dropped */
 int crychic_raster_status(crychic_ctx* ctx, void* stream, uint32_t* flags);
 
+/* Ssao::ComputeSsao's blur iterations 1 .. blurCount - 1 run as ONE launch whose tiles wait for their neighbours' previous iteration
+ * through per-tile counters in the edge workspace (Ssao.cpp:231-266 issues one draw per sweep and relies on the barrier between
+ * draws).  The wait is bounded: a workgroup that gives up -- which would mean the device did not dispatch workgroups in grid order,
+ * the assumption forward progress rests on -- records it and goes on.  This call synchronises `stream` and reports whether that
+ * happened in the most recent chain issued on `ctx` (*timed_out = 1: that frame's ambient map is wrong).  Tests and bench.py
+ * check it; CRYCHIC_BLUR_PER_ITERATION=1 in the environment selects one launch per iteration instead (the same pixels). */
+int crychic_blur_chain_status(crychic_ctx* ctx, void* stream, uint32_t* timed_out);
+
 /* All cascades of CRYCHIC::DrawSceneToShadowMap (CRYCHIC.cpp:2477-2510 loops over four) in one pass: passCBs[c].ViewProj and
  * shadow_dev[c] per cascade, the same items for all.  Bit-identical to nCascades calls of crychic_draw_scene_to_shadow_map;
  * the workspace must hold crychic_raster_workspace_bytes(nCascades * triangles, shadowDim, shadowDim). */

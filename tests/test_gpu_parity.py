@@ -195,6 +195,54 @@ def test_compute_ssao_bit_exact(ctx, built_lib, oracle, W, H, blur_count):
         assert np.array_equal(got[row0:row0 + rows], ref[row0:row0 + rows]), (row0, rows, int((got[row0:row0 + rows] != ref[row0:row0 + rows]).sum()))
 
 
+def test_blur_chain_single_launch_equals_per_iteration(ctx, built_lib, oracle):
+    """Iterations 1 .. blurCount - 1 as ONE launch with per-tile dependencies (kernels.hip blur_replay_chain_kernel) against the oracle's
+    sweep-by-sweep chain and against one launch per iteration (CRYCHIC_BLUR_PER_ITERATION=1 in a child process): whole maps and
+    strips, blurCount 2 .. 8, repeated on one workspace (the counters of the previous frame carry another stamp), and no workgroup
+    may have timed out (crychic_blur_chain_status)."""
+    import os, subprocess, sys, tempfile
+    W, H = 322, 190
+    c = get_case(ctx, built_lib, W, H)
+    lib, check = built_lib.lib, built_lib.check
+    flag = C.c_uint32(7)
+    outs = {}
+    for blur_count in (2, 3, 4, 8):
+        want = oracle.compute_ssao(c.scb, c.np["normal"], c.np["depth"], c.np["randvec"], blur_count)
+        for rep in range(3):
+            c.a0.fill_(0x1111); c.a1.fill_(0x2222)
+            check(lib.crychic_ssao_compute(ctx.handle, C.byref(c.consts.ssao_cb), ptr(c.dev["normal"]), ptr(c.dev["depth"]), ptr(c.dev["randvec"]),
+                                           ptr(c.a0), ptr(c.a1), ptr(c.edge), W, H, blur_count, 0, H // 2, stream(ctx)))
+            check(lib.crychic_blur_chain_status(ctx.handle, stream(ctx), C.byref(flag)))
+            assert flag.value == 0
+            assert np.array_equal(dev_u16(c.a0), want), (blur_count, rep)
+        for row0, rows in ((0, 31), (40, 17), (H // 2 - 23, 23)):
+            c.a0.fill_(0x1111); c.a1.fill_(0x2222)
+            check(lib.crychic_ssao_compute(ctx.handle, C.byref(c.consts.ssao_cb), ptr(c.dev["normal"]), ptr(c.dev["depth"]), ptr(c.dev["randvec"]),
+                                           ptr(c.a0), ptr(c.a1), ptr(c.edge), W, H, blur_count, row0, rows, stream(ctx)))
+            check(lib.crychic_blur_chain_status(ctx.handle, stream(ctx), C.byref(flag)))
+            assert flag.value == 0
+            assert np.array_equal(dev_u16(c.a0)[row0:row0 + rows], want[row0:row0 + rows]), (blur_count, row0, rows)
+        outs[blur_count] = want
+    # the per-iteration launch plan in a child process (the switch is read once per process): same bytes
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.TemporaryDirectory() as d:
+        np.save(os.path.join(d, "want.npy"), outs[4])
+        code = ("import sys, numpy as np, torch, ctypes as C; sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+                "import scene_util\nfrom crychic_renderer_amd import Context\nfrom crychic_renderer_amd._lib import lib, check\n"
+                "ctx = Context(0); W, H = %d, %d\npl = scene_util.cpu_scene(W, H, 512, 64); p = scene_util.np_planes(pl); c = pl['consts']\n"
+                "t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32) if a.dtype == np.uint32 else np.ascontiguousarray(a)).to(ctx.device)\n"
+                "n, d, r = t(p['normal']), t(p['depth']), t(p['randvec'])\n"
+                "a0 = torch.zeros((H // 2, W // 2), dtype=torch.int16, device=ctx.device); a1 = torch.zeros_like(a0)\n"
+                "e = torch.zeros((int(lib.crychic_edge_plane_bytes(W, H)),), dtype=torch.uint8, device=ctx.device)\n"
+                "s = C.c_void_p(torch.cuda.current_stream(ctx.device).cuda_stream)\n"
+                "check(lib.crychic_ssao_compute(ctx.handle, C.byref(c.ssao_cb), C.c_void_p(n.data_ptr()), C.c_void_p(d.data_ptr()), C.c_void_p(r.data_ptr()),"
+                " C.c_void_p(a0.data_ptr()), C.c_void_p(a1.data_ptr()), C.c_void_p(e.data_ptr()), W, H, 4, 0, H // 2, s))\n"
+                "torch.cuda.synchronize()\nassert np.array_equal(a0.cpu().numpy().view(np.uint16), np.load(%r)), 'per-iteration plan differs'\nprint('ok')\n"
+                % (root, os.path.join(root, "tests"), W, H, os.path.join(d, "want.npy")))
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, CRYCHIC_BLUR_PER_ITERATION="1"), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0 and "ok" in r.stdout, r.stdout + r.stderr
+
+
 def test_recycled_workspace_on_device(ctx, built_lib, oracle):
     """The edge workspace is caller-owned and nothing clears it (ADVICE r2 / VERDICT r2 item 2).  Frame A on context 1; context 1
     destroyed; a DIFFERENT frame B on a new context over the same, uncleared workspace; then frame B again over a workspace whose
