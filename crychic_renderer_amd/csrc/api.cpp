@@ -79,11 +79,8 @@ using cry::clamp_rows;
 
 int ssao_compute_impl(const crychic_ssao_constants* cb, const void* normal, const uint32_t* depth,
                       const uint8_t* randvec, uint16_t* ambient0, uint16_t* ambient1, void* edge, uint32_t W,
-                      uint32_t H, int blurCount, uint32_t row0, uint32_t rows, hipStream_t stream, hipEvent_t afterSsao, crychic_ctx* ctx,
-                      uint32_t* deferredChainStamp = nullptr)
+                      uint32_t H, int blurCount, uint32_t row0, uint32_t rows, hipStream_t stream, hipEvent_t afterSsao, crychic_ctx* ctx)
 {
-    // deferredChainStamp != null: the caller launches the replay iterations itself, fused with its lighting pass
-    // (crychic_draw_hot_path -> launch_chain_and_light); *deferredChainStamp = the frame's stamp, or 0 if the chain was issued here
     const uint32_t h2 = H / 2;
     if (row0 > h2 || rows > h2 - row0) return fail(CRYCHIC_E_INVALID_ARG, "rows [%u,+%u) outside the %u-row ambient map", row0, rows, h2);
     if (blurCount < 0) return fail(CRYCHIC_E_INVALID_ARG, "blurCount %d < 0", blurCount);
@@ -111,12 +108,11 @@ int ssao_compute_impl(const crychic_ssao_constants* cb, const void* normal, cons
         else if (perIteration || blurCount - 1 > 8)
             CRY_HIP(cry::launch_blur_replay(*cb, edge, planes[s.in], planes[s.out], W, H, s.row0, s.rows, stamp, stream));
         else {           // iterations 1 .. blurCount - 1 as one launch with per-tile dependencies
+            CRY_HIP(cry::launch_blur_replay_chain(*cb, edge, planes[0], planes[1], W, H, blurCount, row0, rows, stamp, stream));
             if (ctx) {
                 ctx->chainStatus = cry::edge_plane_carve(edge, W, H).progress + (size_t)cry::blur_tiles_x(W) * cry::blur_tiles_y(H);
                 ctx->chainTag = ((unsigned long long)stamp << 8) | 255ull;
             }
-            if (deferredChainStamp) { *deferredChainStamp = stamp; break; }
-            CRY_HIP(cry::launch_blur_replay_chain(*cb, edge, planes[0], planes[1], W, H, blurCount, row0, rows, stamp, stream));
             break;
         }
     }
@@ -320,7 +316,6 @@ int crychic_draw_hot_path(crychic_ctx* ctx, const crychic_ssao_constants* ssaoCB
     const bool ssaoOn = f->blurCount >= 0;
     if (ssaoOn && (!f->normal_dev || !f->randvec_dev || !f->ambient0_dev)) return fail(CRYCHIC_E_INVALID_ARG, "SSAO planes missing");
     hipStream_t stream = (hipStream_t)stream_;
-    static const bool fuseChainLight = getenv("CRYCHIC_NO_CHAIN_LIGHT_FUSION") == nullptr;
     cry::LightParams P;
     if (int rc = fill_light_params(P, passCB, f->shadow_dev, f->shadowDim, f->cubeDim, W, H, f->numDirLights,
                                    f->pcfSearchRadius, f->flags)) return rc;
@@ -330,30 +325,18 @@ int crychic_draw_hot_path(crychic_ctx* ctx, const crychic_ssao_constants* ssaoCB
     P.numPointLights = f->numPointLights;
     const bool prof = ctx->profiling;
     if (prof) { ctx->times_valid = false; CRY_HIP(hipEventRecord(ctx->ev[0], stream)); }
-    uint32_t chainStamp = 0u, a0 = 0u, an = 0u;
     if (ssaoOn) {
         // The lighting pass filters the half-res AO map bilinearly at (about) its own pixel centre
         // (DeferredShading.hlsl:40-42): rows row0/2 - 1 .. (row0+rows)/2; keep one more row of slack.
+        uint32_t a0, an;
         clamp_rows(H / 2, (int64_t)(f->row0 / 2) - 2, (int64_t)((f->row0 + f->rows + 1) / 2) + 2, &a0, &an);
-        // Without per-pass timing the replay iterations and the lighting pass go out as ONE launch (kernels.hip chain_light_kernel);
-        // with it they stay apart, so that blur_ms and light_ms mean what they say.
-        const bool fuse = fuseChainLight && !prof && f->blurCount > 1 && f->numPointLights == 0 && f->edge_dev && f->ambient1_dev;
         if (int rc = ssao_compute_impl(ssaoCB, f->normal_dev, f->depth_dev, f->randvec_dev, f->ambient0_dev,
                                        f->ambient1_dev, f->edge_dev, W, H, f->blurCount, a0, an, stream,
-                                       prof ? ctx->ev[1] : nullptr, ctx, fuse ? &chainStamp : nullptr)) return rc;
+                                       prof ? ctx->ev[1] : nullptr, ctx)) return rc;
     } else if (prof) {
         CRY_HIP(hipEventRecord(ctx->ev[1], stream));
     }
     if (prof) CRY_HIP(hipEventRecord(ctx->ev[2], stream));
-    if (chainStamp != 0u) {
-        hipError_t e = hipSuccess;
-        if (cry::launch_chain_and_light(*ssaoCB, f->edge_dev, f->ambient0_dev, f->ambient1_dev, W, H, f->blurCount, a0, an, chainStamp, P, f->g0_dev, f->g1_dev,
-                                        f->g2_dev, f->depth_dev, f->cube_dev, f->out_rgba8_dev, f->row0, f->rows, stream, &e)) {
-            CRY_HIP(e);
-            return 0;
-        }
-        CRY_HIP(cry::launch_blur_replay_chain(*ssaoCB, f->edge_dev, f->ambient0_dev, f->ambient1_dev, W, H, f->blurCount, a0, an, chainStamp, stream));
-    }
     CRY_HIP(cry::launch_light(P, f->g0_dev, f->g1_dev, f->g2_dev, f->depth_dev, ssaoOn ? f->ambient0_dev : nullptr,
                               f->cube_dev, f->out_rgba8_dev, nullptr, f->row0, f->rows, stream));
     if (prof) { CRY_HIP(hipEventRecord(ctx->ev[3], stream)); ctx->times_valid = true; }

@@ -374,11 +374,14 @@ struct BlurChainPlan {
     uint32_t in[8];                 // plane index it reads (writes the other)
     uint32_t tileRow0;              // first tile row of the grid (absolute 64 x 16 grid)
 };
-__device__ __forceinline__ void blur_chain_workgroup(const crychic_ssao_constants& cb, const EdgePlane& edge, const BlurChainPlan& plan, uint32_t W, uint32_t H,
-                                                     uint32_t stamp, uint32_t exitStamp, int onesShortcut, uint32_t tx, uint32_t tyRel, uint32_t it,
-                                                     uint32_t tileRows, float* s_in, uint32_t* s_mask, float* s_mid, uint32_t* s_rows)
+__global__ __launch_bounds__(512) void blur_replay_chain_kernel(crychic_ssao_constants cb, EdgePlane edge, BlurChainPlan plan, uint32_t W, uint32_t H,
+                                                                uint32_t stamp, uint32_t exitStamp, int onesShortcut)
 {
-    const uint32_t ty = plan.tileRow0 + tyRel, ntx = blur_tiles_x(W);
+    __shared__ float s_in[kBlurPairSW * kBlurPairSH];
+    __shared__ uint32_t s_mask[kBlurPairSW * kBlurPairSH];
+    __shared__ float s_mid[kBlurTileW * kBlurPairSH];
+    __shared__ uint32_t s_rows[kBlurMaxWaves];
+    const uint32_t it = blockIdx.z, tx = blockIdx.x, ty = plan.tileRow0 + blockIdx.y, ntx = blur_tiles_x(W);
     const uint32_t tile = ty * ntx + tx;
     if (exitStamp != 0u && edge.tiles[tile] == exitStamp) return;                     // settled: 65535 in both planes, for good
     const unsigned long long tag = (unsigned long long)stamp << 8;
@@ -386,14 +389,14 @@ __device__ __forceinline__ void blur_chain_workgroup(const crychic_ssao_constant
         // wait for the 3 x 3 neighbourhood's iteration `it` (count >= it), lanes 0..8 of the first wavefront one tile each
         if (threadIdx.x < 9u) {
             const int nx = (int)tx + (int)(threadIdx.x % 3u) - 1, ny = (int)ty + (int)(threadIdx.x / 3u) - 1;
-            const bool inGrid = nx >= 0 && nx < (int)ntx && ny >= (int)plan.tileRow0 && ny < (int)(plan.tileRow0 + tileRows);
+            const bool inGrid = nx >= 0 && nx < (int)ntx && ny >= (int)plan.tileRow0 && ny < (int)(plan.tileRow0 + gridDim.y);
             if (inGrid) {
                 const uint32_t n = (uint32_t)ny * ntx + (uint32_t)nx;
                 if (!(exitStamp != 0u && edge.tiles[n] == exitStamp)) {
                     bool ok = false;
                     for (int spin = 0; spin < (1 << 16) && !ok; ++spin) {
                         // relaxed polls (a coherent load, no cache invalidation per poll: an acquire here flushed the caches under the
-                        // workgroups that were doing the work -- 14x slower)
+                        // workgroups that were doing the work -- 14x slower); ONE acquire fence after the wait, below
                         const unsigned long long v = __hip_atomic_load(edge.progress + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                         ok = (v >> 8) == (tag >> 8) && (v & 255ull) >= (unsigned long long)it;
                         if (!ok) __builtin_amdgcn_s_sleep(16);
@@ -429,15 +432,6 @@ __device__ __forceinline__ void blur_chain_workgroup(const crychic_ssao_constant
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(edge.progress + tile, tag | (unsigned long long)(it + 1u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ __launch_bounds__(512) void blur_replay_chain_kernel(crychic_ssao_constants cb, EdgePlane edge, BlurChainPlan plan, uint32_t W, uint32_t H,
-                                                                uint32_t stamp, uint32_t exitStamp, int onesShortcut)
-{
-    __shared__ float s_in[kBlurPairSW * kBlurPairSH];
-    __shared__ uint32_t s_mask[kBlurPairSW * kBlurPairSH];
-    __shared__ float s_mid[kBlurTileW * kBlurPairSH];
-    __shared__ uint32_t s_rows[kBlurMaxWaves];
-    blur_chain_workgroup(cb, edge, plan, W, H, stamp, exitStamp, onesShortcut, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.y, s_in, s_mask, s_mid, s_rows);
-}
 
 // ---- deferred lighting -----------------------------------------------------------------------------------------
 // Shaders/DeferredShading.hlsl:23-101 as a full-screen pass over rows [row0, row1), masked by depth < 1.
@@ -466,69 +460,6 @@ __global__ __launch_bounds__(256) void light_kernel(LightParams P, const f4a* __
         lit = f4{ 0.690196097f, 0.768627524f, 0.870588303f, 1.0f };  // Colors::LightSteelBlue, CRYCHIC.cpp:247
     }
     if (radiance) radiance[idx] = f4a{ lit.x, lit.y, lit.z, lit.w };
-    out[idx] = pack_rgba8(lit);
-}
-
-// The blur chain's iterations 1 .. blurCount - 1 AND the lighting pass in one launch.  Both are latency-bound on their own -- the chain
-// waits on tile round trips with most of the chip idle, a lit wavefront spends half its life waiting for memory -- and the lighting
-// pass needs the chain only through the ambient texels under each pixel.  Workgroups [0, nChain) are the chain's (blur_chain_workgroup,
-// layer-major as in blur_replay_chain_kernel), workgroups [nChain, ...) light 64 x 8-pixel tiles: each waits -- bounded, on lower-indexed
-// workgroups only, which is what guarantees progress -- until the (at most four) blur tiles under its pixels' ambient footprints
-// are settled or have published their last iteration, then runs light_pixel with device-coherent ambient loads.  Same per-pixel
-// functions, same operands: the same bits as the three separate launches.
-template <bool ZERO_RADIUS, bool FIX>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(8, 8))) void chain_light_kernel(crychic_ssao_constants cb, EdgePlane edge, BlurChainPlan plan, uint32_t stamp, uint32_t exitStamp,
-                                                          int onesShortcut, uint32_t chainGx, uint32_t chainGy, uint32_t chainLayers, LightParams P,
-                                                          const f4a* __restrict__ g0, const f4a* __restrict__ g1, const f4a* __restrict__ g2,
-                                                          const uint32_t* __restrict__ depth, const uint16_t* __restrict__ ambient,
-                                                          const uint32_t* __restrict__ cube, uint32_t* __restrict__ out, uint32_t row0, uint32_t row1)
-{
-    __shared__ float s_in[kBlurPairSW * kBlurPairSH];
-    __shared__ uint32_t s_mask[kBlurPairSW * kBlurPairSH];
-    __shared__ float s_mid[kBlurTileW * kBlurPairSH];
-    __shared__ uint32_t s_rows[kBlurMaxWaves];
-    const uint32_t perLayer = chainGx * chainGy, nChain = perLayer * chainLayers;
-    if (blockIdx.x < nChain) {
-        const uint32_t it = blockIdx.x / perLayer, r = blockIdx.x - it * perLayer, ty = r / chainGx, tx = r - ty * chainGx;
-        blur_chain_workgroup(cb, edge, plan, P.W, P.H, stamp, exitStamp, onesShortcut, tx, ty, it, chainGy, s_in, s_mask, s_mid, s_rows);
-        return;
-    }
-    const uint32_t lid = blockIdx.x - nChain, lgx = (P.W + 63u) / 64u, lby = lid / lgx, lbx = lid - lby * lgx;
-    const uint32_t yFirst = row0 + lby * 8u;
-    // the blur tiles under this workgroup's ambient footprints: half-res columns [32 lbx - 1, 32 lbx + 32], rows [yFirst / 2 - 1, (yFirst + 7) / 2 + 1]
-    if (threadIdx.x < 4u) {
-        const int w2 = (int)(P.W / 2u), h2 = (int)(P.H / 2u);
-        const int hx = clampi((threadIdx.x & 1u) ? 32 * (int)lbx + 32 : 32 * (int)lbx - 1, 0, w2 - 1);
-        const int yl = (int)(yFirst + 7u < row1 ? yFirst + 7u : row1 - 1u);
-        const int hy = clampi((threadIdx.x & 2u) ? yl / 2 + 1 : (int)yFirst / 2 - 1, 0, h2 - 1);
-        const uint32_t ttx = (uint32_t)hx / (uint32_t)kBlurTileW, tty = (uint32_t)hy / (uint32_t)kBlurTileH;
-        if (tty >= plan.tileRow0 && tty < plan.tileRow0 + chainGy) {      // outside the chain's grid: rows this launch does not blur (nothing to wait for)
-            const uint32_t n = tty * blur_tiles_x(P.W) + ttx;
-            if (!(exitStamp != 0u && edge.tiles[n] == exitStamp)) {
-                const unsigned long long tag = (unsigned long long)stamp << 8;
-                bool ok = false;
-                for (int spin = 0; spin < (1 << 16) && !ok; ++spin) {
-                    const unsigned long long v = __hip_atomic_load(edge.progress + n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    ok = (v >> 8) == (tag >> 8) && (v & 255ull) >= (unsigned long long)chainLayers;
-                    if (!ok) __builtin_amdgcn_s_sleep(16);
-                }
-                if (!ok) edge.progress[(size_t)blur_tiles_x(P.W) * blur_tiles_y(P.H)] = tag | 255ull;
-            }
-        }
-    }
-    __syncthreads();
-    const uint32_t x = lbx * 64u + (threadIdx.x & 63u), y = yFirst + (threadIdx.x >> 6);
-    if (x >= P.W || y >= row1) return;
-    const uint32_t idx = y * P.W + x;
-    f4 lit;
-    const uint32_t d = depth[idx];      // (requested before the wait it would ride along with it -- but the wait is rare and the registers are not)
-    if ((d & 0x00FFFFFFu) < 0x00FFFFFFu) {
-        lit = light_pixel<ZERO_RADIUS, NoPointLights, FIX, true>(P, g0[idx], g1[idx], g2[idx], ambient, cube);
-    } else if (P.flags & CRYCHIC_LIGHT_SKY) {
-        lit = sky_pixel(P, cube, x, y);
-    } else {
-        lit = f4{ 0.690196097f, 0.768627524f, 0.870588303f, 1.0f };  // Colors::LightSteelBlue, CRYCHIC.cpp:247
-    }
     out[idx] = pack_rgba8(lit);
 }
 
@@ -765,43 +696,6 @@ hipError_t launch_blur_replay_chain(const crychic_ssao_constants& cb, const void
     const int ones = blur_weights_positive(cb) ? 1 : 0;
     hipLaunchKernelGGL(blur_replay_chain_kernel, dim3(g.x, g.y, (unsigned)n), dim3(512), 0, stream, cb, e, plan, W, H, stamp, ones ? stamp : 0u, ones);
     return hipGetLastError();
-}
-
-// launch_blur_replay_chain + launch_light as one launch (chain_light_kernel); false (nothing launched) when the combination does not
-// apply: no replay iterations, point lights, a radiance target.
-bool launch_chain_and_light(const crychic_ssao_constants& cb, const void* edge_base, uint16_t* plane0, uint16_t* plane1, uint32_t W, uint32_t H, int blurCount,
-                            uint32_t arow0, uint32_t arows, uint32_t stamp, const LightParams& P, const float* g0, const float* g1, const float* g2,
-                            const uint32_t* depth, const uint8_t* cube, uint8_t* out, uint32_t row0, uint32_t rows, hipStream_t stream, hipError_t* err)
-{
-    *err = hipSuccess;
-    const int n = blurCount - 1;
-    if (n <= 0 || n > 8 || arows == 0 || rows == 0 || P.numPointLights) return false;
-    const EdgePlane e = edge_plane_carve(const_cast<void*>(edge_base), W, H);
-    BlurChainPlan plan;
-    plan.plane[0] = plane0;
-    plan.plane[1] = plane1;
-    uint32_t lo = 0xFFFFFFFFu, hi = 0u;
-    for (int i = 1; i <= n; ++i) {
-        const BlurStep st = blur_chain_step(blurCount, arow0, arows, H / 2u, i);
-        plan.row0[i - 1] = st.row0;
-        plan.row1[i - 1] = st.row0 + st.rows;
-        plan.in[i - 1] = (uint32_t)st.in;
-        if (st.rows) { lo = st.row0 < lo ? st.row0 : lo; hi = st.row0 + st.rows > hi ? st.row0 + st.rows : hi; }
-    }
-    for (int i = n; i < 8; ++i) { plan.row0[i] = plan.row1[i] = 0u; plan.in[i] = 0u; }
-    if (hi <= lo) return false;
-    const dim3 g = blur_tile_grid(W, lo, hi - lo);
-    plan.tileRow0 = lo / (uint32_t)kBlurTileH;
-    const int ones = blur_weights_positive(cb) ? 1 : 0;
-    const uint32_t nChain = g.x * g.y * (uint32_t)n, nLight = ((W + 63u) / 64u) * ((rows + 7u) / 8u);
-    const bool fix = (P.flags & (CRYCHIC_FIX_Q1 | CRYCHIC_FIX_Q3 | CRYCHIC_FIX_Q4)) != 0;
-#define CRY_LAUNCH_CL(K) hipLaunchKernelGGL(K, dim3(nChain + nLight), dim3(512), 0, stream, cb, e, plan, stamp, ones ? stamp : 0u, ones, g.x, g.y, (uint32_t)n, P, \
-                                            (const f4a*)g0, (const f4a*)g1, (const f4a*)g2, depth, (const uint16_t*)plane0, (const uint32_t*)cube, (uint32_t*)out, row0, row0 + rows)
-    if (P.pcfSearchRadius == 0.0f) { if (fix) CRY_LAUNCH_CL((chain_light_kernel<true, true>)); else CRY_LAUNCH_CL((chain_light_kernel<true, false>)); }
-    else { if (fix) CRY_LAUNCH_CL((chain_light_kernel<false, true>)); else CRY_LAUNCH_CL((chain_light_kernel<false, false>)); }
-#undef CRY_LAUNCH_CL
-    *err = hipGetLastError();
-    return true;
 }
 
 hipError_t launch_light(const LightParams& P, const float* g0, const float* g1, const float* g2,

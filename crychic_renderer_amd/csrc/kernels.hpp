@@ -40,14 +40,6 @@ hipError_t launch_blur_replay(const crychic_ssao_constants& cb, const void* edge
 hipError_t launch_blur_replay_chain(const crychic_ssao_constants& cb, const void* edge_base, uint16_t* plane0, uint16_t* plane1, uint32_t W, uint32_t H,
                                     int blurCount, uint32_t row0, uint32_t rows, uint32_t stamp, hipStream_t stream);
 
-// The chain above AND the lighting pass as one launch (kernels.hip chain_light_kernel): the lighting workgroups wait for the blur
-// tiles under their pixels instead of for the whole chain.  plane0 = ambient0 = the final map.  arow0 / arows: the half-res rows
-// the chain owes (what the lighting rows [row0, row0 + rows) filter).  Returns false, having launched nothing, when the
-// combination does not apply (no replay iterations, point lights); *err = the launch status otherwise.
-bool launch_chain_and_light(const crychic_ssao_constants& cb, const void* edge_base, uint16_t* plane0, uint16_t* plane1, uint32_t W, uint32_t H, int blurCount,
-                            uint32_t arow0, uint32_t arows, uint32_t stamp, const LightParams& P, const float* g0, const float* g1, const float* g2,
-                            const uint32_t* depth, const uint8_t* cube, uint8_t* out, uint32_t row0, uint32_t rows, hipStream_t stream, hipError_t* err);
-
 hipError_t launch_light(const LightParams& P, const float* g0, const float* g1, const float* g2,
                         const uint32_t* depth, const uint16_t* ambient, const uint8_t* cube, uint8_t* out,
                         float* radiance, uint32_t row0, uint32_t rows, hipStream_t stream);

@@ -445,9 +445,6 @@ CRY_HD AmbientFetch ambient_fetch(const uint16_t* __restrict__ a, uint32_t w2, u
 // compiler wait inside it: three serialised round trips per pixel, measured -- profiles/r04_experiments.txt).
 // hasAO false: the 1 x 1 stand-in of light_pixel (the cubemap's first bytes): w = h = 1, both picks take the low half.
 struct AmbientPairs { uint32_t d0, d1; float fx, fy; bool x0lo, x1lo; };      // t00 = x0lo ? lo(d0) : hi(d0), t10 = x1lo ? lo(d0) : hi(d0), ...
-// COHERENT: the map was written earlier in the SAME launch by workgroups of other XCDs (kernels.hip chain_light_kernel): the texels
-// are then read with device-coherent (agent-scope) loads -- four 16-bit ones, an atomic access being naturally aligned.
-template <bool COHERENT = false>
 CRY_HD AmbientPairs ambient_fetch_projected(const LightParams& P, const uint16_t* __restrict__ a, bool hasAO, const uint16_t* __restrict__ standIn, f3 posW)
 {
     const v2f c0{ P.ScreenPairs[0][0], P.ScreenPairs[0][1] }, c1{ P.ScreenPairs[1][0], P.ScreenPairs[1][1] };
@@ -488,18 +485,8 @@ CRY_HD AmbientPairs ambient_fetch_projected(const LightParams& P, const uint16_t
         f.fx = b.fx; f.fy = b.fy; f.x0lo = x0 == cx; f.x1lo = x1 == cx;
     }
     const uint16_t* src = hasAO ? a : standIn;
-#if defined(__HIP_DEVICE_COMPILE__)
-    if (COHERENT) {
-        const uint32_t l0 = __hip_atomic_load(src + o0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), h0 = __hip_atomic_load(src + o0 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t l1 = __hip_atomic_load(src + o1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), h1 = __hip_atomic_load(src + o1 + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        f.d0 = l0 | (h0 << 16);
-        f.d1 = l1 | (h1 << 16);
-    } else
-#endif
-    {
-        f.d0 = load_at<uint32_t>(src, o0 * 2u);
-        f.d1 = load_at<uint32_t>(src, o1 * 2u);
-    }
+    f.d0 = load_at<uint32_t>(src, o0 * 2u);
+    f.d1 = load_at<uint32_t>(src, o1 * 2u);
     if (tiny) { f.fx = uv.x; f.fy = uv.y; }
     return f;
 }
@@ -766,7 +753,7 @@ CRY_HD float cascade_uniform_resolve(const LightParams& P, const CascadeTexels& 
 // issued before the first is waited for (one memory round trip instead of one per lookup).
 // FIX: a compile-time promise that P.flags may carry CRYCHIC_FIX_* bits; false = the reference as written, with no trace of
 // the switches in the instantiation the benchmark runs.
-template <bool ZERO_RADIUS, class PointLights = NoPointLights, bool FIX = false, bool COHERENT_AO = false>
+template <bool ZERO_RADIUS, class PointLights = NoPointLights, bool FIX = false>
 CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16_t* __restrict__ ambient,
                       const uint32_t* __restrict__ cube, PointLights pointLights = PointLights())
 {
@@ -792,7 +779,7 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
     // :40-42; without an ambient map the fetch still runs, on a 1 x 1 stand-in (the cubemap's first bytes), so that no branch
     // separates it from the other gathers
     const bool hasAO = ambient != nullptr;
-    const AmbientPairs af = ambient_fetch_projected<COHERENT_AO>(P, ambient, hasAO, (const uint16_t*)cube, posW);
+    const AmbientPairs af = ambient_fetch_projected(P, ambient, hasAO, (const uint16_t*)cube, posW);
     const f3 r = reflect3(f3{ -view.x, -view.y, -view.z }, normalW);  // :94
     const CubeRows cf = cube_fetch(cube, P.cubeDim, r);         // :95
 
