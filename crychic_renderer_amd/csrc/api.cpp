@@ -97,25 +97,12 @@ int ssao_compute_impl(const crychic_ssao_constants* cb, const void* normal, cons
     // SSAO kernel gains 15: the pairs plane stays)
     const bool usePairs = edge != nullptr;
     if (edge) CRY_HIP(cry::launch_depth_pairs(*cb, depth, edge, W, H, stamp, usePairs, r0, rn, stream));
-    // Without per-pass timing the SSAO pass and iteration 0 of the blur go out as ONE launch (kernels.hip ssao_pair_kernel); with it
-    // (afterSsao) they stay apart, so that ssao_ms and blur_ms mean what they say.  CRYCHIC_NO_SSAO_BLUR_FUSION keeps them apart too.
-    static const bool fuseSsaoBlur = getenv("CRYCHIC_NO_SSAO_BLUR_FUSION") == nullptr;
-    bool pairDone = false;
-    if (fuseSsaoBlur && !afterSsao && edge && blurCount > 0) {
-        const cry::BlurStep s0 = cry::blur_chain_step(blurCount, row0, rows, h2, 0);
-        hipError_t e = hipSuccess;
-        pairDone = cry::launch_ssao_and_blur_pair(*cb, normal, depth, randvec, planes[s0.in], planes[s0.out], edge, W, H, r0, rn, s0.row0, s0.rows, blurCount > 1,
-                                                  stamp, 5 * blurCount, stream, &e);
-        if (pairDone) CRY_HIP(e);
-    }
-    if (!pairDone)
-        CRY_HIP(cry::launch_ssao(*cb, normal, depth, randvec, planes[cry::blur_chain_ssao_plane(blurCount)], edge, W, H, r0, rn, true, usePairs,
-                                 edge ? stamp : 0u, stream));
+    CRY_HIP(cry::launch_ssao(*cb, normal, depth, randvec, planes[cry::blur_chain_ssao_plane(blurCount)], edge, W, H, r0, rn, true, usePairs,
+                             edge ? stamp : 0u, stream));
     if (afterSsao) CRY_HIP(hipEventRecord(afterSsao, stream));
     static const bool perIteration = getenv("CRYCHIC_BLUR_PER_ITERATION") != nullptr;      // the round-3 launch plan, kept for A / B runs
     for (int i = 0; i < cry::blur_chain_launches(blurCount); ++i) {
         const cry::BlurStep s = cry::blur_chain_step(blurCount, row0, rows, h2, i);
-        if (i == 0 && pairDone) continue;
         if (i == 0)      // a pixel's value after the frame's sweeps depends on inputs within 5 pixels per iteration
             CRY_HIP(cry::launch_blur_pair(*cb, edge, planes[s.in], planes[s.out], W, H, s.row0, s.rows, blurCount > 1, stamp, 5 * blurCount, r0, rn, stream));
         else if (perIteration || blurCount - 1 > 8)

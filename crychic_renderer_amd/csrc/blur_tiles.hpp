@@ -92,10 +92,6 @@ struct BlockSeq {
     // accesses to the ambient planes of a replay iteration (kernels.hip: device-coherent in the single-launch chain)
     CRY_HD uint32_t amb_load(const uint16_t* p) const { return *p; }
     CRY_HD void amb_store(uint16_t* p, uint32_t v) const { *p = (uint16_t)v; }
-    // iteration 0 reading the SSAO pass's outputs: never in flight on the host
-    static constexpr bool kWaitsForSsao = false;
-    CRY_HD PlainLoads ssao_loads() const { return PlainLoads(); }
-    CRY_HD void nap() const {}
 };
 
 struct BlurTileArgs {
@@ -139,28 +135,8 @@ CRY_HD void blur_pair_tile(const Block& blk, const BlurTileArgs& a, uint32_t sta
     constexpr int SW = kBlurPairSW, SH = kBlurPairSH, R = kBlurRadius;
     const int tid = blk.tid(), n = blk.size();
     bool settled = false;
-    const auto ld = blk.ssao_loads();
     if (stamp != 0u) {
         const OnesRegion g = blur_ones_region((uint32_t)a.w2, (uint32_t)a.h2, a.x0, a.y0, kBlurTileW, kBlurTileH, onesMargin);
-        if (Block::kWaitsForSsao) {
-            // The SSAO wavefronts this tile reads from belong to the SAME launch (kernels.hip ssao_pair_kernel): wait until every one of
-            // them inside the tile's neighbourhood -- which contains the staged region: onesMargin >= 5 -- has published its word
-            // (ones_word: written after the wavefront's outputs).  Bounded; they were all dispatched before this workgroup.
-            const int wr0 = (int)g.r0 > ssaoRow0 ? (int)g.r0 : ssaoRow0, wr1 = (int)g.r1 < ssaoRow1 - 1 ? (int)g.r1 : ssaoRow1 - 1;
-            const int ncol = (int)(g.c1 - g.c0) + 1, ncell = wr1 >= wr0 ? ncol * (wr1 - wr0 + 1) : 0;
-            const float rncol = 1.0f / (float)ncol;
-            const uint32_t pitch = (uint32_t)((a.w2 + 63) / 64);
-            for (int spin = 0; spin < (1 << 15); ++spin) {
-                bool ready = true;
-                for (int k = tid; k < ncell; k += n) {
-                    int r, c;
-                    divmod_small(k, ncol, rncol, r, c);
-                    ready &= ones_word_written(ld.u32(a.e.ones + ((uint32_t)(wr0 + r) * pitch + g.c0 + (uint32_t)c)), stamp);
-                }
-                if (blk.all(ready)) break;
-                blk.nap();
-            }
-        }
         if ((int)g.r0 >= ssaoRow0 && (int)g.r1 < ssaoRow1) {
             const int ncol = (int)(g.c1 - g.c0) + 1, ncell = ncol * ((int)(g.r1 - g.r0) + 1);
             const float rncol = 1.0f / (float)ncol;
@@ -169,7 +145,7 @@ CRY_HD void blur_pair_tile(const Block& blk, const BlurTileArgs& a, uint32_t sta
             for (int k = tid; k < ncell; k += n) {
                 int r, c;
                 divmod_small(k, ncol, rncol, r, c);
-                occluded |= ld.u32(a.e.ones + ((g.r0 + (uint32_t)r) * pitch + g.c0 + (uint32_t)c)) != stamp;
+                occluded |= a.e.ones[(g.r0 + (uint32_t)r) * pitch + g.c0 + (uint32_t)c] != stamp;
             }
             settled = !blk.any(occluded);
         }
@@ -200,7 +176,7 @@ CRY_HD void blur_pair_tile(const Block& blk, const BlurTileArgs& a, uint32_t sta
             const int k = base + u * n < SW * SH ? base + u * n : SW * SH - 1;
             int ly, lx;
             divmod_small(k, SW, 1.0f / (float)SW, ly, lx);
-            raw[u] = blur_fetch_raw(a.e, a.in, a.w2, a.h2, a.x0 - R + lx, clampi(a.y0 - R + ly, 0, a.h2 - 1), ld);
+            raw[u] = blur_fetch_raw(a.e, a.in, a.w2, a.h2, a.x0 - R + lx, clampi(a.y0 - R + ly, 0, a.h2 - 1));
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -233,7 +209,7 @@ CRY_HD void blur_pair_tile(const Block& blk, const BlurTileArgs& a, uint32_t sta
         for (int k = tid; k < kBlurTileW * SH; k += n) {
             const int ly = k >> 6, lx = k & 63, x = a.x0 + lx, y = a.y0 - R + ly;
             if (x < a.w2 && (y < 0 || y >= a.h2)) {
-                const BlurTap t = blur_fetch(a.e, a.in, a.borderZ, a.w2, a.h2, x, y, ld);
+                const BlurTap t = blur_fetch(a.e, a.in, a.borderZ, a.w2, a.h2, x, y);
                 s_nz[ly * SW + lx + R] = f4a{ t.n.x, t.n.y, t.n.z, t.z };
             }
         }

@@ -78,13 +78,8 @@ __device__ __forceinline__ void tile_origin_2d(uint32_t& bx, uint32_t& by, uint3
 template <bool WRITE_PAIRS>
 __global__ __launch_bounds__(256) void depth_pairs_kernel(const uint32_t* __restrict__ depth, f4a* __restrict__ pairs, uint32_t* __restrict__ geo,
                                                           float* __restrict__ zcull, uint32_t stamp, uint32_t W, uint32_t H, CullParams cull,
-                                                          uint32_t cellRow0, uint32_t* __restrict__ onesClear, uint32_t onesWords)
+                                                          uint32_t cellRow0)
 {
-    // The words of the unoccluded-wavefront map that this frame's SSAO pass will publish are flags the first blur launch may poll
-    // while that pass is still running (ssao_pair_kernel): cleared here, one launch earlier, so that nothing a previous frame -- or
-    // nobody -- left in the workspace can read as "written" (the workspace keeps needing no initialisation).
-    for (uint32_t i = (blockIdx.y * gridDim.x + blockIdx.x) * 256u + threadIdx.x; i < onesWords; i += gridDim.x * gridDim.y * 256u) onesClear[i] = 0u;
-
     const uint32_t halfPitch = depth_pairs_pitch(W) / 2u;
     const uint32_t lane = threadIdx.x & 63u, seg = blockIdx.x * 4u + (threadIdx.x >> 6);
     if (seg * 64u >= halfPitch) return;                          // wave-uniform
@@ -159,46 +154,31 @@ __global__ __launch_bounds__(256) void depth_pairs_kernel(const uint32_t* __rest
 // ROWS: that pass was limited to the footprint rows [prepJ0, prepJ0 + prepNj) (a strip of a multi-GPU frame): taps that leave them
 // gather from the raw plane (ssao_core.hpp DepthPairsRows).
 struct PrepRows { int j0lo; uint32_t nj; };
-// Stores of the SSAO pass's outputs: plain, or device-coherent (agent scope) when workgroups of the same launch read them
-// (ssao_pair_kernel below).
-template <bool COHERENT> struct SsaoStores {
-    __device__ static void u16(uint16_t* p, uint32_t v) { if (COHERENT) __hip_atomic_store(p, (uint16_t)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = (uint16_t)v; }
-    __device__ static void u32(uint32_t* p, uint32_t v) { if (COHERENT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v; }
-    __device__ static void f32(float* p, float v) { if (COHERENT) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v; }
-    __device__ static void nrm(u2* p, u2 v)
-    {
-        if (COHERENT) {
-            unsigned long long w;
-            __builtin_memcpy(&w, &v, 8);
-            __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else *p = v;
-    }
-    // the wavefront's word of the unoccluded-wavefront map (ssao_core.hpp ones_word), published after its other outputs
-    __device__ static void publish(uint32_t* p, uint32_t v)
-    {
-        if (COHERENT) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");      // this wavefront's stores acknowledged first (s_waitcnt)
-        if ((threadIdx.x & 63u) == 0) u32(p, v);
-    }
-};
-// Shaders/Ssao.hlsl:117-199 for the 64 half-res pixels x = 64 bx .. of row y (one wavefront).
-template <bool EMIT_AO, bool PAIRS, bool MAPS, bool ROWS, bool COHERENT>
-__device__ __forceinline__ void ssao_wave(const crychic_ssao_constants& cb, const u2* __restrict__ normal, const uint32_t* __restrict__ depth,
-                                          const uint32_t* __restrict__ randvec, uint16_t* __restrict__ ambient, const EdgePlane& edge, uint32_t W, uint32_t H,
-                                          uint32_t row0, uint32_t bx, uint32_t x, uint32_t y, int sparseProjTex, const SkyReach& sky, uint32_t stamp,
-                                          int cullEnabled, PrepRows prep, HalfResScale hs)
+template <bool EMIT_AO, bool PAIRS, bool MAPS, bool ROWS>
+__global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, const u2* __restrict__ normal,
+                                                   const uint32_t* __restrict__ depth,
+                                                   const uint32_t* __restrict__ randvec,
+                                                   uint16_t* __restrict__ ambient, EdgePlane edge, uint32_t W,
+                                                   uint32_t H, uint32_t row0, uint32_t row1, uint32_t SX, uint32_t SY, int sparseProjTex,
+                                                   SkyReach sky, uint32_t stamp, int cullEnabled, PrepRows prep, HalfResScale hs)
 {
-    using St = SsaoStores<COHERENT>;
     const uint32_t w2 = W / 2;
+    uint32_t bx, by;
+    tile_origin_2d(bx, by, SX, SY);
+    const uint32_t x = bx * 64u + (threadIdx.x & 63u);
+    const uint32_t y = row0 + by * 4u + (threadIdx.x >> 6);
+    if (x >= w2 || y >= row1) return;
+
     const DepthPairs dp{ edge.pairs, depth_pairs_pitch(W) };
     const DepthD24 dd{ depth, W, H };
     // the pixel's own depth comes from the D24 plane (coalesced): its pairs entry may be one the depth pass did not write
     const SsaoCentre c = ssao_centre(cb, normal, depth, W, H, (int)x, (int)y);
     if (edge.nrm) {
         const uint32_t idx = y * w2 + x;
-        St::nrm(edge.nrm + idx, c.nrm_bits);
-        St::f32(edge.vz + idx, c.vz);
-        if (x == 0) St::nrm(edge.gcol + y, normal[(2u * y + 1u) * W]);   // texel (0, 2y+1)
-        if (y == row0) St::nrm(edge.grow + x, normal[2u * x + 1u]);      // texel (2x+1, 0)
+        edge.nrm[idx] = c.nrm_bits;
+        edge.vz[idx] = c.vz;
+        if (x == 0) edge.gcol[y] = normal[(2u * y + 1u) * W];   // texel (0, 2y+1)
+        if (y == row0) edge.grow[x] = normal[2u * x + 1u];      // texel (2x+1, 0)
     }
     // Sky shortcut (ssao_core.hpp): every live lane of this wave is a sky pixel and no cell its taps can reach holds geometry
     if (EMIT_AO && MAPS && sky.enabled && __builtin_amdgcn_ballot_w64(!c.sky) == 0) {
@@ -211,8 +191,8 @@ __device__ __forceinline__ void ssao_wave(const crychic_ssao_constants& cb, cons
             geometry |= edge.geo[(g.cy0 + cy) * pitch + g.cx0 + cx] == stamp;
         }
         if (g.known && __builtin_amdgcn_ballot_w64(geometry) == 0) {
-            St::u16(ambient + (y * w2 + x), 0xFFFFu);
-            St::publish(edge.ones + (y * ones_map_cols(W) + bx), ones_word(stamp, true));
+            ambient[y * w2 + x] = (uint16_t)0xFFFFu;
+            if ((threadIdx.x & 63u) == 0) edge.ones[y * ones_map_cols(W) + bx] = stamp;
             return;
         }
     }
@@ -228,30 +208,15 @@ __device__ __forceinline__ void ssao_wave(const crychic_ssao_constants& cb, cons
         else if (PAIRS) v = ssao_pixel(cb, c, dp, randvec, W, H, x, y, hs, sparseProjTex != 0);
         else if (MAPS && cullEnabled) v = ssao_pixel(cb, c, dd, randvec, W, H, x, y, hs, sparseProjTex != 0, zm);
         else v = ssao_pixel(cb, c, dd, randvec, W, H, x, y, hs, sparseProjTex != 0);
-        St::u16(ambient + (y * w2 + x), v);
+        ambient[y * w2 + x] = (uint16_t)v;
         // unoccluded-wavefront map (ssao_core.hpp "unoccluded tiles"): lane 0 is live whenever the wave is (x = 64 bx < w2).  The
-        // word is written by EVERY wavefront that emits ambient values -- ones_word: stamp or its complement -- so no word of a row
-        // computed this frame is ever stale.
+        // word is written by EVERY wavefront that emits ambient values -- the stamp or 0 -- so no word of a row computed this
+        // frame is ever stale.
         if (MAPS && stamp != 0u) {
             const bool allOnes = __builtin_amdgcn_ballot_w64(v != 0xFFFFu) == 0;
-            St::publish(edge.ones + (y * ones_map_cols(W) + bx), ones_word(stamp, allOnes));
+            if ((threadIdx.x & 63u) == 0) edge.ones[y * ones_map_cols(W) + bx] = allOnes ? stamp : 0u;
         }
     }
-}
-template <bool EMIT_AO, bool PAIRS, bool MAPS, bool ROWS>
-__global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, const u2* __restrict__ normal,
-                                                   const uint32_t* __restrict__ depth,
-                                                   const uint32_t* __restrict__ randvec,
-                                                   uint16_t* __restrict__ ambient, EdgePlane edge, uint32_t W,
-                                                   uint32_t H, uint32_t row0, uint32_t row1, uint32_t SX, uint32_t SY, int sparseProjTex,
-                                                   SkyReach sky, uint32_t stamp, int cullEnabled, PrepRows prep, HalfResScale hs)
-{
-    uint32_t bx, by;
-    tile_origin_2d(bx, by, SX, SY);
-    const uint32_t x = bx * 64u + (threadIdx.x & 63u);
-    const uint32_t y = row0 + by * 4u + (threadIdx.x >> 6);
-    if (x >= W / 2 || y >= row1) return;
-    ssao_wave<EMIT_AO, PAIRS, MAPS, ROWS, false>(cb, normal, depth, randvec, ambient, edge, W, H, row0, bx, x, y, sparseProjTex, sky, stamp, cullEnabled, prep, hs);
 }
 
 // ---- bilateral blur ------------------------------------------------------------------------------------------
@@ -303,32 +268,10 @@ __global__ __launch_bounds__(256) void blur_kernel(crychic_ssao_constants cb, Ed
     }
 }
 
-// Device-coherent (agent-scope) loads of the SSAO pass's outputs (ssao_core.hpp PlainLoads is the plain twin).
-struct CoherentLoads {
-    __device__ u2 nrm(const u2* p) const
-    {
-        const unsigned long long w = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        u2 v;
-        __builtin_memcpy(&v, &w, 8);
-        return v;
-    }
-    __device__ float f32(const float* p) const { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    __device__ uint32_t u16(const uint16_t* p) const { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-    __device__ uint32_t u32(const uint32_t* p) const { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-};
 // The workgroup behind the tile bodies of blur_tiles.hpp.  COHERENT: the ambient planes are read and written with agent-scope
 // (device-coherent) accesses -- the single-launch chain, whose tiles hand values to workgroups on other XCDs inside one kernel.
-// SSAO_IN_FLIGHT: iteration 0 inside the launch that also runs the SSAO pass (ssao_pair_kernel): its inputs are read with
-// device-coherent loads, after a wait for the wavefronts that write them.
-template <bool COHERENT = false, bool SSAO_IN_FLIGHT = false>
+template <bool COHERENT = false>
 struct BlockDevT {
-    static constexpr bool kWaitsForSsao = SSAO_IN_FLIGHT;
-    __device__ auto ssao_loads() const
-    {
-        if constexpr (SSAO_IN_FLIGHT) return CoherentLoads();
-        else return PlainLoads();
-    }
-    __device__ void nap() const { __builtin_amdgcn_s_sleep(32); }
     static constexpr int kLanes = 1;
     __device__ int tid() const { return (int)threadIdx.x; }
     __device__ int size() const { return (int)blockDim.x; }
@@ -399,56 +342,6 @@ __global__ __launch_bounds__(512) void blur_pair_kernel(crychic_ssao_constants c
     __shared__ uint16_t s_hmask[kBlurTileW * kBlurTileH];
     const BlurTileArgs a = blur_tile_args(cb, edge, in, out, W, H, row0, row1);
     blur_pair_tile<RECORD>(BlockDev{}, a, stamp, onesMargin, ssaoRow0, ssaoRow1, s_nz, s_a, s_mid, s_hmask);
-}
-
-// The SSAO pass and iteration 0 of the blur in ONE launch.  blur_pair_kernel is bound by its round trips -- the unoccluded-tile check,
-// the staging, two sweeps, with a third of the chip's slots in use -- while ssao_kernel is bound by instruction issue: run side by side
-// the first hides inside the second.  A blur tile needs the SSAO wavefronts of its neighbourhood only (the rows and 64-pixel segments
-// of its unoccluded-tile check, which contain what it stages), and every SSAO wavefront already publishes a word of its own when its
-// outputs are written (ssao_core.hpp ones_word) -- so the tile polls those words (bounded) instead of waiting for the kernel boundary.
-// Workgroups of 512: an SSAO workgroup is 64 x 8 half-res pixels (block row B = absolute rows [8 B, 8 B + 8)), a blur workgroup one
-// 64 x 16 tile.  Dispatch order is what guarantees progress -- a workgroup waits only for lower-numbered ones -- and what makes
-// the overlap: the grid is cut into slices of two SSAO block rows (2 S, 2 S + 1) followed by blur tile row S - 3, whose neighbourhood
-// ends at half-res row 16 (S - 3) + 15 + onesMargin <= 16 S - 13 for onesMargin <= 20, inside block row 2 S - 2.  Larger margins
-// (blurCount > 4) shift the tile rows further back (tileLag).  The SSAO outputs are written with device-coherent stores and read
-// with device-coherent loads (the wavefronts sit on other XCDs); the blur tile's own outputs are plain (the next launch reads them).
-template <bool ROWS, bool RECORD>
-__global__ __launch_bounds__(512) void ssao_pair_kernel(crychic_ssao_constants cb, const u2* __restrict__ normal, const uint32_t* __restrict__ depth,
-                                                        const uint32_t* __restrict__ randvec, uint16_t* __restrict__ ssaoOut, uint16_t* __restrict__ blurOut,
-                                                        EdgePlane edge, uint32_t W, uint32_t H, uint32_t ssaoRow0, uint32_t ssaoRow1, uint32_t blurRow0,
-                                                        uint32_t blurRow1, int sparseProjTex, SkyReach sky, uint32_t stamp, uint32_t exitStamp, int cullEnabled,
-                                                        PrepRows prep, HalfResScale hs, int onesMargin, uint32_t slice0, uint32_t tileLag)
-{
-    __shared__ f4a s_nz[kBlurPairSW * kBlurPairSH];
-    __shared__ float s_a[kBlurPairSW * kBlurPairSH];
-    __shared__ float s_mid[kBlurTileW * kBlurPairSH];
-    __shared__ uint16_t s_hmask[kBlurTileW * kBlurTileH];
-    const uint32_t w2 = W / 2, gx = (w2 + 63u) / 64u, perSlice = 3u * gx;
-    const uint32_t S = slice0 + blockIdx.x / perSlice, j = blockIdx.x % perSlice;
-    if (j < 2u * gx) {
-        const uint32_t B = 2u * S + j / gx, bx = j % gx;
-        const uint32_t x = bx * 64u + (threadIdx.x & 63u), y = 8u * B + (threadIdx.x >> 6);
-        if (x >= w2 || y < ssaoRow0 || y >= ssaoRow1) return;
-        ssao_wave<true, true, true, ROWS, true>(cb, normal, depth, randvec, ssaoOut, edge, W, H, ssaoRow0, bx, x, y, sparseProjTex, sky, stamp, cullEnabled, prep, hs);
-        return;
-    }
-    if (S < tileLag) return;
-    const uint32_t T = S - tileLag, tx = j - 2u * gx;
-    if (T * (uint32_t)kBlurTileH >= blurRow1 || (T + 1u) * (uint32_t)kBlurTileH <= blurRow0) return;      // a tile row this launch does not owe
-    BlurTileArgs a;
-    a.w = &cb.BlurWeights[0][0];
-    a.e = edge;
-    a.in = ssaoOut;
-    a.out = blurOut;
-    a.w2 = (int)w2;
-    a.h2 = (int)(H / 2);
-    a.x0 = (int)tx * kBlurTileW;
-    a.y0 = (int)T * kBlurTileH;
-    a.row0 = (int)blurRow0;
-    a.row1 = (int)blurRow1;
-    a.borderZ = ndc_to_view(cb, 1.0f);
-    a.tileIndex = T * blur_tiles_x(W) + tx;
-    blur_pair_tile<RECORD>(BlockDevT<false, true>{}, a, exitStamp, onesMargin, (int)ssaoRow0, (int)ssaoRow1, s_nz, s_a, s_mid, s_hmask);
 }
 
 // A later iteration of the blur, both sweeps, replayed (blur_tiles.hpp blur_replay_tile): 8 wavefronts per tile.
@@ -675,7 +568,6 @@ static inline dim3 grid_for(uint32_t width, uint32_t rows, uint32_t rows_per_blo
 hipError_t launch_depth_pairs(const crychic_ssao_constants& cb, const uint32_t* depth, void* edge_base, uint32_t W, uint32_t H, uint32_t stamp,
                               bool writePairs, uint32_t row0, uint32_t rows, hipStream_t stream)
 {
-    const uint32_t onesFirst = row0 * ones_map_cols(W), onesWords = rows * ones_map_cols(W);      // the SSAO pass's rows of the unoccluded-wavefront map
     const EdgePlane e = edge_plane_carve(edge_base, W, H);
     uint32_t c0, cn;
     depth_pass_cell_rows(H, row0, rows, &c0, &cn, depth_margin());
@@ -684,7 +576,7 @@ hipError_t launch_depth_pairs(const crychic_ssao_constants& cb, const uint32_t* 
     const uint32_t segs = (depth_pairs_pitch(W) / 2u + 63u) / 64u;
     const dim3 grid((segs + 3u) / 4u, cn, 1);
 #define CRY_LAUNCH_DP(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, depth, (f4a*)const_cast<void*>(e.pairs), e.geo, e.zcull, stamp, W, H, \
-                                            ssao_cull_params(cb), c0, e.ones + onesFirst, onesWords)
+                                            ssao_cull_params(cb), c0)
     if (writePairs) CRY_LAUNCH_DP(depth_pairs_kernel<true>); else CRY_LAUNCH_DP(depth_pairs_kernel<false>);
 #undef CRY_LAUNCH_DP
     return hipGetLastError();
@@ -732,43 +624,6 @@ hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, con
     else CRY_LAUNCH_SSAO((ssao_kernel<true, false, false, false>));
 #undef CRY_LAUNCH_SSAO
     return hipGetLastError();
-}
-
-// launch_ssao (pairs + maps) and launch_blur_pair as one launch (ssao_pair_kernel).  Returns false, having launched nothing, when the
-// combination does not apply (no workspace maps, blur weights that rule the unoccluded-tile exit out).
-bool launch_ssao_and_blur_pair(const crychic_ssao_constants& cb, const void* normal, const uint32_t* depth, const uint8_t* randvec, uint16_t* ssaoOut,
-                               uint16_t* blurOut, void* edge_base, uint32_t W, uint32_t H, uint32_t ssaoRow0, uint32_t ssaoRows, uint32_t blurRow0,
-                               uint32_t blurRows, bool record, uint32_t stamp, int onesMargin, hipStream_t stream, hipError_t* err)
-{
-    *err = hipSuccess;
-    if (!edge_base || stamp == 0u || ssaoRows == 0 || blurRows == 0 || !blur_weights_positive(cb)) return false;
-    const EdgePlane e = edge_plane_carve(edge_base, W, H);
-    const int sparse = ssao_projtex_is_sparse(cb) ? 1 : 0;
-    SkyReach sky = ssao_sky_reach(cb, W, H);
-    const int cull = ssao_cull_params(cb).enabled ? 1 : 0;
-    uint32_t c0, cn;
-    depth_pass_cell_rows(H, ssaoRow0, ssaoRows, &c0, &cn, depth_margin());
-    const bool limited = c0 > 0u || c0 + cn < zmin_map_rows(H);
-    const PrepRows prep{ 8 * (int)c0 - 2, 8u * cn };
-    if (limited) {
-        sky.y0 = 8 * (int)c0 - 2 < 0 ? 0 : 8 * (int)c0 - 2;
-        sky.y1 = 8 * (int)(c0 + cn) - 2 > (int)H ? (int)H : 8 * (int)(c0 + cn) - 2;
-    }
-    const uint32_t gx = (W / 2u + 63u) / 64u, tileLag = ((uint32_t)onesMargin + 15u) / 16u + 1u;
-    const uint32_t ssaoRow1 = ssaoRow0 + ssaoRows, blurRow1 = blurRow0 + blurRows;
-    const uint32_t t0 = blurRow0 / (uint32_t)kBlurTileH, t1 = (blurRow1 - 1u) / (uint32_t)kBlurTileH;
-    uint32_t slice0 = ssaoRow0 / 16u;
-    slice0 = t0 + tileLag < slice0 ? t0 + tileLag : slice0;
-    uint32_t sliceEnd = (ssaoRow1 + 15u) / 16u;
-    sliceEnd = t1 + tileLag + 1u > sliceEnd ? t1 + tileLag + 1u : sliceEnd;
-    const dim3 grid((sliceEnd - slice0) * 3u * gx, 1, 1);
-#define CRY_LAUNCH_SP(K) hipLaunchKernelGGL(K, grid, dim3(512), 0, stream, cb, (const u2*)normal, depth, (const uint32_t*)randvec, ssaoOut, blurOut, e, W, H, ssaoRow0, \
-                                            ssaoRow1, blurRow0, blurRow1, sparse, sky, stamp, stamp, cull, prep, half_res_scale(W, H), onesMargin, slice0, tileLag)
-    if (limited) { if (record) CRY_LAUNCH_SP((ssao_pair_kernel<true, true>)); else CRY_LAUNCH_SP((ssao_pair_kernel<true, false>)); }
-    else { if (record) CRY_LAUNCH_SP((ssao_pair_kernel<false, true>)); else CRY_LAUNCH_SP((ssao_pair_kernel<false, false>)); }
-#undef CRY_LAUNCH_SP
-    *err = hipGetLastError();
-    return true;
 }
 
 hipError_t launch_blur(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out,

@@ -19,14 +19,6 @@ hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, con
                        const uint8_t* randvec, uint16_t* ambient, void* edge_base, uint32_t W, uint32_t H,
                        uint32_t row0, uint32_t rows, bool emit_ao, bool use_pairs, uint32_t stamp, hipStream_t stream);
 
-// The SSAO pass (pairs plane + maps of launch_depth_pairs with `stamp`) and iteration 0 of the blur chain as ONE launch
-// (kernels.hip ssao_pair_kernel: the blur tiles wait for the SSAO wavefronts of their neighbourhood instead of for the kernel
-// boundary).  ssaoOut / blurOut: the planes launch_ssao / launch_blur_pair would write; same pixels.  Returns false, having
-// launched nothing, when the combination does not apply; *err = the launch status otherwise.
-bool launch_ssao_and_blur_pair(const crychic_ssao_constants& cb, const void* normal, const uint32_t* depth, const uint8_t* randvec, uint16_t* ssaoOut,
-                               uint16_t* blurOut, void* edge_base, uint32_t W, uint32_t H, uint32_t ssaoRow0, uint32_t ssaoRows, uint32_t blurRow0,
-                               uint32_t blurRows, bool record, uint32_t stamp, int onesMargin, hipStream_t stream, hipError_t* err);
-
 // One self-contained sweep of SsaoBlur.hlsl (Ssao::BlurAmbientMap(cmdList, bool), Ssao.cpp:245-293) over half-res rows [row0, row0 + rows).
 hipError_t launch_blur(const crychic_ssao_constants& cb, const void* edge_base, const uint16_t* in, uint16_t* out,
                        uint32_t W, uint32_t H, bool horizontal, uint32_t row0, uint32_t rows, hipStream_t stream);

@@ -600,11 +600,6 @@ CRY_HD uint32_t ssao_pixel(const crychic_ssao_constants& cb, const SsaoCentre& c
 // that emitted ambient values, the frame's stamp if all 64 are 65535 and 0 otherwise.  A tile whose neighbourhood leaves the rows
 // the SSAO pass computed this frame is never settled, so no word is looked at that this frame did not write.
 // CLAMP addressing maps taps beyond the map to its edge texels, so the neighbourhood is clamped to the map, not extended.
-// The word of an emitting wavefront: the frame's stamp when all its ambient values are 65535, the stamp's complement otherwise.  Both
-// values belong to this frame alone (stamps are unique per process), so a word also says "this wavefront's ambient values, normal
-// texels and depths have been written" -- what the fused SSAO + first-blur launch waits for (kernels.hip ssao_pair_kernel).
-CRY_HD uint32_t ones_word(uint32_t stamp, bool allOnes) { return allOnes ? stamp : ~stamp; }
-CRY_HD bool ones_word_written(uint32_t word, uint32_t stamp) { return word == stamp || word == ~stamp; }
 struct OnesRegion { uint32_t c0, c1, r0, r1; };      // inclusive cell columns (64-pixel segments) and half-res rows
 CRY_HD OnesRegion blur_ones_region(uint32_t w2, uint32_t h2, int x0, int y0, int bw, int bh, int margin)
 {
@@ -627,16 +622,7 @@ struct BlurTap {
 // sweep axis: normal CLAMPs in full-res texel space, depth takes the BORDER value, ambient CLAMPs.
 // In two halves, so that a caller can issue the loads of many positions before it decodes the first (blur_tiles.hpp).
 struct BlurTapRaw { u2 nrm; float vz; uint32_t amb; bool inside; };
-// How the SSAO pass's outputs are read: plainly (they come from an earlier launch), or -- kernels.hip CoherentLoads -- with
-// device-coherent loads, when the wavefronts that wrote them belong to the same launch.
-struct PlainLoads {
-    CRY_HD u2 nrm(const u2* p) const { return *p; }
-    CRY_HD float f32(const float* p) const { return *p; }
-    CRY_HD uint32_t u16(const uint16_t* p) const { return *p; }
-    CRY_HD uint32_t u32(const uint32_t* p) const { return *p; }
-};
-template <class Loads = PlainLoads>
-CRY_HD BlurTapRaw blur_fetch_raw(const EdgePlane& e, const uint16_t* __restrict__ amb, int w2, int h2, int xi, int yi, const Loads ld = Loads())
+CRY_HD BlurTapRaw blur_fetch_raw(const EdgePlane& e, const uint16_t* __restrict__ amb, int w2, int h2, int xi, int yi)
 {
     const int cx = clampi(xi, 0, w2 - 1), cy = clampi(yi, 0, h2 - 1);
     const uint32_t idx = mul24((uint32_t)cy, (uint32_t)w2) + (uint32_t)cx;
@@ -644,9 +630,9 @@ CRY_HD BlurTapRaw blur_fetch_raw(const EdgePlane& e, const uint16_t* __restrict_
     src = (yi < 0) ? e.grow + cx : src;
     src = (xi < 0) ? e.gcol + cy : src;
     BlurTapRaw r;
-    r.nrm = ld.nrm(src);
-    r.vz = ld.f32(e.vz + idx);
-    r.amb = ld.u16(amb + idx);
+    r.nrm = *src;
+    r.vz = e.vz[idx];
+    r.amb = amb[idx];
     r.inside = ((uint32_t)xi < (uint32_t)w2) & ((uint32_t)yi < (uint32_t)h2);
     return r;
 }
@@ -658,11 +644,10 @@ CRY_HD BlurTap blur_fetch_decode(const BlurTapRaw& r, float borderZ)
     t.a = unorm16_to_float(r.amb);
     return t;
 }
-template <class Loads = PlainLoads>
 CRY_HD BlurTap blur_fetch(const EdgePlane& e, const uint16_t* __restrict__ amb, float borderZ, int w2, int h2,
-                          int xi, int yi, const Loads ld = Loads())
+                          int xi, int yi)
 {
-    return blur_fetch_decode(blur_fetch_raw(e, amb, w2, h2, xi, yi, ld), borderZ);
+    return blur_fetch_decode(blur_fetch_raw(e, amb, w2, h2, xi, yi), borderZ);
 }
 
 // One output pixel from its 11 taps; fetch(i) returns tap i (i = 5 is the centre).  Accumulation order is the

@@ -211,7 +211,7 @@ void hs_ssao_path(const crychic_ssao_constants* cb, const void* normal, const ui
                 if (!skip && culling && g_cull_masks) g_cull_masks[y * w2 + x] = (uint16_t)(acc[1] | 0x8000u);
                 allOnes = allOnes && ambient[y * w2 + x] == 0xFFFFu;
             }
-            if (pairs) e.ones[y * ones_map_cols(W) + x0 / 64u] = ones_word(stamp, allOnes);      // the unoccluded-wavefront map, as ssao_kernel writes it
+            if (pairs) e.ones[y * ones_map_cols(W) + x0 / 64u] = allOnes ? stamp : 0u;      // the unoccluded-wavefront map, as ssao_kernel writes it
         }
     }
 }
