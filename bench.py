@@ -42,7 +42,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s is the measured copy ceiling
-PMC_PROFILE = os.path.join(ROOT, "profiles", "r03_pmc_counters.json")
+PMC_PROFILE = os.path.join(ROOT, "profiles", "r04_pmc_counters.json")
 
 
 def parse():
@@ -813,7 +813,7 @@ def main():
             return row
 
         kernels = [kernel_row("SSAO pass (depth_pairs_kernel + ssao_kernel)", acc["ssao_ms"], 6.5, "ssao"),
-                   kernel_row("blur, %d sweeps (blur_pair_kernel + %d x blur_replay_kernel)" % (2 * bc, max(bc - 1, 0)), acc["blur_ms"], 7.0 * 2 * bc, "blur"),
+                   kernel_row("blur, %d sweeps (blur_pair_kernel + blur_replay_chain_kernel: iterations 1..%d in one launch)" % (2 * bc, max(bc - 1, 0)), acc["blur_ms"], 7.0 * 2 * bc, "blur"),
                    kernel_row("light_kernel", acc["light_ms"], 52.5, "light")]
         traffic = None
         if pmc and all(k in pmc for k in ("ssao", "blur", "light")):

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 PMC passes of tools/pmc_passes.sh (pmc_table.json) plus the kernel-trace stats of a bench.py run into
-profiles/r03_pmc_counters.json, the file bench.py's `roofline` object reads hardware-counter figures from.
+profiles/r04_pmc_counters.json, the file bench.py's `roofline` object reads hardware-counter figures from.
 
     tools/make_pmc_profile.py <pmc dir with pmc_table.json> <kernel_stats.csv of the same workload> [out.json]
 
-Per pass (ssao = depth_pairs_kernel + ssao_kernel, blur = blur_pair_kernel + (blurCount - 1) x blur_replay_kernel, light) and per launch
+Per pass (ssao = depth_pairs_kernel + ssao_kernel, blur = blur_pair_kernel + blur_replay_chain_kernel, light) and per launch
 of the 4K bench frame:
   hbm_bytes_per_launch  (2 * FETCH_SIZE + WRITE_SIZE) * 1024: FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950
                         (MI355X_MICROARCH.md, HBM section); WRITE_SIZE is exact
@@ -15,7 +15,9 @@ of the 4K bench frame:
                         unprofiled timings.  GRBM_GUI_ACTIVE / 8 is recorded beside it (reads high on dispatches this short)
   l2_read_GBs           TCP_TCC_READ_REQ_sum * 64 B / kernel time
   ta_busy_frac          TA_TA_BUSY_sum / 256 TAs / kernel cycles
-  bound                 the largest of the fractions, by name
+  bound                 the largest of the fractions, by name -- a label, not a diagnosis: round 4 cut light_kernel's VALU instructions by 21 %
+                        without moving its duration; what bounds it is (wavefronts x exposed latency) / resident wavefronts over a
+                        streaming floor (profiles/r04_experiments.txt, occupancy sweep)
 The file records the sha of the kernel sources it was taken on (bench.kernel_source_hash); bench.py prints null instead of
 these figures when the sources have changed since."""
 import csv
@@ -30,7 +32,7 @@ SIMDS, TAS = 1024, 256
 
 def main():
     pmc_dir, stats_csv = sys.argv[1], sys.argv[2]
-    out_path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r03_pmc_counters.json")
+    out_path = sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "profiles", "r04_pmc_counters.json")
     table = json.load(open(os.path.join(pmc_dir, "pmc_table.json")))
     dur = {}
     for r in csv.DictReader(l for l in open(stats_csv) if not l.startswith("#")):
@@ -57,7 +59,7 @@ def main():
     args = type("A", (), {})()
     wl = {"width": 3840, "height": 2160, "blur_count": 4, "lights": 3, "pcf": "literal", "shadow_dim": 4096, "camera": "reference"}
     passes = {"ssao": [("depth_pairs_kernel", 1), ("ssao_kernel<true, true, true, false>", 1)],
-              "blur": [("blur_pair_kernel<true>", 1), ("blur_replay_kernel", wl["blur_count"] - 1)],
+              "blur": [("blur_pair_kernel<true>", 1), ("blur_replay_chain_kernel", 1)],
               "light": [("light_kernel<true, false>", 1)]}
     kernels = {}
     for name, kw in passes.items():
