@@ -5,6 +5,7 @@
 # 2 rocprofv3 kernel trace of the same workload (no legs, so that every cry:: row is the headline configuration)
 # 3 PMC passes on the torch-free driver        4 other configs (1080p / blurCount 1; 8K + 64 point lights)
 # 5 the eight strips of an 8-GPU run, one at a time on this GPU (one frame at a time, and four in flight)
+# 6 the same for 8K + 64 point lights; the kernels' register / LDS / occupancy table
 set -o pipefail
 cd "$(dirname "$0")/.."
 export TMPDIR=/tmp
@@ -46,4 +47,7 @@ python bench.py --steps 100 --warmup 10 $L --width 1920 --height 1080 --blur-cou
 python bench.py --steps 30 --warmup 5 $L --width 7680 --height 4320 --point-lights 8 > "$out/bench_c5_8k_64lights.json" 2>> "$out/bench.err" || exit 1
 tools/strips_rehearsal.sh "$out/strips.txt" 1 > /dev/null || exit 1
 tools/strips_rehearsal.sh "$out/strips_4_in_flight.txt" 4 > /dev/null || exit 1
+bash tools/resusage.sh > "$out/resource_usage.txt" 2>&1
+# (6: the eight strips of BASELINE configs[4], 8K + 64 point lights, is a gpurun call of its own -- ~8 minutes:
+#   tools/strips_rehearsal.sh gpurun_out/<tag>/strips_8k_64lights.txt 1 "--width 7680 --height 4320 --point-lights 8 --steps 30")
 echo "measure_all done"

@@ -1,12 +1,13 @@
 #!/bin/bash
 # Run on the GPU box: what each rank of an 8-GPU run computes per frame, measured one strip at a time on one GPU (no exchange):
-#   tools/strips_rehearsal.sh <out.txt> [frames in flight, default 1 = the benchmark's own mode]
+#   tools/strips_rehearsal.sh <out.txt> [frames in flight, default 1 = the benchmark's own mode] ["extra bench.py flags", e.g. the 8K + 64 lights config]
 cd "$(dirname "$0")/.."
 out=$1
 F=${2:-1}
+X=${3:-}
 : > "$out"
-L="--no-cpu-baseline --no-producers --no-legs --steps 100 --warmup 10 --frames-in-flight $F"
-echo "frames in flight: $F" >> "$out"
+L="--no-cpu-baseline --no-producers --no-legs --steps 100 --warmup 10 --frames-in-flight $F $X"
+echo "frames in flight: $F   extra flags: ${X:-none}" >> "$out"
 full=$(python bench.py $L 2>/dev/null | python -c "import sys, json; print(json.loads(sys.stdin.readline())['ms_per_step'])")
 echo "whole frame, one GPU: $full ms" >> "$out"
 for part in equal balanced; do
