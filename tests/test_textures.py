@@ -325,6 +325,51 @@ def test_cube_map_loader(built_lib, oracle, tmp_path):
     assert lib.crychic_load_dds_rgba8(str(p).encode(), None, 0, C.byref(w), C.byref(h)) == -4
 
 
+def test_cube_face_order_known_answer(built_lib, oracle, hostsim, tmp_path):
+    """Face order and orientation of the sky cube map, end to end (the reference holds no decoded fixture and snowcube1024.dds is not
+    in the checkout, so this is a derived known answer, not a pinned one): a hand-built six-face A8R8G8B8 DDS with one colour per
+    face, plus a black marker texel next to each face's centre on its (s, t) = (0, 0) side, goes through crychic_load_dds_cube_rgba8 and the sky lookup
+    (sky.hlsl:21-47) of an all-sky frame whose camera looks along +X, -X, +Y, -Y, +Z, -Z: the centre pixel shows D3D's face 0 .. 5
+    (DDS order +X, -X, +Y, -Y, +Z, -Z), kernel bodies == oracle, and the marker corner sits where D3D's cube-face axes put it."""
+    import copy
+    from crychic_renderer_amd import geometry as g, scene
+    from crychic_renderer_amd._lib import Camera, PassConstants, lib
+    dim = 8
+    colours = [(250, 10, 10), (10, 250, 10), (10, 10, 250), (250, 250, 10), (250, 10, 250), (10, 250, 250)]      # R, G, B per face
+    payload = b""
+    for k, (r, gg, b) in enumerate(colours):
+        px = np.zeros((dim, dim, 4), np.uint8)
+        px[..., 0], px[..., 1], px[..., 2], px[..., 3] = b, gg, r, 255          # memory order B, G, R, A
+        px[dim // 2 - 1, dim // 2 - 1] = (0, 0, 0, 255)                         # the texel up and to the left of the face centre (towards s = t = 0)
+        payload += px.tobytes()
+    p = tmp_path / "faces.dds"
+    p.write_bytes(cube_header(dim, 1, None, (0xFF0000, 0xFF00, 0xFF, 0xFF000000)) + payload)
+    cube = g.load_dds_cube(str(p))
+    assert np.array_equal(cube, oracle_cube(oracle, str(p)))
+    W = H = 32
+    base = scene.Constants(W, H, shadow_dim=64)
+    views = [((1, 0, 0), (0, 1, 0)), ((-1, 0, 0), (0, 1, 0)), ((0, 1, 0), (0, 0, -1)), ((0, -1, 0), (0, 0, 1)), ((0, 0, 1), (0, 1, 0)), ((0, 0, -1), (0, 1, 0))]
+    depth = np.full((H, W), 0xFFFFFF, np.uint32)
+    z = np.zeros((H, W, 4), np.float32)
+    shadow = np.full((4, 64, 64), 0xFFFFFF, np.uint32)
+    dirs = np.asarray(scene.BASE_LIGHT_DIRS, dtype=np.float32)
+    for face, (look, up) in enumerate(views):
+        cam = copy.deepcopy(base.cam)
+        cam.pos[:] = (0.0, 0.0, 0.0); cam.look[:] = look; cam.up[:] = up
+        cb = PassConstants()
+        assert lib.crychic_update_main_pass_cb(C.byref(cam), W, H, base.shadow_transform.ctypes.data, dirs.ctypes.data, C.byref(cb)) == 0
+        got = hostsim.light(cb, z, z, z, depth, None, shadow, cube, 1, 0.0, flags=1)
+        ref = oracle.deferred_light(oracle_lib.as_oracle_cb(cb, oracle_lib.OrPassConstants), z, z, z, depth, None, shadow, cube, 1, 0.0, sky=True)
+        assert np.array_equal(got, ref), face
+        centre = got[H // 2 + 4, W // 2 + 4, :3]          # just down-right of the centre: clear of the marker's filter footprint
+        assert tuple(int(v) for v in centre) == colours[face], (face, centre)
+        # D3D cube-face axes: (s, t) = (0, 0) is the face's top-left as seen from inside with the face's own "up":
+        # for the +-X and +-Z faces with up = +Y that is the image's top-left corner; +Y is seen with up = -Z, -Y with up = +Z
+        dark = (got[..., :3].astype(int).sum(-1) < 60)
+        ys, xs = np.nonzero(dark)
+        assert len(ys) > 0 and ys.mean() < H / 2 and xs.mean() < W / 2, (face, ys.mean() if len(ys) else None, xs.mean() if len(xs) else None)
+
+
 @pytest.mark.gpu
 def test_loaded_cube_map_lights_a_frame(built_lib, oracle, tmp_path):
     """A cube map that went through the DDS loader is the plane the lighting pass samples: sky + reflections of a small frame ==
