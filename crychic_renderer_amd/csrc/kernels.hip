@@ -334,13 +334,17 @@ __device__ __forceinline__ BlurTileArgs blur_tile_args(const crychic_ssao_consta
 template <bool RECORD>
 __global__ __launch_bounds__(512) void blur_pair_kernel(crychic_ssao_constants cb, EdgePlane edge, const uint16_t* __restrict__ in,
                                                         uint16_t* __restrict__ out, uint32_t W, uint32_t H, uint32_t row0, uint32_t row1,
-                                                        uint32_t stamp, int onesMargin, int ssaoRow0, int ssaoRow1)
+                                                        uint32_t stamp, int onesMargin, int ssaoRow0, int ssaoRow1, uint32_t frameStamp)
 {
     __shared__ f4a s_nz[kBlurPairSW * kBlurPairSH];
     __shared__ float s_a[kBlurPairSW * kBlurPairSH];
     __shared__ float s_mid[kBlurTileW * kBlurPairSH];
     __shared__ uint16_t s_hmask[kBlurTileW * kBlurTileH];
     const BlurTileArgs a = blur_tile_args(cb, edge, in, out, W, H, row0, row1);
+    // The tile's counter of the single-launch chain that follows (blur_replay_chain_kernel): this frame's tag, no iteration done.
+    // Written here, one launch earlier, so that every counter the chain polls was written in this frame -- whatever the workspace
+    // held before, it cannot read as a neighbour's progress.
+    if (RECORD && threadIdx.x == 0) edge.progress[a.tileIndex] = (unsigned long long)frameStamp << 8;
     blur_pair_tile<RECORD>(BlockDev{}, a, stamp, onesMargin, ssaoRow0, ssaoRow1, s_nz, s_a, s_mid, s_hmask);
 }
 
@@ -651,10 +655,11 @@ hipError_t launch_blur_pair(const crychic_ssao_constants& cb, const void* edge_b
     if (rows == 0) return hipSuccess;
     const EdgePlane e = edge_plane_carve(const_cast<void*>(edge_base), W, H);
     // the unoccluded-tile exit needs finite positive weights (x * rcp(x) of a finite positive total) and the SSAO pass's map
+    const uint32_t frameStamp = stamp;
     if (!blur_weights_positive(cb)) stamp = 0u;
     const dim3 grid = blur_tile_grid(W, row0, rows);
 #define CRY_LAUNCH_PAIR(K) hipLaunchKernelGGL(K, grid, dim3(512), 0, stream, cb, e, in, out, W, H, row0, row0 + rows, stamp, onesMargin, \
-                                              (int)ssaoRow0, (int)(ssaoRow0 + ssaoRows))
+                                              (int)ssaoRow0, (int)(ssaoRow0 + ssaoRows), frameStamp)
     if (record) CRY_LAUNCH_PAIR(blur_pair_kernel<true>); else CRY_LAUNCH_PAIR(blur_pair_kernel<false>);
 #undef CRY_LAUNCH_PAIR
     return hipGetLastError();

@@ -247,7 +247,8 @@ def test_recycled_workspace_on_device(ctx, built_lib, oracle):
     """The edge workspace is caller-owned and nothing clears it (ADVICE r2 / VERDICT r2 item 2).  Frame A on context 1; context 1
     destroyed; a DIFFERENT frame B on a new context over the same, uncleared workspace; then frame B again over a workspace whose
     every 32-bit word holds the stamp the next call will draw (read back from the map frame A left: stamps come from one
-    process-wide counter, one per SSAO pass).  Frame B must equal the oracle each time."""
+    process-wide counter, one per SSAO pass), and over one whose every 64-bit word is a finished counter of the blur chain for the
+    upcoming stamp.  Frame B must equal the oracle each time."""
     import fuzz_util
     from crychic_renderer_amd import Context
     W, H, c, scb, depth_a, normal_a, randvec = fuzz_util.sky_probe_case(0)
@@ -282,6 +283,17 @@ def test_recycled_workspace_on_device(ctx, built_lib, oracle):
         assert np.array_equal(run(c2, depth_b, normal_b), want_b)
         words = edge.view(torch.int32).cpu().numpy().view(np.uint32)
         assert (words == nxt).any(), "the pre-filled value was not the stamp the call drew: the probe did not bite"
+        # ... and over a workspace whose every 64-bit word reads "this frame, three blur iterations done" to the single-launch chain
+        # (its per-tile counters: (stamp << 8) | iterations): the launch before the chain rewrites the counters it will poll
+        nxt2 = nxt + 1
+        n64 = edge.numel() // 8
+        edge[:n64 * 8].view(torch.int64).fill_((nxt2 << 8) | 3)
+        assert np.array_equal(run(c2, depth_b, normal_b), want_b)
+        flag = C.c_uint32(9)
+        check(lib.crychic_blur_chain_status(c2.handle, C.c_void_p(torch.cuda.current_stream(dev).cuda_stream), C.byref(flag)))
+        assert flag.value == 0
+        words = edge.view(torch.int32).cpu().numpy().view(np.uint32)
+        assert (words == nxt2).any(), "the pre-filled counter tag was not the stamp the call drew: the probe did not bite"
     finally:
         c2.close()
 
