@@ -68,6 +68,9 @@ def parse():
     ap.add_argument("--no-legs", action="store_true", help="skip the informational legs of the N = 1 line (throughput, intended PCF, covered camera)")
     ap.add_argument("--force-gather", action="store_true",
                     help="run the strip exchange even with one rank: exercises the N > 1 code path on a 1-GPU box")
+    ap.add_argument("--exchange-parts", type=int, default=1,
+                    help="N > 1: crychic_draw_hot_path_shared -- the lighting pass in N row ranges, each range's exchange on a side "
+                         "stream while the next is lit (SURVEY 8e); 1 = the strip, then one exchange (default)")
     ap.add_argument("--exchange", choices=["abi", "torch"], default="abi",
                     help="abi: crychic_allgather_frame (RCCL behind the C ABI); torch: torch.distributed nccl all_gather (fallback)")
     ap.add_argument("--partition", choices=["equal", "balanced"], default="balanced",
@@ -594,6 +597,8 @@ def main():
             if exchange is None:
                 apps[k].mBackBuffer = outs[k]
                 apps[k].Draw(row0, rows)
+            elif abi and args.exchange_parts > 1:
+                exchange.draw(apps[k], k, args.exchange_parts)
             elif abi:
                 apps[k].mBackBuffer = exchange.strip_buffer(k)
                 apps[k].Draw(row0, rows)
@@ -669,6 +674,8 @@ def main():
             args.partition = "equal (the torch.distributed exchange gathers equal strips only)"
         if abi:
             exchange_kind += ": " + ("one group of in-place ncclBroadcasts" if bounds else "in-place ncclAllGather")
+            if args.exchange_parts > 1:
+                exchange_kind = "crychic_draw_hot_path_shared (C ABI, RCCL): %d parts, each one group of in-place ncclBroadcasts on a side stream" % args.exchange_parts
     elif args.warmup > 0:
         for i in range(args.warmup):
             step(i)

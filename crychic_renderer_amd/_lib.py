@@ -114,6 +114,7 @@ PROTOTYPES = {
     "crychic_allgather_frame": (_i, [_vp, _vp, _u32, _u32, _P(_u32), _vp]),
     "crychic_allgather_frame_all": (_i, [_P(_vp), _i, _P(_vp), _u32, _u32, _P(_u32), _P(_vp)]),
     "crychic_comm_barrier": (_i, [_vp, _vp]),
+    "crychic_draw_hot_path_shared": (_i, [_vp, _P(SsaoConstants), _P(PassConstants), _P(FrameDesc), _P(_u32), _u32, _vp]),
     "crychic_create_box": (_i, [_f, _f, _f, _u32, _vp, _u32, _vp, _u32, _P(_u32)]),
     "crychic_create_grid": (_i, [_f, _f, _u32, _u32, _vp, _u32, _vp, _u32, _P(_u32)]),
     "crychic_load_mesh_text": (_i, [C.c_char_p, _vp, _u32, _vp, _u32, _P(_u32), _P(_u32)]),

@@ -302,8 +302,13 @@ int crychic_deferred_light_points(crychic_ctx* ctx, const crychic_pass_constants
     return 0;
 }
 
-int crychic_draw_hot_path(crychic_ctx* ctx, const crychic_ssao_constants* ssaoCB, const crychic_pass_constants* passCB,
-                          const crychic_frame_desc* f, void* stream_)
+}  // extern "C"
+
+// crychic_draw_hot_path with the lighting pass issued as `nparts` consecutive row ranges of the strip (even-aligned, the
+// crychic_strip_rows cut of the strip's rows); after(user, part, row0, rows) runs behind part's launch -- comm.cpp hangs that
+// part's exchange there (crychic_draw_hot_path_shared).  nparts == 1, after == nullptr is crychic_draw_hot_path itself.
+int cry::hot_path_parts(crychic_ctx* ctx, const crychic_ssao_constants* ssaoCB, const crychic_pass_constants* passCB,
+                        const crychic_frame_desc* f, hipStream_t stream, uint32_t nparts, cry::PartHook after, void* user)
 {
     if (int rc = bind(ctx)) return rc;
     if (!ssaoCB || !passCB || !f) return fail(CRYCHIC_E_INVALID_ARG, "null argument");
@@ -315,7 +320,7 @@ int crychic_draw_hot_path(crychic_ctx* ctx, const crychic_ssao_constants* ssaoCB
         return fail(CRYCHIC_E_INVALID_ARG, "null plane in frame descriptor");
     const bool ssaoOn = f->blurCount >= 0;
     if (ssaoOn && (!f->normal_dev || !f->randvec_dev || !f->ambient0_dev)) return fail(CRYCHIC_E_INVALID_ARG, "SSAO planes missing");
-    hipStream_t stream = (hipStream_t)stream_;
+    if (nparts == 0 || nparts > CRYCHIC_MAX_EXCHANGE_PARTS) return fail(CRYCHIC_E_INVALID_ARG, "nparts %u (1 .. %d)", nparts, CRYCHIC_MAX_EXCHANGE_PARTS);
     cry::LightParams P;
     if (int rc = fill_light_params(P, passCB, f->shadow_dev, f->shadowDim, f->cubeDim, W, H, f->numDirLights,
                                    f->pcfSearchRadius, f->flags)) return rc;
@@ -337,10 +342,27 @@ int crychic_draw_hot_path(crychic_ctx* ctx, const crychic_ssao_constants* ssaoCB
         CRY_HIP(hipEventRecord(ctx->ev[1], stream));
     }
     if (prof) CRY_HIP(hipEventRecord(ctx->ev[2], stream));
-    CRY_HIP(cry::launch_light(P, f->g0_dev, f->g1_dev, f->g2_dev, f->depth_dev, ssaoOn ? f->ambient0_dev : nullptr,
-                              f->cube_dev, f->out_rgba8_dev, nullptr, f->row0, f->rows, stream));
-    if (prof) { CRY_HIP(hipEventRecord(ctx->ev[3], stream)); ctx->times_valid = true; }
+    // parts: whole half-res rows each, the last one takes the remainder (and an odd last row of the frame)
+    const uint32_t pairs = f->rows / 2u, per = pairs / nparts;
+    for (uint32_t p = 0; p < nparts; ++p) {
+        const uint32_t r0 = f->row0 + 2u * per * p;
+        const uint32_t r1 = (p + 1u == nparts) ? f->row0 + f->rows : r0 + 2u * per;
+        if (r1 > r0)
+            CRY_HIP(cry::launch_light(P, f->g0_dev, f->g1_dev, f->g2_dev, f->depth_dev, ssaoOn ? f->ambient0_dev : nullptr,
+                                      f->cube_dev, f->out_rgba8_dev, nullptr, r0, r1 - r0, stream));
+        if (prof && p + 1u == nparts) { CRY_HIP(hipEventRecord(ctx->ev[3], stream)); ctx->times_valid = true; }
+        if (after)
+            if (int rc = after(user, p, r0, r1 - r0)) return rc;
+    }
     return 0;
+}
+
+extern "C" {
+
+int crychic_draw_hot_path(crychic_ctx* ctx, const crychic_ssao_constants* ssaoCB, const crychic_pass_constants* passCB,
+                          const crychic_frame_desc* f, void* stream)
+{
+    return cry::hot_path_parts(ctx, ssaoCB, passCB, f, (hipStream_t)stream, 1u, nullptr, nullptr);
 }
 
 int crychic_ctx_set_profiling(crychic_ctx* ctx, int enabled)

@@ -91,6 +91,11 @@ struct crychic_comm {
     ncclComm_t nccl;
     int nranks, rank;
     uint32_t* barrier_word;     // device scratch of crychic_comm_barrier
+    // crychic_draw_hot_path_shared with nparts > 1: the exchange runs on a stream of its own, ordered by events (created on first use)
+    hipStream_t side;
+    hipEvent_t partDone[CRYCHIC_MAX_EXCHANGE_PARTS];    // recorded on the caller's stream behind each lighting part
+    hipEvent_t sideDone;                                // recorded on `side` behind the last part's exchange
+    hipEvent_t sideFree;                                // recorded on the caller's stream at entry: `side` starts no earlier
 };
 
 namespace {
@@ -156,6 +161,27 @@ int enqueue_gather(const Rccl* r, crychic_comm* c, uint8_t* frame, const std::ve
     return 0;
 }
 
+void free_comm(crychic_comm* c)        // the HIP objects only; the RCCL communicator is the caller's business
+{
+    if (c->barrier_word) (void)hipFree(c->barrier_word);
+    for (hipEvent_t e : c->partDone) if (e) (void)hipEventDestroy(e);
+    if (c->sideDone) (void)hipEventDestroy(c->sideDone);
+    if (c->sideFree) (void)hipEventDestroy(c->sideFree);
+    if (c->side) (void)hipStreamDestroy(c->side);
+    delete c;
+}
+
+int side_stream(crychic_comm* c)
+{
+    if (c->side) return 0;
+    hipError_t e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    for (hipEvent_t& ev : c->partDone) if (e == hipSuccess) e = hipEventCreateWithFlags(&ev, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->sideDone, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->sideFree, hipEventDisableTiming);
+    if (e != hipSuccess) return fail(CRYCHIC_E_HIP, "creating the exchange stream failed: %s", hipGetErrorString(e));
+    return 0;
+}
+
 crychic_comm* new_comm(crychic_ctx* ctx, ncclComm_t nccl, int nranks, int rank)
 {
     crychic_comm* c = new (std::nothrow) crychic_comm();
@@ -165,6 +191,9 @@ crychic_comm* new_comm(crychic_ctx* ctx, ncclComm_t nccl, int nranks, int rank)
     c->nranks = nranks;
     c->rank = rank;
     c->barrier_word = nullptr;
+    c->side = nullptr;
+    c->sideDone = c->sideFree = nullptr;
+    for (hipEvent_t& e : c->partDone) e = nullptr;
     if (hipMalloc((void**)&c->barrier_word, sizeof(uint32_t)) != hipSuccess || hipMemset(c->barrier_word, 0, sizeof(uint32_t)) != hipSuccess) {
         if (c->barrier_word) (void)hipFree(c->barrier_word);
         delete c;
@@ -225,7 +254,7 @@ int crychic_comm_create_all(crychic_ctx* const* ctxs, int nranks, crychic_comm**
         out[k] = new_comm(ctxs[k], comms[(size_t)k], nranks, k);
         if (!out[k]) {
             for (int j = 0; j < nranks; ++j) {
-                if (out[j]) { (void)hipFree(out[j]->barrier_word); delete out[j]; out[j] = nullptr; }
+                if (out[j]) { free_comm(out[j]); out[j] = nullptr; }
                 r->CommAbort(comms[(size_t)j]);
             }
             return fail(CRYCHIC_E_HIP, "out of memory creating the communicators");
@@ -239,9 +268,9 @@ void crychic_comm_destroy(crychic_comm* c)
     if (!c) return;
     const Rccl* r = rccl();
     (void)hipSetDevice(c->ctx->device);
+    if (c->side) (void)hipStreamSynchronize(c->side);
     if (r && c->nccl) r->CommDestroy(c->nccl);
-    if (c->barrier_word) (void)hipFree(c->barrier_word);
-    delete c;
+    free_comm(c);
 }
 
 int crychic_comm_abort(crychic_comm* c)
@@ -300,6 +329,82 @@ int crychic_allgather_frame_all(crychic_comm* const* comms, int nranks, uint8_t*
     const ncclResult_t e = r->GroupEnd();
     if (rc) return rc;
     if (e != ncclSuccess) return comm_fail(r, comms[0], "ncclGroupEnd", e);
+    return 0;
+}
+
+namespace {
+struct SharedDraw {
+    const Rccl* r;
+    crychic_comm* c;
+    uint8_t* frame;
+    size_t pitch;
+    uint32_t nparts;
+    const uint32_t* row0;       // per rank
+    const uint32_t* rows;
+    hipStream_t main;
+};
+
+// Behind lighting part p of this rank's strip: part p of EVERY rank's strip travels (one group of in-place ncclBroadcasts, each
+// rooted at the strip's owner), on the side stream, while the caller's stream goes on to light part p + 1.
+int exchange_part(void* user, uint32_t p, uint32_t, uint32_t)
+{
+    SharedDraw& d = *static_cast<SharedDraw*>(user);
+    crychic_comm* c = d.c;
+    hipError_t he = hipEventRecord(c->partDone[p], d.main);
+    if (he == hipSuccess) he = hipStreamWaitEvent(c->side, c->partDone[p], 0);
+    if (he != hipSuccess) return fail(CRYCHIC_E_HIP, "ordering the exchange behind lighting part %u failed: %s", p, hipGetErrorString(he));
+    CRY_NCCL(d.r, c, d.r->GroupStart());
+    ncclResult_t first = ncclSuccess;
+    for (int k = 0; k < c->nranks; ++k) {
+        const uint32_t pairs = d.rows[k] / 2u, per = pairs / d.nparts;          // the same cut api.cpp's hot_path_parts makes
+        const uint32_t r0 = d.row0[k] + 2u * per * p;
+        const uint32_t r1 = (p + 1u == d.nparts) ? d.row0[k] + d.rows[k] : r0 + 2u * per;
+        if (r1 == r0) continue;
+        uint8_t* at = d.frame + (size_t)r0 * d.pitch;
+        const ncclResult_t e = d.r->Broadcast(at, at, (size_t)(r1 - r0) * d.pitch, ncclUint8, k, c->nccl, c->side);
+        if (e != ncclSuccess && first == ncclSuccess) first = e;
+    }
+    const ncclResult_t e = d.r->GroupEnd();
+    if (first == ncclSuccess) first = e;
+    if (first != ncclSuccess) return comm_fail(d.r, c, "ncclBroadcast group (exchange part)", first);
+    return 0;
+}
+}  // namespace
+
+int crychic_draw_hot_path_shared(crychic_comm* c, const crychic_ssao_constants* ssaoCB, const crychic_pass_constants* passCB,
+                                 const crychic_frame_desc* f, const uint32_t* bounds, uint32_t nparts, void* stream_)
+{
+    if (!c || !c->nccl || !f) return fail(CRYCHIC_E_INVALID_ARG, "null communicator / frame descriptor");
+    const Rccl* r = rccl();
+    if (!r) return fail(CRYCHIC_E_COMM, "RCCL unavailable: %s", g_rccl.why);
+    if (nparts == 0 || nparts > CRYCHIC_MAX_EXCHANGE_PARTS) return fail(CRYCHIC_E_INVALID_ARG, "nparts %u (1 .. %d)", nparts, CRYCHIC_MAX_EXCHANGE_PARTS);
+    hipStream_t stream = (hipStream_t)stream_;
+    std::vector<size_t> off, len;
+    if (int rc = strip_table(c, f->W, f->H, bounds, off, len)) return rc;
+    const size_t pitch = (size_t)f->W * 4u;
+    if ((size_t)f->row0 * pitch != off[(size_t)c->rank] || (size_t)f->rows * pitch != len[(size_t)c->rank])
+        return fail(CRYCHIC_E_INVALID_ARG, "the frame descriptor's strip [%u,+%u) is not rank %d's strip of the plan", f->row0, f->rows, c->rank);
+    if (nparts == 1u) {                         // nothing to overlap: the strip, then the one-call exchange, on the caller's stream
+        if (int rc = cry::hot_path_parts(c->ctx, ssaoCB, passCB, f, stream, 1u, nullptr, nullptr)) return rc;
+        return enqueue_gather(r, c, f->out_rgba8_dev, off, len, stream, false);
+    }
+    hipError_t he = hipSetDevice(c->ctx->device);
+    if (he != hipSuccess) return fail(CRYCHIC_E_HIP, "hipSetDevice(%d) failed: %s", c->ctx->device, hipGetErrorString(he));
+    if (int rc = side_stream(c)) return rc;
+    std::vector<uint32_t> row0((size_t)c->nranks), rows((size_t)c->nranks);
+    for (int k = 0; k < c->nranks; ++k) { row0[(size_t)k] = (uint32_t)(off[(size_t)k] / pitch); rows[(size_t)k] = (uint32_t)(len[(size_t)k] / pitch); }
+    SharedDraw d{ r, c, f->out_rgba8_dev, pitch, nparts, row0.data(), rows.data(), stream };
+    // the peers' rows of this buffer may still be read by work enqueued earlier on the caller's stream (a copy-out of the previous
+    // frame): the side stream writes them no earlier than this call's position in that stream
+    he = hipEventRecord(c->sideFree, stream);
+    if (he == hipSuccess) he = hipStreamWaitEvent(c->side, c->sideFree, 0);
+    if (he != hipSuccess) return fail(CRYCHIC_E_HIP, "ordering the exchange stream failed: %s", hipGetErrorString(he));
+    const int rc = cry::hot_path_parts(c->ctx, ssaoCB, passCB, f, stream, nparts, exchange_part, &d);
+    // whatever happened above, the caller's stream joins the side stream again: the frame is complete behind this call
+    he = hipEventRecord(c->sideDone, c->side);
+    if (he == hipSuccess) he = hipStreamWaitEvent(stream, c->sideDone, 0);
+    if (rc) return rc;
+    if (he != hipSuccess) return fail(CRYCHIC_E_HIP, "joining the exchange stream failed: %s", hipGetErrorString(he));
     return 0;
 }
 

@@ -17,4 +17,9 @@ struct crychic_ctx {
 namespace cry {
 // Stores the message crychic_last_error() returns (thread-local) and returns `code`.
 int fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+
+// api.cpp: crychic_draw_hot_path with the lighting pass in `nparts` row ranges and a hook behind each (comm.cpp's overlapped exchange).
+typedef int (*PartHook)(void* user, uint32_t part, uint32_t row0, uint32_t rows);
+int hot_path_parts(crychic_ctx* ctx, const crychic_ssao_constants* ssaoCB, const crychic_pass_constants* passCB,
+                   const crychic_frame_desc* f, hipStream_t stream, uint32_t nparts, PartHook after, void* user);
 }  // namespace cry

@@ -203,7 +203,9 @@ class Crychic:
             f.numPointLights = self.mPointLights.numel() // 48
         return f
 
-    def Draw(self, row0=0, rows=None):  # CRYCHIC.cpp:172-306 (hot part)
+    def Draw(self, row0=0, rows=None, shared=None):  # CRYCHIC.cpp:172-306 (hot part)
+        """shared = (communicator handle, bounds array or None, parts): crychic_draw_hot_path_shared -- the strip AND its exchange,
+        the lighting pass in `parts` row ranges that travel while the next is lit (sharding.StripExchange.draw)."""
         # The descriptor only changes when a plane is re-allocated or a knob is turned: keep it across frames so the
         # per-frame host cost is one FFI call (matters once a strip takes tens of microseconds on 8 GPUs).  The key holds
         # every device pointer and size frame_desc() reads, so replacing any plane object invalidates the cached descriptor.
@@ -221,6 +223,10 @@ class Crychic:
             if len(self._desc) > 16:
                 self._desc.clear()
             f = self._desc[key] = self.frame_desc(row0, rows)
+        if shared is not None:
+            check(lib.crychic_draw_hot_path_shared(shared[0], C.byref(self.mSsaoCB), C.byref(self.mMainPassCB), C.byref(f), shared[1],
+                                                   int(shared[2]), _stream(self.ctx.device)))
+            return
         check(lib.crychic_draw_hot_path(self.ctx.handle, C.byref(self.mSsaoCB), C.byref(self.mMainPassCB), C.byref(f),
                                         _stream(self.ctx.device)))
 

@@ -231,6 +231,12 @@ class StripExchange:
         check(lib.crychic_allgather_frame(self.handle, C.c_void_p(self.render[i % len(self.render)].data_ptr()), self.W, self.H,
                                           self._bounds_arr, C.c_void_p(s.cuda_stream)))
 
+    def draw(self, app, i, parts):
+        """Frame i on torch's current stream through crychic_draw_hot_path_shared: app's strip into this slot's buffer and the
+        exchange, overlapped in `parts` row ranges (1 = the strip, then one exchange -- what Draw + launch do)."""
+        app.mBackBuffer = self.render[i % len(self.render)]
+        app.Draw(self.row0, self.rows, shared=(self.handle, self._bounds_arr, parts))
+
     def barrier(self, stream=None):
         """Stream-ordered rendezvous of all ranks (one-word all-reduce); the caller synchronises the stream."""
         s = torch.cuda.current_stream(self.ctx.device) if stream is None else stream

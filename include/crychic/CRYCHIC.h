@@ -220,13 +220,17 @@ public:
         f.out_rgba8_dev = static_cast<uint8_t*>(mBackBuffer->Data());
         const SsaoConstants& scb = mCurrFrameResource->SsaoCB->Element(0);
         const PassConstants& pcb = mCurrFrameResource->PassCB->Element(0);
-        CrychicThrowIfFailed(crychic_draw_hot_path(md3dDevice->Ctx(), reinterpret_cast<const crychic_ssao_constants*>(&scb),
-                                                   reinterpret_cast<const crychic_pass_constants*>(&pcb), &f, mCommandList->Stream()));
         // Several GPUs, one frame: the peers' strips arrive in place behind this strip's lighting pass (RCCL over xGMI), so the
         // back buffer that Present sees is complete on every GPU.  The reference has one GPU (NodeMask 0, CRYCHIC.cpp:96,105).
+        // With SetExchangeParts(n > 1) the lighting pass runs in n row ranges and each range travels while the next is lit.
         if (mComm)
-            CrychicThrowIfFailed(crychic_allgather_frame(mComm, static_cast<uint8_t*>(mBackBuffer->Data()), mClientWidth, mClientHeight,
-                                                         mStripBounds.empty() ? nullptr : mStripBounds.data(), mCommandList->Stream()));
+            CrychicThrowIfFailed(crychic_draw_hot_path_shared(mComm, reinterpret_cast<const crychic_ssao_constants*>(&scb),
+                                                              reinterpret_cast<const crychic_pass_constants*>(&pcb), &f,
+                                                              mStripBounds.empty() ? nullptr : mStripBounds.data(), mExchangeParts,
+                                                              mCommandList->Stream()));
+        else
+            CrychicThrowIfFailed(crychic_draw_hot_path(md3dDevice->Ctx(), reinterpret_cast<const crychic_ssao_constants*>(&scb),
+                                                       reinterpret_cast<const crychic_pass_constants*>(&pcb), &f, mCommandList->Stream()));
         // :300-305: advance the fence and signal it behind this frame's commands
         mCurrFrameResource->Fence = ++mCurrentFence;
         CrychicHipThrowIfFailed(hipEventRecord(mCurrFrameResource->FenceEvent, mCommandList->Stream()));
@@ -253,6 +257,12 @@ public:
         if (bounds.empty()) CrychicThrowIfFailed(crychic_strip_rows(mClientHeight, nranks, rank, &r0, &rn));
         else { r0 = bounds.at(2 * (size_t)rank); rn = bounds.at(2 * (size_t)rank + 1); }
         SetStrip(r0, rn);
+    }
+    // 1 (default): the strip, then one exchange.  n > 1: crychic_draw_hot_path_shared's overlapped exchange in n parts.
+    void SetExchangeParts(UINT n)
+    {
+        if (n == 0 || n > CRYCHIC_MAX_EXCHANGE_PARTS) throw CrychicException(CRYCHIC_E_INVALID_ARG, "CRYCHIC::SetExchangeParts", __FILE__, __LINE__);
+        mExchangeParts = n;
     }
     void LeaveNode()
     {
@@ -623,6 +633,7 @@ private:
     crychic_comm* mComm = nullptr;            // set by JoinNode: this GPU renders a strip and gathers the others'
     std::vector<uint32_t> mStripBounds;       // nranks x {row0, rows}; empty = crychic_strip_rows
     UINT mStripRow0 = 0, mStripRows = 0;      // this GPU's rows when the frame is shared
+    UINT mExchangeParts = 1;                  // SetExchangeParts
     bool mWholeFrame = true;
     std::unique_ptr<ID3D12Resource> mDepthStencilBuffer, mBackBuffer, mCubeMap;
     UINT mCubeMapSize = 0;

@@ -442,6 +442,17 @@ int crychic_allgather_frame(crychic_comm* comm, uint8_t* frame_rgba8_dev, uint32
 /* The same for a single host thread that owns every rank: frames_rgba8_dev[k] / streams[k] belong to comms[k]. */
 int crychic_allgather_frame_all(crychic_comm* const* comms, int nranks, uint8_t* const* frames_rgba8_dev, uint32_t W, uint32_t H,
                                 const uint32_t* bounds, void* const* streams);
+/* SURVEY.md 8e "overlap by chunking the strip and gathering on a side stream": crychic_draw_hot_path for this rank's strip
+ * (frame->row0 / rows must be this rank's entry of the plan, frame->out_rgba8_dev the full W x H frame) AND the exchange, with the
+ * lighting pass issued in `nparts` (1 .. CRYCHIC_MAX_EXCHANGE_PARTS) consecutive row ranges: as soon as range p is lit, range p of
+ * every rank's strip travels (one group of in-place ncclBroadcasts on a stream the communicator owns) while the caller's stream
+ * lights range p + 1.  Ranges are whole half-res rows -- the crychic_strip_rows cut of each strip's rows -- so the image is the
+ * one crychic_draw_hot_path + crychic_allgather_frame produce, bit for bit.  On return the caller's stream is ordered behind the last
+ * range's exchange (no host wait).  nparts == 1 is exactly those two calls on the caller's stream.  Every rank must call it with
+ * the same bounds and nparts, in the same order relative to the communicator's other collectives.  One process per GPU only. */
+#define CRYCHIC_MAX_EXCHANGE_PARTS 8
+int crychic_draw_hot_path_shared(crychic_comm* comm, const crychic_ssao_constants* ssaoCB, const crychic_pass_constants* passCB,
+                                 const crychic_frame_desc* frame, const uint32_t* bounds, uint32_t nparts, void* stream);
 /* Stream-ordered rendezvous of all ranks (a one-word ncclAllReduce): brackets timed regions; no host wait inside. */
 int crychic_comm_barrier(crychic_comm* comm, void* stream);
 

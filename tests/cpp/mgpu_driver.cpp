@@ -2,7 +2,7 @@
 // every rank runs CRYCHIC::Initialize / Update / Draw on its own scene (producer passes on the device), joined by
 // CRYCHIC::JoinNode, so Draw renders the rank's row strip and crychic_allgather_frame (RCCL) completes the back buffer.
 //
-//   mgpu_driver rank <nranks> <rank> <idfile> <dir> <W> <H> [ragged]   one process per GPU (rank r uses device r); rank 0 writes
+//   mgpu_driver rank <nranks> <rank> <idfile> <dir> <W> <H> [ragged] [parts=N]   one process per GPU (rank r uses device r); rank 0 writes
 //                                                                      the 128-byte rendezvous id to <idfile>, the others wait for it
 //   mgpu_driver all <nranks> <dir> <W> <H>                             one process, one thread, every GPU (crychic_comm_create_all)
 //
@@ -76,7 +76,13 @@ int main(int argc, char** argv)
             const int nranks = std::atoi(argv[2]), rank = std::atoi(argv[3]);
             const std::string idfile = argv[4], dir = argv[5];
             const UINT W = std::atoi(argv[6]), H = std::atoi(argv[7]);
-            const bool ragged = argc > 8 && std::string(argv[8]) == "ragged";
+            bool ragged = false;
+            UINT parts = 1;
+            for (int a = 8; a < argc; ++a) {
+                const std::string o = argv[a];
+                if (o == "ragged") ragged = true;
+                else if (o.rfind("parts=", 0) == 0) parts = (UINT)std::atoi(o.c_str() + 6);      // CRYCHIC::SetExchangeParts
+            }
             uint8_t id[CRYCHIC_COMM_ID_BYTES];
             if (rank == 0) {
                 CrychicThrowIfFailed(crychic_comm_unique_id(id));
@@ -97,6 +103,7 @@ int main(int argc, char** argv)
                 dump(dir + "/frame_single.bin", frame_of(*app, W, H).data(), (size_t)W * H * 4);
             }
             app->JoinNode(nranks, rank, id, ragged ? ragged_bounds(nranks, H) : std::vector<uint32_t>{});
+            app->SetExchangeParts(parts);
             for (int frame = 0; frame < 3; ++frame) { gt.Tick(1.0f / 60.0f); app->Update(gt); app->Draw(gt); }
             dump(dir + "/frame_" + std::to_string(rank) + ".bin", frame_of(*app, W, H).data(), (size_t)W * H * 4);
             app->LeaveNode();
@@ -134,7 +141,7 @@ int main(int argc, char** argv)
             std::printf("mgpu all %d ok\n", nranks);
             return 0;
         }
-        std::fprintf(stderr, "usage: mgpu_driver rank <nranks> <rank> <idfile> <dir> <W> <H> [ragged] | all <nranks> <dir> <W> <H>\n");
+        std::fprintf(stderr, "usage: mgpu_driver rank <nranks> <rank> <idfile> <dir> <W> <H> [ragged] [parts=N] | all <nranks> <dir> <W> <H>\n");
         return 2;
     } catch (const std::exception& e) {
         std::fprintf(stderr, "exception: %s\n", e.what());

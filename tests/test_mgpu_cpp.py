@@ -19,7 +19,7 @@ def test_mgpu_driver_compiles(built_lib):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["rank", "rank-ragged", "all"])
+@pytest.mark.parametrize("mode", ["rank", "rank-ragged", "rank-parts", "all"])
 def test_cpp_host_single_rank_rccl(built_lib, tmp_path, mode):
     exe = build_driver("mgpu_driver")
     W, H = 256, 144
@@ -27,7 +27,8 @@ def test_cpp_host_single_rank_rccl(built_lib, tmp_path, mode):
     if mode == "all":
         cmd = [exe, "all", "1", d, str(W), str(H)]
     else:
-        cmd = [exe, "rank", "1", "0", os.path.join(d, "id.bin"), d, str(W), str(H)] + (["ragged"] if mode == "rank-ragged" else [])
+        cmd = [exe, "rank", "1", "0", os.path.join(d, "id.bin"), d, str(W), str(H)] + {"rank-ragged": ["ragged"], "rank-parts": ["parts=3"]}.get(mode, [])     # parts=3: crychic_draw_hot_path_shared's
+        #                                                                  side-stream exchange, lighting in three row ranges
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     single = np.fromfile(os.path.join(d, "frame_single.bin"), dtype=np.uint8)

@@ -22,13 +22,16 @@ def free_port():
     return p
 
 
-@pytest.mark.parametrize("exchange,inflight,partition", [("abi", 1, "equal"), ("abi", 2, "equal"), ("abi", 2, "balanced"), ("torch", 2, "equal")])
-def test_bench_gather_path_single_rank_rccl(built_lib, exchange, inflight, partition):
+@pytest.mark.parametrize("exchange,inflight,partition,parts", [("abi", 1, "equal", 1), ("abi", 2, "equal", 1), ("abi", 2, "balanced", 1), ("torch", 2, "equal", 1),
+                                                                ("abi", 1, "equal", 3), ("abi", 2, "balanced", 4)])
+def test_bench_gather_path_single_rank_rccl(built_lib, exchange, inflight, partition, parts):
     """bench.py's N > 1 path with one rank: gloo control plane, the RCCL exchange behind the C ABI (or the torch nccl
     fallback), frames in flight; bench.py itself compares the gathered frame with a direct render and exits non-zero on a
-    difference (config.exchange_verified)."""
+    difference (config.exchange_verified).  parts > 1: crychic_draw_hot_path_shared -- the lighting pass in row ranges, each range's
+    exchange on the communicator's side stream."""
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--force-gather", "--exchange", exchange, "--frames-in-flight", str(inflight),
+           "--exchange-parts", str(parts),
            "--partition", partition, "--steps", "7", "--warmup", "3", "--width", "640", "--height", "360", "--shadow-dim", "512", "--cube-dim", "64",
            "--no-cpu-baseline", "--no-producers", "--timeout", "400"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
@@ -39,7 +42,8 @@ def test_bench_gather_path_single_rank_rccl(built_lib, exchange, inflight, parti
     assert out["n_gpus"] == 1 and out["value"] > 0
     assert out["config"]["exchange_verified"] is True
     assert out["config"]["frames_in_flight"] == inflight
-    assert ("crychic_allgather_frame" in out["config"]["exchange"]) == (exchange == "abi"), out["config"]["exchange"]
+    assert ("crychic_allgather_frame" in out["config"]["exchange"]) == (exchange == "abi" and parts == 1), out["config"]["exchange"]
+    assert ("crychic_draw_hot_path_shared" in out["config"]["exchange"]) == (parts > 1), out["config"]["exchange"]
 
 
 def test_bench_balanced_plan_falls_back_to_equal(built_lib):
@@ -99,6 +103,17 @@ def test_allgather_frame_abi_single_rank(built_lib):
     assert lib.crychic_allgather_frame(ex.handle, C.c_void_p(frame.data_ptr()), W, H, bad, None) == -1
     assert b"strips cover" in lib.crychic_last_error()
     assert lib.crychic_allgather_frame(None, C.c_void_p(frame.data_ptr()), W, H, None, None) == -1
+    # the overlapped form refuses a part count outside 1 .. 8, a null communicator and a strip that is not the rank's own
+    from crychic_renderer_amd._lib import FrameDesc, SsaoConstants, PassConstants
+    f = FrameDesc()
+    f.W, f.H, f.row0, f.rows = W, H, 0, H
+    for parts in (0, 9):
+        assert lib.crychic_draw_hot_path_shared(ex.handle, C.byref(SsaoConstants()), C.byref(PassConstants()), C.byref(f), None, parts, None) == -1
+        assert b"nparts" in lib.crychic_last_error()
+    assert lib.crychic_draw_hot_path_shared(None, C.byref(SsaoConstants()), C.byref(PassConstants()), C.byref(f), None, 2, None) == -1
+    f.rows = H - 2
+    assert lib.crychic_draw_hot_path_shared(ex.handle, C.byref(SsaoConstants()), C.byref(PassConstants()), C.byref(f), None, 2, None) == -1
+    assert b"is not rank 0's strip" in lib.crychic_last_error()
     # a rank outside the communicator size is refused without touching RCCL
     h = C.c_void_p()
     assert lib.crychic_comm_create(ctx.handle, 2, 2, (C.c_uint8 * 128)(), C.byref(h)) == -1 and not h.value

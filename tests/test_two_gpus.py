@@ -53,14 +53,14 @@ def run_all(procs, timeout):
 
 
 @pytest.mark.parametrize("n", [2, 4])
-@pytest.mark.parametrize("partition", ["balanced", "equal"])
-def test_bench_two_or_more_ranks_on_rccl(built_lib, n, partition):
+@pytest.mark.parametrize("partition,parts", [("balanced", 1), ("equal", 1), ("balanced", 3)])
+def test_bench_two_or_more_ranks_on_rccl(built_lib, n, partition, parts):
     """`python bench.py --gpus N` (self-spawning launcher): equal strips + in-place ncclAllGather -> frame check on every rank ->
     (balanced) measured ragged plan + grouped ncclBroadcasts -> the same check.  bench.py exits non-zero if the gathered frame
-    differs between ranks or from the frame one GPU renders alone."""
+    differs between ranks or from the frame one GPU renders alone.  parts = 3: the overlapped exchange (crychic_draw_hot_path_shared)."""
     need(n)
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "3", "--warmup", "2", "--width", "640", "--height", "360",
-           "--shadow-dim", "512", "--cube-dim", "64", "--partition", partition, "--no-cpu-baseline", "--no-producers", "--timeout", "300"]
+           "--shadow-dim", "512", "--cube-dim", "64", "--partition", partition, "--exchange-parts", str(parts), "--no-cpu-baseline", "--no-producers", "--timeout", "300"]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
         env.pop(k, None)
@@ -71,23 +71,24 @@ def test_bench_two_or_more_ranks_on_rccl(built_lib, n, partition):
     out = json.loads(lines[0])
     assert out["n_gpus"] == n and out["value"] > 0 and out["scaling"] == "strong"
     assert out["config"]["exchange_verified"] is True
-    assert "crychic_allgather_frame" in out["config"]["exchange"], out["config"]["exchange"]
-    if partition == "balanced":
+    assert ("crychic_allgather_frame" if parts == 1 else "crychic_draw_hot_path_shared") in out["config"]["exchange"], out["config"]["exchange"]
+    if partition == "balanced" and parts == 1:
         assert "ncclBroadcast" in out["config"]["exchange"] or out["config"]["partition"].startswith("equal (fallback"), out["config"]
 
 
 @pytest.mark.parametrize("n", [2, 3])
-@pytest.mark.parametrize("ragged", [False, True])
+@pytest.mark.parametrize("ragged", [False, True, "parts"])
 def test_cpp_host_one_process_per_gpu(built_lib, tmp_path, n, ragged):
     """tests/cpp/mgpu_driver `rank` x N (no Python in the ranks): crychic_comm_unique_id -> file rendezvous -> crychic_comm_create ->
-    CRYCHIC::JoinNode -> Draw; every rank's gathered frame == the frame rank 0 rendered alone, byte for byte."""
+    CRYCHIC::JoinNode -> Draw; every rank's gathered frame == the frame rank 0 rendered alone, byte for byte.  "parts": ragged strips
+    with crychic_draw_hot_path_shared's overlapped exchange (lighting in three row ranges, each travelling on the side stream)."""
     need(n)
     from test_cpp_veneer import build_driver
     exe = build_driver("mgpu_driver")
     W, H = 256, 144
     d = str(tmp_path)
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([exe, "rank", str(n), str(r), os.path.join(d, "id.bin"), d, str(W), str(H)] + (["ragged"] if ragged else []),
+    procs = [subprocess.Popen([exe, "rank", str(n), str(r), os.path.join(d, "id.bin"), d, str(W), str(H)] + {True: ["ragged"], "parts": ["ragged", "parts=3"]}.get(ragged, []),
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, env=env) for r in range(n)]
     res = run_all(procs, 300)
     assert all(rc == 0 for rc, _, _ in res), "\n".join("rank %d rc %d: %s %s" % (i, rc, so[-500:], se[-1500:]) for i, (rc, so, se) in enumerate(res))
