@@ -746,6 +746,22 @@ def main():
             a2.set_profiling(False)
             legs["pcf_intended"] = dict(leg(wall, W * H), frame_ms_median_hipevent=round(med, 4), light_ms=round(lt, 4))
             del a2
+        # (d) the cube map with its mip chain bound, as the reference binds snowcube1024.dds' (CRYCHIC.cpp:1148-1151; the file is not in
+        # the checkout and the benchmark's cube map is a procedural level 0, so `value` is quoted without a chain): trilinear
+        # reflection and sky lookups, level of detail from the pixel quads (light_kernel<.., MIPS>)
+        if not args.point_lights:
+            from crychic_renderer_amd import geometry
+            chain, nlev = geometry.cube_mip_chain(planes["cube"].cpu().numpy())
+            a4 = new_app()
+            a4.set_cube_map(torch.from_numpy(chain).to(dev), dim=int(planes["cube"].shape[1]), levels=nlev)
+            a4.mBackBuffer = torch.zeros_like(planes["out"])
+            wall, med = frame_stats(a4, row0, rows, nleg)
+            a4.set_profiling(True)
+            a4.Draw(row0, rows)
+            lt = a4.last_pass_times()["light_ms"]
+            a4.set_profiling(False)
+            legs["cube_mip_chain"] = dict(leg(wall, W * H), frame_ms_median_hipevent=round(med, 4), light_ms=round(lt, 4), cube_levels=nlev)
+            del a4, chain
         # (c, second) a camera pitched down until every pixel is covered: no sky, every G-buffer texel is read
         if args.camera == "reference":
             args.camera = "covered"

@@ -121,6 +121,7 @@ PROTOTYPES = {
     "crychic_load_dds_rgba8": (_i, [C.c_char_p, _vp, _sz, _P(_u32), _P(_u32)]),
     "crychic_load_dds_rgba8_mips": (_i, [C.c_char_p, _vp, _sz, _P(_u32), _P(_u32), _P(_u32)]),
     "crychic_load_dds_cube_rgba8": (_i, [C.c_char_p, _vp, _sz, _P(_u32)]),
+    "crychic_load_dds_cube_rgba8_mips": (_i, [C.c_char_p, _vp, C.c_size_t, _P(_u32), _P(_u32)]),
     "crychic_save_ppm": (_i, [C.c_char_p, _vp, _u32, _u32]),
     "crychic_raster_workspace_bytes": (_sz, [C.c_uint64, _u32, _u32]),
     "crychic_raster_status": (_i, [_vp, _vp, _P(_u32)]),

@@ -146,6 +146,10 @@ int fill_light_params(cry::LightParams& P, const crychic_pass_constants* cb, con
     P.H = H;
     P.numDirLights = numDirLights;
     P.flags = flags;
+    // CRYCHIC_LIGHT_CUBE_LEVELS: the cube map's mip chain (0 / 1 = level 0 alone); a chain ends at 1 x 1 at the latest
+    P.cubeLevels = (flags >> 16) & 15u;
+    { uint32_t full = 1; for (uint32_t m = cubeDim; m > 1u; m >>= 1) ++full;
+      if (P.cubeLevels > full) return fail(CRYCHIC_E_INVALID_ARG, "%u cube map levels, a %u-texel face has at most %u", P.cubeLevels, cubeDim, full); }
     P.pointLights = nullptr;
     P.numPointLights = 0;
     P.shadowWIsOne = cry::light_shadow_w_is_one(P.ShadowTransforms) ? 1u : 0u;
@@ -154,6 +158,14 @@ int fill_light_params(cry::LightParams& P, const crychic_pass_constants* cb, con
     P.rcpW = cry::rcp((float)W);          // sky_pixel's pixel-centre uv: (x + 0.5) * rcp(W), the reciprocal taken once
     P.rcpH = cry::rcp((float)H);
     cry::light_params_derive(P);
+    return 0;
+}
+
+// With a mip chain the level of detail comes from 2 x 2 pixel quads: a call's rows have to be whole quad rows.
+int check_chain_rows(const cry::LightParams& P, uint32_t row0, uint32_t rows, uint32_t H)
+{
+    if (P.cubeLevels > 1u && ((row0 & 1u) || ((rows & 1u) && row0 + rows != H)))
+        return fail(CRYCHIC_E_INVALID_ARG, "rows [%u,+%u): with a cube map mip chain a call covers whole pixel quads (even row0; even rows unless they end the frame)", row0, rows);
     return 0;
 }
 
@@ -274,6 +286,7 @@ int crychic_deferred_light(crychic_ctx* ctx, const crychic_pass_constants* cb, c
     if (row0 > H || rows > H - row0) return fail(CRYCHIC_E_INVALID_ARG, "rows [%u,+%u) outside the %u-row frame", row0, rows, H);
     cry::LightParams P;
     if (int rc = fill_light_params(P, cb, shadow_dev, shadowDim, cubeDim, W, H, numDirLights, pcfSearchRadius, flags)) return rc;
+    if (int rc = check_chain_rows(P, row0, rows, H)) return rc;
     CRY_HIP(cry::launch_light(P, g0_dev, g1_dev, g2_dev, depth_dev, ambient_dev, cube_dev, out_rgba8_dev, radiance_out_dev,
                               row0, rows, (hipStream_t)stream));
     return 0;
@@ -297,6 +310,7 @@ int crychic_deferred_light_points(crychic_ctx* ctx, const crychic_pass_constants
     if (int rc = fill_light_params(P, cb, shadow_dev, shadowDim, cubeDim, W, H, numDirLights, pcfSearchRadius, flags)) return rc;
     P.pointLights = point_lights_dev;
     P.numPointLights = numPointLights;
+    if (int rc = check_chain_rows(P, row0, rows, H)) return rc;
     CRY_HIP(cry::launch_light(P, g0_dev, g1_dev, g2_dev, depth_dev, ambient_dev, cube_dev, out_rgba8_dev, radiance_out_dev,
                               row0, rows, (hipStream_t)stream));
     return 0;

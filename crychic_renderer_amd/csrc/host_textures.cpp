@@ -195,8 +195,9 @@ int load_dds(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32_t* w
     return 0;
 }
 
-// The sky cube map: level 0 of each of the six faces, stacked in the file's (= D3D's) face order.
-int load_dds_cube(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32_t* dim)
+// The sky cube map: the six faces in the file's (= D3D's) order.  wantMips false: level 0 of each face, stacked.  Otherwise every
+// level the file stores, re-ordered level after level (each level six faces) -- the layout light_core.hpp's cube_trilinear reads.
+int load_dds_cube(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32_t* dim, uint32_t* mipLevels, bool wantMips)
 {
     if (!path) return CRYCHIC_E_INVALID_ARG;
     std::ifstream in(path, std::ios::binary);
@@ -204,19 +205,34 @@ int load_dds_cube(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32
     std::vector<uint8_t> f((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
     DdsInfo d;
     if (!parse_header(f, d) || !d.cube) return CRYCHIC_E_UNSUPPORTED;
-    if (d.width != d.height || d.width > 16384u) return CRYCHIC_E_UNSUPPORTED;
+    if (d.width != d.height || d.width == 0 || d.width > 16384u) return CRYCHIC_E_UNSUPPORTED;
     uint32_t full = 1;
     for (uint32_t m = d.width; m > 1; m >>= 1) ++full;
     if (d.fileLevels > full) return CRYCHIC_E_UNSUPPORTED;
+    const uint32_t outLevels = wantMips ? d.fileLevels : 1u;
     if (dim) *dim = d.width;
+    if (mipLevels) *mipLevels = outLevels;
     if (!rgba8) return 0;
-    const size_t faceOut = (size_t)d.width * d.width * 4;
-    if (capacityBytes < 6 * faceOut) return CRYCHIC_E_INVALID_ARG;
-    size_t faceFile = 0;                                          // a face's whole chain in the file
-    { uint32_t w = d.width; for (uint32_t k = 0; k < d.fileLevels; ++k) { faceFile += level_file_bytes(d, w, w); w = w > 1 ? w >> 1 : 1; } }
+    size_t faceFile = 0, need = 0;                                // a face's whole chain in the file; the output's size
+    { uint32_t w = d.width;
+      for (uint32_t k = 0; k < d.fileLevels; ++k) {
+          faceFile += level_file_bytes(d, w, w);
+          if (k < outLevels) need += (size_t)6 * w * w * 4;
+          w = w > 1 ? w >> 1 : 1;
+      } }
+    if (capacityBytes < need) return CRYCHIC_E_INVALID_ARG;
     if (f.size() - d.dataOffset < 6 * faceFile) return CRYCHIC_E_INVALID_ARG;      // truncated payload
-    for (uint32_t face = 0; face < 6; ++face)
-        decode_level(d, f.data() + d.dataOffset + face * faceFile, d.width, d.width, rgba8 + face * faceOut);
+    for (uint32_t face = 0; face < 6; ++face) {
+        const uint8_t* src = f.data() + d.dataOffset + face * faceFile;
+        uint8_t* levelOut = rgba8;
+        uint32_t w = d.width;
+        for (uint32_t k = 0; k < outLevels; ++k) {
+            decode_level(d, src, w, w, levelOut + (size_t)face * w * w * 4);
+            src += level_file_bytes(d, w, w);
+            levelOut += (size_t)6 * w * w * 4;
+            w = w > 1 ? w >> 1 : 1;
+        }
+    }
     return 0;
 }
 
@@ -225,7 +241,13 @@ int load_dds_cube(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32
 extern "C" int crychic_load_dds_cube_rgba8(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32_t* dim)
 {
     if (!dim) return CRYCHIC_E_INVALID_ARG;
-    return load_dds_cube(path, rgba8, capacityBytes, dim);
+    return load_dds_cube(path, rgba8, capacityBytes, dim, nullptr, false);
+}
+
+extern "C" int crychic_load_dds_cube_rgba8_mips(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32_t* dim, uint32_t* mipLevels)
+{
+    if (!dim || !mipLevels) return CRYCHIC_E_INVALID_ARG;
+    return load_dds_cube(path, rgba8, capacityBytes, dim, mipLevels, true);
 }
 
 extern "C" int crychic_load_dds_rgba8(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32_t* width, uint32_t* height)

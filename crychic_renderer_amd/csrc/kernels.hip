@@ -439,7 +439,38 @@ __global__ __launch_bounds__(512) void blur_replay_chain_kernel(crychic_ssao_con
 
 // ---- deferred lighting -----------------------------------------------------------------------------------------
 // Shaders/DeferredShading.hlsl:23-101 as a full-screen pass over rows [row0, row1), masked by depth < 1.
-template <bool ZERO_RADIUS, bool FIX>
+// MIPS (the cube map holds a mip chain, P.cubeLevels > 1): a wavefront covers 32 x 2 pixels instead of 64 x 1, so that every 2 x 2
+// quad of the frame lies inside one wavefront -- the x neighbour is lane ^ 1, the y neighbour lane ^ 32 -- and the level of detail of
+// the reflection lookup comes from the neighbours' reflection vectors without a second pass (light_core.hpp "TextureCube.Sample
+// with the mip chain bound").
+template <bool MIPS>
+__device__ __forceinline__ void light_tile_pixel(uint32_t bx, uint32_t by, uint32_t row0, uint32_t& x, uint32_t& y)
+{
+    if (MIPS) {
+        const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+        x = bx * 64u + (wave & 1u) * 32u + (lane & 31u);
+        y = row0 + by * 4u + (wave >> 1) * 2u + (lane >> 5);
+    } else {
+        x = bx * 64u + (threadIdx.x & 63u);
+        y = row0 + by * 4u + (threadIdx.x >> 6);
+    }
+}
+// The level of detail of this lane's reflection lookup; every lane of the wavefront calls it (converged).  `r` is the lane's
+// reflection vector when `covered`.  A neighbour the pass does not shade contributes a zero derivative (the oracle's definition).
+__device__ __forceinline__ float quad_reflection_lod(const LightParams& P, bool covered, f3 r, uint32_t x, uint32_t y)
+{
+    const unsigned long long mask = __builtin_amdgcn_ballot_w64(covered);
+    const uint32_t lane = threadIdx.x & 63u;
+    const f3 nx{ __shfl_xor(r.x, 1), __shfl_xor(r.y, 1), __shfl_xor(r.z, 1) };
+    const f3 ny{ __shfl_xor(r.x, 32), __shfl_xor(r.y, 32), __shfl_xor(r.z, 32) };
+    const bool hasX = (mask >> (lane ^ 1u)) & 1ull, hasY = (mask >> (lane ^ 32u)) & 1ull;
+    f3 ddx{ 0.0f, 0.0f, 0.0f }, ddy{ 0.0f, 0.0f, 0.0f };
+    if (hasX) ddx = (x & 1u) ? f3{ r.x - nx.x, r.y - nx.y, r.z - nx.z } : f3{ nx.x - r.x, nx.y - r.y, nx.z - r.z };
+    if (hasY) ddy = (y & 1u) ? f3{ r.x - ny.x, r.y - ny.y, r.z - ny.z } : f3{ ny.x - r.x, ny.y - r.y, ny.z - r.z };
+    return cube_lod(P.cubeDim, P.cubeLevels, r, ddx, ddy);
+}
+
+template <bool ZERO_RADIUS, bool FIX, bool MIPS = false>
 __global__ __launch_bounds__(256) void light_kernel(LightParams P, const f4a* __restrict__ g0,
                                                     const f4a* __restrict__ g1, const f4a* __restrict__ g2,
                                                     const uint32_t* __restrict__ depth,
@@ -449,8 +480,25 @@ __global__ __launch_bounds__(256) void light_kernel(LightParams P, const f4a* __
 {
     uint32_t bx, by;
     tile_origin<0>(bx, by);
-    const uint32_t x = bx * 64u + (threadIdx.x & 63u);
-    const uint32_t y = row0 + by * 4u + (threadIdx.x >> 6);
+    uint32_t x, y;
+    light_tile_pixel<MIPS>(bx, by, row0, x, y);
+    if (MIPS) {
+        const bool in = x < P.W && y < row1;
+        const uint32_t idx = in ? y * P.W + x : 0u;
+        const bool covered = in && (depth[idx] & 0x00FFFFFFu) < 0x00FFFFFFu;
+        f4a G0{ 0, 0, 0, 0 }, G2{ 0, 0, 0, 0 };
+        f3 r{ 0.0f, 0.0f, 0.0f };
+        if (covered) { G0 = g0[idx]; G2 = g2[idx]; r = reflection_dir(P, G0, G2); }
+        const float lod = quad_reflection_lod(P, covered, r, x, y);
+        if (!in) return;
+        f4 lit;
+        if (covered) lit = light_pixel<ZERO_RADIUS, NoPointLights, FIX, CubeChain>(P, G0, g1[idx], G2, ambient, cube, NoPointLights(), CubeChain{ lod });
+        else if (P.flags & CRYCHIC_LIGHT_SKY) lit = sky_pixel_chain(P, cube, x, y);
+        else lit = f4{ 0.690196097f, 0.768627524f, 0.870588303f, 1.0f };
+        if (radiance) radiance[idx] = f4a{ lit.x, lit.y, lit.z, lit.w };
+        out[idx] = pack_rgba8(lit);
+        return;
+    }
     if (x >= P.W || y >= row1) return;
     const uint32_t idx = y * P.W + x;
     f4 lit;
@@ -473,7 +521,7 @@ __global__ __launch_bounds__(256) void light_kernel(LightParams P, const f4a* __
 // against the box (sphere of radius FalloffEnd vs AABB, conservatively inflated) and sets the light's bit in an LDS mask;
 // each pixel finally walks the set bits in ascending index order -- the accumulation order of the un-culled loop -- and
 // applies the exact per-pixel range test, so culling never changes a bit of the result.
-template <bool ZERO_RADIUS>
+template <bool ZERO_RADIUS, bool MIPS = false>
 __global__ __launch_bounds__(256) void light_points_kernel(LightParams P, const f4a* __restrict__ g0, const f4a* __restrict__ g1,
                                                            const f4a* __restrict__ g2, const uint32_t* __restrict__ depth,
                                                            const uint16_t* __restrict__ ambient, const uint32_t* __restrict__ cube,
@@ -484,8 +532,8 @@ __global__ __launch_bounds__(256) void light_points_kernel(LightParams P, const 
     __shared__ uint32_t s_mask[kMaxPointLights / 32];
     uint32_t bx, by;
     tile_origin<0>(bx, by);
-    const uint32_t x = bx * 64u + (threadIdx.x & 63u);
-    const uint32_t y = row0 + by * 4u + (threadIdx.x >> 6);
+    uint32_t x, y;
+    light_tile_pixel<MIPS>(bx, by, row0, x, y);             // MIPS: 32 x 2 pixels per wavefront (quads inside a wavefront)
     const bool inFrame = (x < P.W) && (y < row1);
     const uint32_t idx = inFrame ? y * P.W + x : 0u;
     const bool covered = inFrame && ((depth[idx] & 0x00FFFFFFu) < 0x00FFFFFFu);
@@ -529,6 +577,13 @@ __global__ __launch_bounds__(256) void light_points_kernel(LightParams P, const 
             if (d2 <= r * r) atomicOr(&s_mask[l >> 5], 1u << (l & 31u));
         }
     __syncthreads();
+    float lod = 0.0f;
+    f4a G2{ 0, 0, 0, 0 };
+    if (MIPS) {                                              // every lane, converged: the quad neighbours' reflection vectors
+        f3 r{ 0.0f, 0.0f, 0.0f };
+        if (covered) { G2 = g2[idx]; r = reflection_dir(P, G0, G2); }
+        lod = quad_reflection_lod(P, covered, r, x, y);
+    }
     if (!inFrame) return;
 
     // 3. shade
@@ -545,9 +600,10 @@ __global__ __launch_bounds__(256) void light_points_kernel(LightParams P, const 
                 }
             }
         };
-        lit = light_pixel<ZERO_RADIUS, decltype(culled), true>(P, G0, g1[idx], g2[idx], ambient, cube, culled);
+        if (MIPS) lit = light_pixel<ZERO_RADIUS, decltype(culled), true, CubeChain>(P, G0, g1[idx], G2, ambient, cube, culled, CubeChain{ lod });
+        else lit = light_pixel<ZERO_RADIUS, decltype(culled), true>(P, G0, g1[idx], g2[idx], ambient, cube, culled);
     } else if (P.flags & CRYCHIC_LIGHT_SKY) {
-        lit = sky_pixel(P, cube, x, y);
+        lit = MIPS ? sky_pixel_chain(P, cube, x, y) : sky_pixel(P, cube, x, y);
     } else {
         lit = f4{ 0.690196097f, 0.768627524f, 0.870588303f, 1.0f };
     }
@@ -709,19 +765,23 @@ hipError_t launch_light(const LightParams& P, const float* g0, const float* g1, 
 {
     if (rows == 0) return hipSuccess;
     const dim3 grid = grid_for(P.W, rows);
+    const bool mips = P.cubeLevels > 1u;          // the chain: quads inside wavefronts (light_tile_pixel), so the rows must start a quad
+    if (mips && (row0 & 1u)) return hipErrorInvalidValue;
     if (P.numPointLights) {
-        if (P.pcfSearchRadius == 0.0f)
-            hipLaunchKernelGGL(light_points_kernel<true>, grid, dim3(256), 0, stream, P, (const f4a*)g0, (const f4a*)g1, (const f4a*)g2,
-                               depth, ambient, (const uint32_t*)cube, (uint32_t*)out, (f4a*)radiance, row0, row0 + rows);
-        else
-            hipLaunchKernelGGL(light_points_kernel<false>, grid, dim3(256), 0, stream, P, (const f4a*)g0, (const f4a*)g1, (const f4a*)g2,
-                               depth, ambient, (const uint32_t*)cube, (uint32_t*)out, (f4a*)radiance, row0, row0 + rows);
+#define CRY_LAUNCH_POINTS(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, P, (const f4a*)g0, (const f4a*)g1, (const f4a*)g2, depth, ambient, \
+                                                (const uint32_t*)cube, (uint32_t*)out, (f4a*)radiance, row0, row0 + rows)
+        if (P.pcfSearchRadius == 0.0f) { if (mips) CRY_LAUNCH_POINTS((light_points_kernel<true, true>)); else CRY_LAUNCH_POINTS((light_points_kernel<true, false>)); }
+        else { if (mips) CRY_LAUNCH_POINTS((light_points_kernel<false, true>)); else CRY_LAUNCH_POINTS((light_points_kernel<false, false>)); }
+#undef CRY_LAUNCH_POINTS
         return hipGetLastError();
     }
     const bool fix = (P.flags & (CRYCHIC_FIX_Q1 | CRYCHIC_FIX_Q3 | CRYCHIC_FIX_Q4)) != 0;
 #define CRY_LAUNCH_LIGHT(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, P, (const f4a*)g0, (const f4a*)g1, (const f4a*)g2, depth, ambient, \
                                                (const uint32_t*)cube, (uint32_t*)out, (f4a*)radiance, row0, row0 + rows)
-    if (P.pcfSearchRadius == 0.0f) { if (fix) CRY_LAUNCH_LIGHT((light_kernel<true, true>)); else CRY_LAUNCH_LIGHT((light_kernel<true, false>)); }
+    if (mips) {                                   // FIX compiled in: the chain is not the benchmark's instantiation
+        if (P.pcfSearchRadius == 0.0f) CRY_LAUNCH_LIGHT((light_kernel<true, true, true>)); else CRY_LAUNCH_LIGHT((light_kernel<false, true, true>));
+    }
+    else if (P.pcfSearchRadius == 0.0f) { if (fix) CRY_LAUNCH_LIGHT((light_kernel<true, true>)); else CRY_LAUNCH_LIGHT((light_kernel<true, false>)); }
     else { if (fix) CRY_LAUNCH_LIGHT((light_kernel<false, true>)); else CRY_LAUNCH_LIGHT((light_kernel<false, false>)); }
 #undef CRY_LAUNCH_LIGHT
     return hipGetLastError();

@@ -36,6 +36,7 @@ struct LightParams {
     float ShadowPairs[3][12][2];
     float ScreenPairs[4][2];
     float halfDims[2];         // (float)(W / 2), (float)(H / 2)
+    uint32_t cubeLevels;       // mip levels the cube map holds (CRYCHIC_LIGHT_CUBE_LEVELS; 0 / 1 = level 0 alone)
 };
 CRY_HD void light_params_derive(LightParams& P)
 {
@@ -424,6 +425,82 @@ CRY_HD f4 cube_resolve(const CubeFetch& f)
 }
 CRY_HD f4 cube_linear(const uint32_t* __restrict__ cube, uint32_t dim, f3 r) { return cube_resolve(cube_pick(cube_fetch(cube, dim, r), dim)); }
 
+// ---- TextureCube.Sample with the mip chain bound (MIN_MAG_MIP_LINEAR, CRYCHIC.cpp:2617-2622, :1148-1151) -------------------------
+// D3D leaves the level-of-detail arithmetic to the hardware; the definition used here is written out in DESIGN.md section 3 ("the cube
+// map's mip chain") and restated independently by the test suite's CPU checker: derivatives of the direction inside
+// the pixel's 2 x 2 quad, carried to the selected face by the chain rule, lod = min(0.5 log2(rho^2), levels - 1), two levels
+// filtered as level 0 is and mixed with one mad.  The chain: level after level, each six faces of max(dim >> level, 1)^2 texels.
+CRY_HD void cube_face_delta(f3 r, f3 d, float halfDim, float& du, float& dv)
+{
+    const float ax = __builtin_fabsf(r.x), ay = __builtin_fabsf(r.y), az = __builtin_fabsf(r.z);
+    const bool isx = (ax >= ay) & (ax >= az), isy = !isx & (ay >= az);
+    const bool px = r.x >= 0.0f, py = r.y >= 0.0f, pz = r.z >= 0.0f;
+    const float ma = isx ? ax : (isy ? ay : az);
+    const float sc = isx ? (px ? -r.z : r.z) : (isy ? r.x : (pz ? r.x : -r.x));
+    const float tc = isx ? -r.y : (isy ? (py ? r.z : -r.z) : -r.y);
+    const float dsc = isx ? (px ? -d.z : d.z) : (isy ? d.x : (pz ? d.x : -d.x));
+    const float dtc = isx ? -d.y : (isy ? (py ? d.z : -d.z) : -d.y);
+    const float dma = isx ? (px ? d.x : -d.x) : (isy ? (py ? d.y : -d.y) : (pz ? d.z : -d.z));
+    const float rma = rcp(ma);
+    du = fma(-(sc * rma), dma, dsc) * rma * halfDim;
+    dv = fma(-(tc * rma), dma, dtc) * rma * halfDim;
+}
+CRY_HD float cube_lod(uint32_t dim, uint32_t levels, f3 r, f3 ddx, f3 ddy)
+{
+    const float halfDim = 0.5f * (float)dim;
+    float ux, vx, uy, vy;
+    cube_face_delta(r, ddx, halfDim, ux, vx);
+    cube_face_delta(r, ddy, halfDim, uy, vy);
+    const float rx = fma(ux, ux, vx * vx), ry = fma(uy, uy, vy * vy);
+    const float rho2 = (ry > rx) ? ry : rx;
+    if (!(rho2 > 1.0f)) return 0.0f;
+    const float lod = 0.5f * det_log2_normal(rho2 < 3.0e38f ? rho2 : 3.0e38f);
+    const float top = (float)(levels - 1u);
+    return lod < top ? lod : top;
+}
+CRY_HD uint32_t cube_level_dim(uint32_t dim, uint32_t level) { const uint32_t d = dim >> level; return d ? d : 1u; }
+// One level of the chain (dim and level may differ from lane to lane).  A 1 x 1 level is its face's texel.
+template <bool WANT_ALPHA>
+CRY_HD f4 cube_level_linear(const uint32_t* __restrict__ chain, uint32_t dim, uint32_t levels, uint32_t level, f3 r)
+{
+    uint32_t off = 0;                                   // texels before `level`
+    for (uint32_t k = 0; k + 1u < levels; ++k) { const uint32_t d = cube_level_dim(dim, k); off += k < level ? 6u * d * d : 0u; }
+    const uint32_t d = cube_level_dim(dim, level);
+    if (d >= 2u) return cube_resolve<WANT_ALPHA>(cube_pick(cube_fetch(chain + off, d, r), d));
+    const float ax = __builtin_fabsf(r.x), ay = __builtin_fabsf(r.y), az = __builtin_fabsf(r.z);
+    const bool isx = (ax >= ay) & (ax >= az), isy = !isx & (ay >= az);
+    const uint32_t face = isx ? (r.x >= 0.0f ? 0u : 1u) : (isy ? (r.y >= 0.0f ? 2u : 3u) : (r.z >= 0.0f ? 4u : 5u));
+    const uint32_t t = chain[off + face];
+    const CubeFetch f{ TexelPair{ t, t }, TexelPair{ t, t }, 0.0f, 0.0f };
+    // bilinear_setup's weights on a 1 x 1 level are not 0, but all four texels are the one texel and lerp(t, t, w) == t for the
+    // unorm8 values a texel decodes to (t + w * (t - t)); a non-finite direction poisons the weights in the oracle alone -- and
+    // poisons the face selection the same way on both sides first (all comparisons false: face 5, -Z)
+    return cube_resolve<WANT_ALPHA>(f);
+}
+template <bool WANT_ALPHA>
+CRY_HD f4 cube_trilinear(const uint32_t* __restrict__ chain, uint32_t dim, uint32_t levels, f3 r, float lod)
+{
+    const uint32_t l0 = (uint32_t)lod;
+    const float frac = lod - (float)l0;
+    const uint32_t l1 = l0 + 1u < levels ? l0 + 1u : l0;
+    const f4 c0 = cube_level_linear<WANT_ALPHA>(chain, dim, levels, l0, r);
+    const f4 c1 = cube_level_linear<WANT_ALPHA>(chain, dim, levels, l1, r);       // l1 == l0 or frac == 0: the mad returns c0 (finite texels)
+    return f4{ fma(frac, c1.x - c0.x, c0.x), fma(frac, c1.y - c0.y, c0.y), fma(frac, c1.z - c0.z, c0.z), WANT_ALPHA ? fma(frac, c1.w - c0.w, c0.w) : 0.0f };
+}
+// How light_pixel looks the cube map up: level 0 alone (the fetch in flight with the pixel's other gathers) ...
+struct CubeLevel0 {
+    struct Fetch { CubeRows c; };
+    CRY_HD Fetch fetch(const LightParams& P, const uint32_t* __restrict__ cube, f3 r) const { return Fetch{ cube_fetch(cube, P.cubeDim, r) }; }
+    CRY_HD f4 resolve(const LightParams& P, const uint32_t* __restrict__, const Fetch& f) const { return cube_resolve<false>(cube_pick(f.c, P.cubeDim)); }
+};
+// ... or the chain at the level of detail the caller derived from the pixel's quad (light_kernel<.., MIPS>)
+struct CubeChain {
+    float lod;
+    struct Fetch { f3 r; };
+    CRY_HD Fetch fetch(const LightParams&, const uint32_t* __restrict__, f3 r) const { return Fetch{ r }; }
+    CRY_HD f4 resolve(const LightParams& P, const uint32_t* __restrict__ cube, const Fetch& f) const { return cube_trilinear<false>(cube, P.cubeDim, P.cubeLevels, f.r, lod); }
+};
+
 // gsamLinearClamp on the half-res R16_UNORM ambient map  (CRYCHIC.cpp:2624-2629)
 struct AmbientFetch { uint16_t t00, t10, t01, t11; float fx, fy; };
 CRY_HD AmbientFetch ambient_fetch(const uint16_t* __restrict__ a, uint32_t w2, uint32_t h2, float u, float v)
@@ -753,9 +830,19 @@ CRY_HD float cascade_uniform_resolve(const LightParams& P, const CascadeTexels& 
 // issued before the first is waited for (one memory round trip instead of one per lookup).
 // FIX: a compile-time promise that P.flags may carry CRYCHIC_FIX_* bits; false = the reference as written, with no trace of
 // the switches in the instantiation the benchmark runs.
-template <bool ZERO_RADIUS, class PointLights = NoPointLights, bool FIX = false>
+// DeferredShading.hlsl:32,94 + GBuffer.hlsl:41: the direction light_pixel looks the cube map up with (the same operations in the same
+// order; a kernel that needs it before the call -- the quad derivatives of the chain lookup -- gets the identical value).
+CRY_HD f3 reflection_dir(const LightParams& P, f4a G0, f4a G2)
+{
+    const f3 normalW = normalize3(f3{ G2.x, G2.y, G2.z });
+    const f3 toEye{ P.EyePosW[0] - G0.x, P.EyePosW[1] - G0.y, P.EyePosW[2] - G0.z };
+    const f3 view = normalize3(toEye);
+    return reflect3(f3{ -view.x, -view.y, -view.z }, normalW);
+}
+
+template <bool ZERO_RADIUS, class PointLights = NoPointLights, bool FIX = false, class Cube = CubeLevel0>
 CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16_t* __restrict__ ambient,
-                      const uint32_t* __restrict__ cube, PointLights pointLights = PointLights())
+                      const uint32_t* __restrict__ cube, PointLights pointLights = PointLights(), Cube cubeLookup = Cube())
 {
     const bool fixQ1 = FIX && (P.flags & CRYCHIC_FIX_Q1), fixQ3 = FIX && (P.flags & CRYCHIC_FIX_Q3), fixQ4 = FIX && (P.flags & CRYCHIC_FIX_Q4);
     const f3 posW{ G0.x, G0.y, G0.z };                         // GBuffer.hlsl:37-41
@@ -781,7 +868,7 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
     const bool hasAO = ambient != nullptr;
     const AmbientPairs af = ambient_fetch_projected(P, ambient, hasAO, (const uint16_t*)cube, posW);
     const f3 r = reflect3(f3{ -view.x, -view.y, -view.z }, normalW);  // :94
-    const CubeRows cf = cube_fetch(cube, P.cubeDim, r);         // :95
+    const typename Cube::Fetch cf = cubeLookup.fetch(P, cube, r);   // :95
 
     CascadeTexels ct;
     if (packedCascades) {
@@ -792,7 +879,7 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
     const float ambientAccess = hasAO ? ambient_resolve(P, ambient, af) : 1.0f;
     // the reflection lookup is filtered here as well -- every gather of the pixel has arrived with the cascades' texels -- so that
     // what stays live across the lights is three colours and one Fresnel factor, not two texel pairs, weights and the vector
-    const f4 refl = cube_resolve<false>(cube_pick(cf, P.cubeDim));
+    const f4 refl = cubeLookup.resolve(P, cube, cf);
     const float f0 = 1.0f - saturate(dot3(normalW, r));         // LightingUtil.hlsl:54-57
     const float f5 = f0 * f0 * f0 * f0 * f0;
     const f3 amb{ ambientAccess * P.AmbientLight[0] * albedo.x, ambientAccess * P.AmbientLight[1] * albedo.y,
@@ -836,7 +923,7 @@ CRY_HD f4 light_pixel(const LightParams& P, f4a G0, f4a G1, f4a G2, const uint16
 }
 
 // sky.hlsl:21-47 for an uncovered pixel: cubemap lookup along the pixel's view ray.
-CRY_HD f4 sky_pixel(const LightParams& P, const uint32_t* __restrict__ cube, uint32_t x, uint32_t y)
+CRY_HD f3 sky_direction(const LightParams& P, uint32_t x, uint32_t y)
 {
     const float u = ((float)x + 0.5f) * P.rcpW, v = ((float)y + 0.5f) * P.rcpH;         // (x + 0.5) / W as a * rcp(b)
     const float hx = fma(2.0f, u, -1.0f), hy = fma(-2.0f, v, 1.0f);
@@ -846,9 +933,21 @@ CRY_HD f4 sky_pixel(const LightParams& P, const uint32_t* __restrict__ cube, uin
     const float phw = mulcol(hx, hy, 0.0f, 1.0f, P.InvProj + 12);
     const float rphw = rcp(phw);
     const float vx = phx * rphw, vy = phy * rphw, vz = phz * rphw;
-    const f3 d{ mulcol(vx, vy, vz, 0.0f, P.InvView + 0), mulcol(vx, vy, vz, 0.0f, P.InvView + 4),
-                mulcol(vx, vy, vz, 0.0f, P.InvView + 8) };
-    return cube_linear(cube, P.cubeDim, d);
+    return f3{ mulcol(vx, vy, vz, 0.0f, P.InvView + 0), mulcol(vx, vy, vz, 0.0f, P.InvView + 4),
+               mulcol(vx, vy, vz, 0.0f, P.InvView + 8) };
+}
+CRY_HD f4 sky_pixel(const LightParams& P, const uint32_t* __restrict__ cube, uint32_t x, uint32_t y)
+{
+    return cube_linear(cube, P.cubeDim, sky_direction(P, x, y));
+}
+// The same with the chain: the quad neighbours' directions are those of their own pixels (outside the frame: zero derivative).
+CRY_HD f4 sky_pixel_chain(const LightParams& P, const uint32_t* __restrict__ cube, uint32_t x, uint32_t y)
+{
+    const f3 d = sky_direction(P, x, y);
+    f3 ddx{ 0.0f, 0.0f, 0.0f }, ddy{ 0.0f, 0.0f, 0.0f };
+    if ((x ^ 1u) < P.W) { const f3 n = sky_direction(P, x ^ 1u, y); ddx = (x & 1u) ? f3{ d.x - n.x, d.y - n.y, d.z - n.z } : f3{ n.x - d.x, n.y - d.y, n.z - d.z }; }
+    if ((y ^ 1u) < P.H) { const f3 n = sky_direction(P, x, y ^ 1u); ddy = (y & 1u) ? f3{ d.x - n.x, d.y - n.y, d.z - n.z } : f3{ n.x - d.x, n.y - d.y, n.z - d.z }; }
+    return cube_trilinear<true>(cube, P.cubeDim, P.cubeLevels, d, cube_lod(P.cubeDim, P.cubeLevels, d, ddx, ddy));
 }
 
 CRY_HD uint32_t pack_rgba8(f4 c)

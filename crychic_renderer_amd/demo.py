@@ -26,8 +26,11 @@ def main():
     tex = g.reference_textures(a.textures) if a.textures else g.procedural_textures(64)
     geo = SceneGeometry(ctx, g.cascade_scene_items(), g.reference_materials(), tex)
     sgeo = SceneGeometry(ctx, g.cascade_scene_items(shadow_layer=True))
-    cube = torch.from_numpy(g.load_dds_cube(a.cube)).to(ctx.device) if a.cube else scene.make_cubemap(256, ctx.device)
+    cube = scene.make_cubemap(256, ctx.device)
     app = Crychic(ctx, W, H, torch.from_numpy(consts.randvec.copy()).to(ctx.device), cube, shadow_dim=a.shadow_dim)
+    if a.cube:            # with the mip chain the file stores, as the reference binds it (CRYCHIC.cpp:1148-1151)
+        chain, dim, levels = g.load_dds_cube_mips(a.cube)
+        app.set_cube_map(torch.from_numpy(chain).to(ctx.device), dim=dim, levels=levels)
     app.mMainPassCB, app.mSsaoCB = consts.pass_cb, consts.ssao_cb
     for k in range(4):
         cb = PassConstants()

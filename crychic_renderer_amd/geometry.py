@@ -161,6 +161,15 @@ def box_mips(level0):
     return levels
 
 
+def cube_mip_chain(cube, levels=None):
+    """The mip chain of a 6 x dim x dim x 4 uint8 cube map by 2 x 2 box filtering of each face (box_mips), flattened into the layout
+    CRYCHIC_LIGHT_CUBE_LEVELS announces: level after level, each level the six faces of max(dim >> level, 1)^2 texels.  Returns (flat
+    uint8 array, number of levels); `levels` caps the chain (default: down to 1 x 1)."""
+    faces = [box_mips(cube[f]) for f in range(6)]
+    n = len(faces[0]) if levels is None else min(int(levels), len(faces[0]))
+    return np.concatenate([faces[f][k].reshape(-1) for k in range(n) for f in range(6)]), n
+
+
 def texture_levels(t):
     """(flat uint8 array of all levels back to back, width, height, mipLevels) for a texture given as one H x W x 4 array or as a
     list of level arrays (level k = max(1, W >> k) x max(1, H >> k))."""
@@ -203,6 +212,16 @@ def load_dds_cube(path):
     out = np.zeros((6, d.value, d.value, 4), np.uint8)
     check(lib.crychic_load_dds_cube_rgba8(path.encode(), out.ctypes.data, out.nbytes, C.byref(d)))
     return out
+
+
+def load_dds_cube_mips(path):
+    """A DDS cube map with the mip chain the file stores (crychic_load_dds_cube_rgba8_mips): (flat uint8 array in the level-after-level
+    layout of CRYCHIC_LIGHT_CUBE_LEVELS, dim, mipLevels)."""
+    d, m = C.c_uint32(), C.c_uint32()
+    check(lib.crychic_load_dds_cube_rgba8_mips(path.encode(), None, 0, C.byref(d), C.byref(m)))
+    out = np.zeros(sum(6 * max(d.value >> k, 1) ** 2 * 4 for k in range(m.value)), np.uint8)
+    check(lib.crychic_load_dds_cube_rgba8_mips(path.encode(), out.ctypes.data, out.nbytes, C.byref(d), C.byref(m)))
+    return out, d.value, m.value
 
 
 def reference_textures(texture_dir):

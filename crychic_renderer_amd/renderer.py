@@ -156,6 +156,8 @@ class Crychic:
         self.mSsao = Ssao(ctx, width, height, randvec)
         self.mDeferred = DeferredShading(ctx, width, height)
         self.mCubeMap = cube
+        self.mCubeMapLevels = 1      # set_cube_map: > 1 = mCubeMap is a flat mip chain (CRYCHIC_LIGHT_CUBE_LEVELS), mCubeMapSize its level-0 face size
+        self.mCubeMapSize = None
         self.mDepthStencilBuffer = torch.full((height, width), 0xFFFFFF, device=ctx.device, dtype=torch.int32)
         self.mBackBuffer = torch.zeros((height, width, 4), device=ctx.device, dtype=torch.uint8)
         self.mMainPassCB = PassConstants()
@@ -174,6 +176,7 @@ class Crychic:
         self.mDeferred.mGBuffer = [planes["g0"], planes["g1"], planes["g2"]]
         self.mShadowMap.mShadowMap = planes["shadow"]
         self.mCubeMap = planes["cube"]
+        self.mCubeMapLevels, self.mCubeMapSize = 1, None
         self.mSsao.mRandomVectorMap = planes["randvec"]
         self.mMainPassCB = planes["consts"].pass_cb
         self.mSsaoCB = planes["consts"].ssao_cb
@@ -184,7 +187,7 @@ class Crychic:
         f = FrameDesc()
         f.W, f.H = W, H
         f.blurCount, f.numDirLights = int(self.blurCount), int(self.numDirLights)
-        f.pcfSearchRadius, f.flags = float(self.pcfSearchRadius), int(self.flags)
+        f.pcfSearchRadius, f.flags = float(self.pcfSearchRadius), int(self.flags) | ((int(self.mCubeMapLevels) & 15) << 16 if self.mCubeMapLevels > 1 else 0)
         f.row0, f.rows = int(row0), int(H - row0 if rows is None else rows)
         f.normal_dev = self.mSsao.mNormalMap.data_ptr()
         f.depth_dev = self.mDepthStencilBuffer.data_ptr()
@@ -193,7 +196,7 @@ class Crychic:
         for i in range(4):
             f.shadow_dev[i] = self.mShadowMap.mShadowMap[i].data_ptr()
         f.shadowDim = self.mShadowMap.Width()
-        f.cube_dev, f.cubeDim = self.mCubeMap.data_ptr(), int(self.mCubeMap.shape[1])
+        f.cube_dev, f.cubeDim = self.mCubeMap.data_ptr(), int(self.mCubeMapSize or self.mCubeMap.shape[1])
         f.ambient0_dev = self.mSsao.mAmbientMap0.data_ptr()
         f.ambient1_dev = self.mSsao.mAmbientMap1.data_ptr()
         f.edge_dev = self.mSsao.mEdge.data_ptr()
@@ -213,7 +216,7 @@ class Crychic:
         key = (row0, rows, self.mBackBuffer.data_ptr(), ssao.mAmbientMap0.data_ptr(), ssao.mAmbientMap1.data_ptr(), ssao.mEdge.data_ptr(),
                ssao.mNormalMap.data_ptr(), ssao.mRandomVectorMap.data_ptr(), self.mDepthStencilBuffer.data_ptr(),
                self.mDeferred.mGBuffer[0].data_ptr(), self.mDeferred.mGBuffer[1].data_ptr(), self.mDeferred.mGBuffer[2].data_ptr(),
-               sm.data_ptr(), int(sm.shape[-1]), self.mCubeMap.data_ptr(), int(self.mCubeMap.shape[1]),
+               sm.data_ptr(), int(sm.shape[-1]), self.mCubeMap.data_ptr(), int(self.mCubeMapSize or self.mCubeMap.shape[1]), int(self.mCubeMapLevels),
                self.blurCount, self.numDirLights, self.pcfSearchRadius, self.flags,
                0 if self.mPointLights is None else self.mPointLights.data_ptr())
         if self._desc is None:
@@ -229,6 +232,15 @@ class Crychic:
             return
         check(lib.crychic_draw_hot_path(self.ctx.handle, C.byref(self.mSsaoCB), C.byref(self.mMainPassCB), C.byref(f),
                                         _stream(self.ctx.device)))
+
+    def set_cube_map(self, cube, dim=None, levels=1):
+        """The sky cube map: a 6 x dim x dim x 4 uint8 tensor (level 0 alone), or -- with `levels` > 1 -- the flat mip chain
+        geometry.cube_mip_chain / load_dds_cube_mips produce (the reference binds the whole chain, CRYCHIC.cpp:1148-1151): the
+        reflection and sky lookups are then trilinear (CRYCHIC_LIGHT_CUBE_LEVELS)."""
+        self.mCubeMap = cube
+        self.mCubeMapLevels = int(levels)
+        self.mCubeMapSize = int(dim) if dim is not None else None
+        self._desc = None
 
     def set_point_lights(self, lights):
         """Extension: `lights` is a ctypes array of Light (or None); copied to the device."""

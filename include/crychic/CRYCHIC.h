@@ -201,7 +201,7 @@ public:
         f.blurCount = mBlurCount;                                                                   // :221
         f.numDirLights = mNumDirLights;
         f.pcfSearchRadius = crychic_pcf_search_radius(mShadowMap->Width(), mPcfLiteral ? 1 : 0);
-        f.flags = mSkyEnabled ? CRYCHIC_LIGHT_SKY : 0u;                                             // :278-279
+        f.flags = (mSkyEnabled ? CRYCHIC_LIGHT_SKY : 0u) | (mCubeMapLevels > 1 ? CRYCHIC_LIGHT_CUBE_LEVELS(mCubeMapLevels) : 0u);   // :278-279, :1148-1151
         f.row0 = mStripRow0; f.rows = mWholeFrame ? mClientHeight : mStripRows;                      // whole frame unless SetStrip / JoinNode
         f.normal_dev = mSsao->NormalMap()->Data();
         f.depth_dev = static_cast<const uint32_t*>(mDepthStencilBuffer->Data());
@@ -283,7 +283,9 @@ public:
     // ---- planes the producer passes would fill (row f1) + the result ----
     ID3D12Resource* DepthStencilBuffer() { return mDepthStencilBuffer.get(); }
     ID3D12Resource* CurrentBackBuffer() { return mBackBuffer.get(); }
-    void SetCubeMap(std::unique_ptr<ID3D12Resource> cube, UINT dim) { mCubeMap = std::move(cube); mCubeMapSize = dim; }
+    // `levels` > 1: the resource holds the mip chain in crychic_load_dds_cube_rgba8_mips' layout (the reference binds every level,
+    // CRYCHIC.cpp:1148-1151) and Draw announces it with CRYCHIC_LIGHT_CUBE_LEVELS
+    void SetCubeMap(std::unique_ptr<ID3D12Resource> cube, UINT dim, UINT levels = 1) { mCubeMap = std::move(cube); mCubeMapSize = dim; mCubeMapLevels = levels ? levels : 1; }
 
     // CRYCHIC::LoadTextures (CRYCHIC.cpp:939-973): the six material textures in heap order (= gTextureMaps indices, :954-959) with the
     // mip chains their files store, and the sky cube map, from `dir` (the reference opens "Textures/...").  The DDS decoding that
@@ -310,15 +312,17 @@ public:
             tex.push_back(crychic_texture{ static_cast<const uint8_t*>(planes.back()->Data()), w, h, levels });
         }
         const std::string cubePath = dir + "/snowcube1024.dds";
-        uint32_t dim = 0;
-        const int rc = crychic_load_dds_cube_rgba8(cubePath.c_str(), nullptr, 0, &dim);
+        uint32_t dim = 0, cubeLevels = 0;
+        const int rc = crychic_load_dds_cube_rgba8_mips(cubePath.c_str(), nullptr, 0, &dim, &cubeLevels);      // :1148-1151: the whole chain
         if (rc == 0) {
-            host.resize((size_t)6 * dim * dim * 4);
-            CrychicThrowIfFailed(crychic_load_dds_cube_rgba8(cubePath.c_str(), host.data(), host.size(), &dim));
+            size_t bytes = 0;
+            for (uint32_t k = 0; k < cubeLevels; ++k) { const size_t d = (dim >> k) ? (dim >> k) : 1; bytes += 6 * d * d * 4; }
+            host.resize(bytes);
+            CrychicThrowIfFailed(crychic_load_dds_cube_rgba8_mips(cubePath.c_str(), host.data(), host.size(), &dim, &cubeLevels));
             auto cube = std::make_unique<ID3D12Resource>(host.size(), ID3D12Resource::DEFAULT_HEAP);
             cube->Upload(host.data(), host.size(), s);
             mCommandList->Flush();
-            SetCubeMap(std::move(cube), dim);
+            SetCubeMap(std::move(cube), dim, cubeLevels);
         } else if (requireCubeMap) {
             CrychicThrowIfFailed(rc);
         }
@@ -636,7 +640,7 @@ private:
     UINT mExchangeParts = 1;                  // SetExchangeParts
     bool mWholeFrame = true;
     std::unique_ptr<ID3D12Resource> mDepthStencilBuffer, mBackBuffer, mCubeMap;
-    UINT mCubeMapSize = 0;
+    UINT mCubeMapSize = 0, mCubeMapLevels = 1;
     UINT mClientWidth, mClientHeight;
     float mLightRotationAngle = 0.0f;
     DirectX::XMFLOAT3 mBaseLightDirections[3] = { { 0.57735f, -0.57735f, 0.57735f }, { -0.57735f, -0.57735f, 0.57735f }, { 0.0f, -0.707f, -0.707f } };  // CRYCHIC.h:173-177

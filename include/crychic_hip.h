@@ -190,6 +190,14 @@ int crychic_ssao_compute(crychic_ctx* ctx, const crychic_ssao_constants* cb, con
  *       -> `abs(distance - radius[j]) < 5.0f`, the form of the forward shader (Default.hlsl:131)
  *   Q3  PBR.hlsl:58,66 the specular denominator uses hDotv where nDotv is meant -> nDotl * nDotv
  *   Q4  PBR.hlsl:61-68 `ks * fs` with fs already holding F (Fresnel applied twice) -> kd * fd + fs */
+/* The cube map's mip chain (the reference binds the whole chain, CRYCHIC.cpp:1148-1151, and samples it MIN_MAG_MIP_LINEAR,
+ * :2617-2622): CRYCHIC_LIGHT_CUBE_LEVELS(n) in `flags` says that cube_dev holds n levels (crychic_load_dds_cube_rgba8_mips' layout:
+ * level after level, each six faces of max(cubeDim >> level, 1)^2 RGBA8 texels); the reflection lookup (DeferredShading.hlsl:95)
+ * and the sky (sky.hlsl:46) are then trilinear, the level of detail taken from the direction's differences inside the pixel's
+ * 2 x 2 quad -- a BUILD DEFINITION (D3D leaves the arithmetic to the hardware; DESIGN.md section 3 states it), parity against
+ * this repo's CPU checker.  n = 0 or 1: level 0 alone, the lookup of every earlier release.  With n > 1 a call's rows must be whole
+ * quad rows (even row0; even rows unless they end the frame). */
+#define CRYCHIC_LIGHT_CUBE_LEVELS(n) (((uint32_t)(n) & 15u) << 16)
 #define CRYCHIC_FIX_Q1 0x100u
 #define CRYCHIC_FIX_Q3 0x200u
 #define CRYCHIC_FIX_Q4 0x400u
@@ -320,6 +328,10 @@ int crychic_load_dds_rgba8_mips(const char* path, uint8_t* rgba8, size_t capacit
  * lighting and sky passes filter level 0.  NULL buffer: only *dim is written.  The 2-D loaders above refuse
  * a cube file and this one refuses a 2-D file (CRYCHIC_E_UNSUPPORTED). */
 int crychic_load_dds_cube_rgba8(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32_t* dim);
+/* The same with the mip chain the file stores (CRYCHIC.cpp:1148-1151 binds every level): level after level, each level the six
+ * faces of max(dim >> level, 1)^2 texels -- what CRYCHIC_LIGHT_CUBE_LEVELS(*mipLevels) announces to the lighting pass.  rgba8 = NULL
+ * queries *dim and *mipLevels (capacity: sum over the levels of 6 * d * d * 4 bytes). */
+int crychic_load_dds_cube_rgba8_mips(const char* path, uint8_t* rgba8, size_t capacityBytes, uint32_t* dim, uint32_t* mipLevels);
 
 /* Present stand-in (row f3; the reference calls IDXGISwapChain::Present, CRYCHIC.cpp:294-297): writes a HOST R8G8B8A8
  * image as binary PPM (alpha dropped). */

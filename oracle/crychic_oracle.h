@@ -165,7 +165,9 @@ float or_pcf_search_radius(uint32_t shadowWidth, int literal);
  * ambient may be NULL (SSAO off: ambientAccess = 1).  radiance_out (optional) receives litColor before
  * UNORM8 quantisation as 4 floats per pixel.  `sky` is a flag word: bit 0 = uncovered pixels get the sky cubemap along
  * the view ray (Shaders/sky.hlsl:21-47) instead of the clear colour (CRYCHIC.cpp:247); 0x100 / 0x200 / 0x400 select the
- * evidently intended forms of quirks Q1 / Q3 / Q4 (same bits as CRYCHIC_FIX_* of the product's ABI); 0 = as written. */
+ * evidently intended forms of quirks Q1 / Q3 / Q4 (same bits as CRYCHIC_FIX_* of the product's ABI); 0 = as written;
+ * bits 16..19 = the number of mip levels `cube` holds (CRYCHIC_LIGHT_CUBE_LEVELS; 0 / 1 = level 0 alone): with more than one the
+ * reflection and sky lookups are trilinear with quad derivatives (or_samplers.h "TextureCube.Sample with a mip chain"). */
 void or_deferred_light(const or_pass_constants* cb, const float* g0, const float* g1, const float* g2,
                        const uint32_t* depth, const uint16_t* ambient, const uint32_t* const shadow[4],
                        uint32_t shadowDim, const uint8_t* cube, uint32_t cubeDim, uint8_t* out_rgba8,
@@ -222,6 +224,8 @@ int or_load_dds_rgba8(const char* path, uint8_t* rgba8, size_t capacity, uint32_
 int or_load_dds_rgba8_mips(const char* path, uint8_t* rgba8, size_t capacity, uint32_t* width, uint32_t* height, uint32_t* mips);
 /* A DDS cube map (legacy caps2 or DX10 header): level 0 of the faces +X, -X, +Y, -Y, +Z, -Z as one 6 x dim x dim R8G8B8A8 plane. */
 int or_load_dds_cube_rgba8(const char* path, uint8_t* rgba8, size_t capacity, uint32_t* dim);
+/* The same with the chain the file stores, level after level (each six faces of max(dim >> level, 1)^2 texels). */
+int or_load_dds_cube_rgba8_mips(const char* path, uint8_t* rgba8, size_t capacity, uint32_t* dim, uint32_t* mips);
 
 /* or_deferred_light plus NUM_POINT_LIGHTS point lights from a separate buffer: BUILD-DEFINED EXTENSION for BASELINE
  * configs[4] (the reference's point-light branch, PBR.hlsl:109-124, is dead code); see or_light.c. */
@@ -246,6 +250,8 @@ float or_sample_depth_linear_border(const uint32_t* depth, uint32_t W, uint32_t 
 float or_sample_shadow_cmp(const uint32_t* shadow, uint32_t dim, float u, float v, float ref);
 float or_pcf_poisson(const uint32_t* shadow, uint32_t dim, const float shadowPosH[4], float searchRadius);
 void  or_sample_cube(const uint8_t* cube, uint32_t dim, const float dir[3], float rgb[3]);
+float or_sample_cube_lod(uint32_t dim, uint32_t levels, const float dir[3], const float ddx[3], const float ddy[3]);
+void  or_sample_cube_level(const uint8_t* chain, uint32_t dim, uint32_t levels, const float dir[3], float lod, float rgb[3]);
 void  or_sample_randvec(const uint8_t* randvec, float u, float v, float rgb[3]);
 float or_sample_ambient_linear_clamp(const uint16_t* ambient, uint32_t w2, uint32_t h2, float u, float v);
 

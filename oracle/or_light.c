@@ -162,15 +162,52 @@ static void pbr_point_light(const or_light* L, const float pos[3], const float a
     }
 }
 
+#define OR_CUBE_LEVELS(flags) (((uint32_t)(flags) >> 16) & 15u)   /* the cube map's mip levels (0 and 1: level 0 alone): CRYCHIC_LIGHT_CUBE_LEVELS */
+
 static void cube4(const uint8_t* cube, uint32_t dim, const float dir[3], float rgba[4])
 {
     or_cube_linear(cube, dim, dir, rgba, 4);
 }
 
+/* DeferredShading.hlsl:32,94 and GBuffer.hlsl:41 for the pixel at idx: r = reflect(-view, normalW) -- what light_pixel looks the
+ * cube map up with, recomputed for the pixel's quad neighbours when the cube map has a mip chain. */
+static void pixel_reflection(const or_pass_constants* cb, const float* g0, const float* g2, size_t idx, float r[3])
+{
+    const float* G0 = g0 + idx * 4; const float* G2 = g2 + idx * 4;
+    float nraw[3] = { G2[0], G2[1], G2[2] }, normalW[3], view[3];
+    or_normalize3(nraw, normalW);
+    float toEye[3] = { cb->EyePosW[0] - G0[0], cb->EyePosW[1] - G0[1], cb->EyePosW[2] - G0[2] };
+    or_normalize3(toEye, view);
+    float negv[3] = { -view[0], -view[1], -view[2] };
+    or_reflect3(negv, normalW, r);
+}
+static int covered_at(const uint32_t* depth, uint32_t W, uint32_t H, uint32_t x, uint32_t y)
+{
+    return x < W && y < H && (depth[(size_t)y * W + x] & 0x00FFFFFFu) < 0x00FFFFFFu;
+}
+/* The implicit derivatives of gCubeMap.Sample in the lighting pass (oracle definition, or_samplers.h): differences inside the
+ * pixel's 2 x 2 quad (quads start on even pixel coordinates), right - left in the pixel's row and lower - upper in its column; a
+ * neighbour that the pass does not shade (no geometry there, or outside the frame) contributes a zero derivative. */
+static float reflection_lod(const or_pass_constants* cb, const float* g0, const float* g2, const uint32_t* depth, uint32_t cubeDim,
+                            uint32_t levels, uint32_t W, uint32_t H, uint32_t x, uint32_t y, const float r[3])
+{
+    float ddx[3] = { 0.0f, 0.0f, 0.0f }, ddy[3] = { 0.0f, 0.0f, 0.0f }, n[3];
+    if (covered_at(depth, W, H, x ^ 1u, y)) {
+        pixel_reflection(cb, g0, g2, (size_t)y * W + (x ^ 1u), n);
+        for (int c = 0; c < 3; ++c) ddx[c] = (x & 1u) ? r[c] - n[c] : n[c] - r[c];
+    }
+    if (covered_at(depth, W, H, x, y ^ 1u)) {
+        pixel_reflection(cb, g0, g2, (size_t)(y ^ 1u) * W + x, n);
+        for (int c = 0; c < 3; ++c) ddy[c] = (y & 1u) ? r[c] - n[c] : n[c] - r[c];
+    }
+    return or_cube_lod(cubeDim, levels, r, ddx, ddy);
+}
+
 static void light_pixel(const or_pass_constants* cb, const float* g0, const float* g1, const float* g2,
                         const uint16_t* ambient, const uint32_t* const shadow[4], uint32_t shadowDim,
                         const uint8_t* cube, uint32_t cubeDim, uint32_t W, uint32_t H, size_t idx,
-                        int numDirLights, float pcfRadius, const or_light* pointLights, uint32_t numPointLights, int flags, float lit[4])
+                        int numDirLights, float pcfRadius, const or_light* pointLights, uint32_t numPointLights, int flags,
+                        const uint32_t* depth, float lit[4])
 {
     /* DeferredShading.hlsl:25-30: the anisotropic-wrap fetch at exact texel centres is the texel itself. */
     const float* G0 = g0 + idx * 4; const float* G1 = g1 + idx * 4; const float* G2 = g2 + idx * 4;
@@ -242,7 +279,12 @@ static void light_pixel(const or_pass_constants* cb, const float* g0, const floa
     float negv[3] = { -view[0], -view[1], -view[2] }, r[3];
     or_reflect3(negv, normalW, r);                                    /* :94 */
     float refl[4];
-    cube4(cube, cubeDim, r, refl);                                    /* :95 */
+    if (OR_CUBE_LEVELS(flags) > 1u) {                                 /* :95 with the chain bound (CRYCHIC.cpp:1148-1151) */
+        uint32_t x = (uint32_t)(idx % W), y = (uint32_t)(idx / W);
+        float lod = reflection_lod(cb, g0, g2, depth, cubeDim, OR_CUBE_LEVELS(flags), W, H, x, y, r);
+        or_cube_trilinear(cube, cubeDim, OR_CUBE_LEVELS(flags), r, lod, refl, 4);
+    } else
+        cube4(cube, cubeDim, r, refl);                                /* :95 */
     float cosI = or_saturate(or_dot3(normalW, r));                    /* LightingUtil.hlsl:54 */
     float f0 = 1.0f - cosI;
     float f5 = f0 * f0 * f0 * f0 * f0;                                /* :57 */
@@ -256,15 +298,29 @@ static void light_pixel(const or_pass_constants* cb, const float* g0, const floa
 /* Shaders/sky.hlsl:21-47: cubemap lookup along the view ray of the pixel (the sky sphere is centred on
  * the eye, so the interpolated PosL is parallel to the ray).  Ray = near-plane point of the pixel in view
  * space rotated by InvView. */
-static void sky_pixel(const or_pass_constants* cb, const uint8_t* cube, uint32_t cubeDim, uint32_t W, uint32_t H,
-                      uint32_t x, uint32_t y, float out[4])
+static void sky_direction(const or_pass_constants* cb, uint32_t W, uint32_t H, uint32_t x, uint32_t y, float dw[4])
 {
     float u = or_div((float)x + 0.5f, (float)W), v = or_div((float)y + 0.5f, (float)H);
     float posh[4] = { fmaf(2.0f, u, -1.0f), fmaf(-2.0f, v, 1.0f), 0.0f, 1.0f }, ph[4];
     or_mul_v4_m(posh, cb->InvProj, ph);
     float rw = or_rcp(ph[3]);
-    float pv[4] = { ph[0] * rw, ph[1] * rw, ph[2] * rw, 0.0f }, dw[4];
+    float pv[4] = { ph[0] * rw, ph[1] * rw, ph[2] * rw, 0.0f };
     or_mul_v4_m(pv, cb->InvView, dw);
+}
+static void sky_pixel(const or_pass_constants* cb, const uint8_t* cube, uint32_t cubeDim, uint32_t levels, uint32_t W, uint32_t H,
+                      uint32_t x, uint32_t y, float out[4])
+{
+    float dw[4];
+    sky_direction(cb, W, H, x, y, dw);
+    if (levels > 1u) {
+        /* sky.hlsl:46 with the chain: the quad neighbours' directions are those of their own pixels (the sky sphere covers the
+         * whole quad, its far pixels running as helpers); outside the frame: zero derivative */
+        float ddx[3] = { 0.0f, 0.0f, 0.0f }, ddy[3] = { 0.0f, 0.0f, 0.0f }, n[4];
+        if ((x ^ 1u) < W) { sky_direction(cb, W, H, x ^ 1u, y, n); for (int c = 0; c < 3; ++c) ddx[c] = (x & 1u) ? dw[c] - n[c] : n[c] - dw[c]; }
+        if ((y ^ 1u) < H) { sky_direction(cb, W, H, x, y ^ 1u, n); for (int c = 0; c < 3; ++c) ddy[c] = (y & 1u) ? dw[c] - n[c] : n[c] - dw[c]; }
+        or_cube_trilinear(cube, cubeDim, levels, dw, or_cube_lod(cubeDim, levels, dw, ddx, ddy), out, 4);
+        return;
+    }
     cube4(cube, cubeDim, dw, out);
 }
 
@@ -297,9 +353,9 @@ void or_deferred_light_points(const or_pass_constants* cb, const float* g0, cons
              * is below the clear value. */
             if ((depth[idx] & 0x00FFFFFFu) < 0x00FFFFFFu)
                 light_pixel(cb, g0, g1, g2, ambient, shadow, shadowDim, cube, cubeDim, W, H, idx, numDirLights,
-                            pcfSearchRadius, pointLights, numPointLights, sky, lit);
+                            pcfSearchRadius, pointLights, numPointLights, sky, depth, lit);
             else if (sky & 1)
-                sky_pixel(cb, cube, cubeDim, W, H, x, (uint32_t)y, lit);
+                sky_pixel(cb, cube, cubeDim, OR_CUBE_LEVELS(sky), W, H, x, (uint32_t)y, lit);
             else
                 for (int c = 0; c < 4; ++c) lit[c] = clearColor[c];
             if (radiance_out) for (int c = 0; c < 4; ++c) radiance_out[idx * 4 + c] = lit[c];
@@ -309,6 +365,11 @@ void or_deferred_light_points(const or_pass_constants* cb, const float* g0, cons
 }
 
 void or_sample_cube(const uint8_t* cube, uint32_t dim, const float dir[3], float rgb[3]) { or_cube_linear(cube, dim, dir, rgb, 3); }
+float or_sample_cube_lod(uint32_t dim, uint32_t levels, const float dir[3], const float ddx[3], const float ddy[3]) { return or_cube_lod(dim, levels, dir, ddx, ddy); }
+void or_sample_cube_level(const uint8_t* chain, uint32_t dim, uint32_t levels, const float dir[3], float lod, float rgb[3])
+{
+    or_cube_trilinear(chain, dim, levels, dir, lod, rgb, 3);
+}
 float or_sample_ambient_linear_clamp(const uint16_t* ambient, uint32_t w2, uint32_t h2, float u, float v)
 {
     return or_ambient_linear_clamp(ambient, w2, h2, u, v);

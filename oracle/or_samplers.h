@@ -147,4 +147,55 @@ static inline void or_cube_linear(const uint8_t* cube, uint32_t dim, const float
     }
 }
 
+/* ---- TextureCube.Sample with a mip chain (MIN_MAG_MIP_LINEAR: CRYCHIC.cpp:2617-2622; the whole chain is bound, :1148-1151) ----
+ * D3D specifies what goes into the level-of-detail of a cube lookup -- the screen-space derivatives of the direction, carried to
+ * the selected face -- and leaves the arithmetic to the hardware, so this is an ORACLE DEFINITION (parity unpinned):
+ *   face, (sc, tc, ma) of r as in or_cube_linear; for a derivative d of r (ddx or ddy) the same selection gives (dsc, dtc) and
+ *   dma = sign(r_major) * d_major; the face coordinate u = 0.5 (sc / ma + 1) then moves by (chain rule)
+ *       du = (dsc - (sc / ma) dma) / ma * 0.5 dim      [level-0 texels per pixel], dv alike;
+ *   rho^2 = max(du_x^2 + dv_x^2, du_y^2 + dv_y^2);  lod = min(0.5 log2(min(rho^2, 3e38)), levels - 1), 0 unless rho^2 > 1
+ *   (the deterministic log2 of or_math.h);  the two levels floor(lod), floor(lod) + 1 are each filtered as or_cube_linear
+ *   filters level 0 and mixed with one mad: c0 + frac * (c1 - c0); frac == 0 takes the lower level alone.
+ * The chain is stored level after level, each level six faces of max(dim >> level, 1)^2 RGBA8 texels. */
+static inline uint32_t or_cube_level_dim(uint32_t dim, uint32_t level) { uint32_t d = dim >> level; return d ? d : 1u; }
+static inline size_t or_cube_level_offset(uint32_t dim, uint32_t level)
+{
+    size_t off = 0;
+    for (uint32_t k = 0; k < level; ++k) { size_t d = or_cube_level_dim(dim, k); off += 6u * d * d * 4u; }
+    return off;
+}
+static inline void or_cube_face_delta(const float r[3], const float d[3], float half_dim, float* du, float* dv)
+{
+    float ax = fabsf(r[0]), ay = fabsf(r[1]), az = fabsf(r[2]);
+    float sc, tc, ma, dsc, dtc, dma;
+    if (ax >= ay && ax >= az) { ma = ax; if (r[0] >= 0.0f) { sc = -r[2]; tc = -r[1]; dsc = -d[2]; dtc = -d[1]; dma = d[0]; } else { sc = r[2]; tc = -r[1]; dsc = d[2]; dtc = -d[1]; dma = -d[0]; } }
+    else if (ay >= az)        { ma = ay; if (r[1] >= 0.0f) { sc = r[0]; tc = r[2]; dsc = d[0]; dtc = d[2]; dma = d[1]; } else { sc = r[0]; tc = -r[2]; dsc = d[0]; dtc = -d[2]; dma = -d[1]; } }
+    else                      { ma = az; if (r[2] >= 0.0f) { sc = r[0]; tc = -r[1]; dsc = d[0]; dtc = -d[1]; dma = d[2]; } else { sc = -r[0]; tc = -r[1]; dsc = -d[0]; dtc = -d[1]; dma = -d[2]; } }
+    float inv = or_rcp(ma);
+    *du = fmaf(-(sc * inv), dma, dsc) * inv * half_dim;
+    *dv = fmaf(-(tc * inv), dma, dtc) * inv * half_dim;
+}
+static inline float or_cube_lod(uint32_t dim, uint32_t levels, const float r[3], const float ddx[3], const float ddy[3])
+{
+    float half_dim = 0.5f * (float)dim, ux, vx, uy, vy;
+    or_cube_face_delta(r, ddx, half_dim, &ux, &vx);
+    or_cube_face_delta(r, ddy, half_dim, &uy, &vy);
+    float rx = fmaf(ux, ux, vx * vx), ry = fmaf(uy, uy, vy * vy);
+    float rho2 = (ry > rx) ? ry : rx;               /* a NaN rx makes rho2 NaN, a NaN ry is ignored; either way: */
+    if (!(rho2 > 1.0f)) return 0.0f;                /* ... magnified, or undefined -> level 0 */
+    float lod = 0.5f * or_det_log2_normal(rho2 < 3.0e38f ? rho2 : 3.0e38f);
+    float top = (float)(levels - 1u);
+    return lod < top ? lod : top;
+}
+static inline void or_cube_trilinear(const uint8_t* chain, uint32_t dim, uint32_t levels, const float r[3], float lod, float* out, int nch)
+{
+    uint32_t l0 = (uint32_t)lod;
+    float frac = lod - (float)l0;
+    float c0[4], c1[4];
+    or_cube_linear(chain + or_cube_level_offset(dim, l0), or_cube_level_dim(dim, l0), r, c0, nch);
+    if (frac == 0.0f || l0 + 1u >= levels) { for (int c = 0; c < nch; ++c) out[c] = c0[c]; return; }
+    or_cube_linear(chain + or_cube_level_offset(dim, l0 + 1u), or_cube_level_dim(dim, l0 + 1u), r, c1, nch);
+    for (int c = 0; c < nch; ++c) out[c] = fmaf(frac, c1[c] - c0[c], c0[c]);
+}
+
 #endif

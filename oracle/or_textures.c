@@ -191,9 +191,10 @@ int or_load_dds_rgba8_mips(const char* path, uint8_t* rgba8, size_t capacity, ui
     return load_dds(path, rgba8, capacity, width, height, mips, 1);
 }
 
-/* The sky cube map (CRYCHIC.cpp:960,968,1148-1151): level 0 of the six faces, +X -X +Y -Y +Z -Z, each face followed in the file by
- * the rest of its mip chain. */
-int or_load_dds_cube_rgba8(const char* path, uint8_t* rgba8, size_t capacity, uint32_t* dim)
+/* The sky cube map (CRYCHIC.cpp:960,968,1148-1151): the six faces, +X -X +Y -Y +Z -Z, each face followed in the file by the rest of
+ * its mip chain.  want_mips == 0: level 0 of each face, stacked.  Otherwise the whole chain the file stores, re-ordered level after
+ * level (each level: six faces of max(dim >> level, 1)^2 texels) -- the layout or_cube_trilinear reads. */
+static int load_dds_cube(const char* path, uint8_t* rgba8, size_t capacity, uint32_t* dim, uint32_t* mips, int want_mips)
 {
     FILE* f = fopen(path, "rb");
     if (!f) return -1;
@@ -214,20 +215,39 @@ int or_load_dds_cube_rgba8(const char* path, uint8_t* rgba8, size_t capacity, ui
         for (uint32_t mm = w; mm > 1; mm >>= 1) ++full;
         if (levels == 0) levels = 1;
         if (kind >= 0 && cube && w == h && w > 0 && w <= 16384u && levels <= full) {
+            uint32_t out_levels = want_mips ? levels : 1u;
             if (dim) *dim = w;
-            size_t face_file = 0;
+            if (mips) *mips = out_levels;
+            size_t face_file = 0, need = 0;
             { uint32_t lw = w; for (uint32_t k = 0; k < levels; ++k) {
                   face_file += kind == 0 ? (size_t)lw * lw * 4 : (size_t)((lw + 3) / 4) * ((lw + 3) / 4) * (kind == 1 ? 8 : 16);
+                  if (k < out_levels) need += (size_t)6 * lw * lw * 4;
                   lw = lw > 1 ? lw >> 1 : 1; } }
             if (!rgba8) rc = 0;
-            else if (capacity < (size_t)6 * w * w * 4 || (size_t)n - off < 6 * face_file) rc = -1;
+            else if (capacity < need || (size_t)n - off < 6 * face_file) rc = -1;
             else {
                 rc = 0;
-                for (uint32_t face = 0; face < 6; ++face)
-                    if (!decode_level(kind, m, d + off + face * face_file, (size_t)n - off - face * face_file, w, w, rgba8 + (size_t)face * w * w * 4)) rc = -1;
+                for (uint32_t face = 0; face < 6; ++face) {
+                    const unsigned char* src = d + off + face * face_file;
+                    size_t avail = (size_t)n - off - face * face_file;
+                    uint8_t* level_out = rgba8;
+                    uint32_t lw = w;
+                    for (uint32_t k = 0; k < out_levels && rc == 0; ++k) {
+                        size_t used = decode_level(kind, m, src, avail, lw, lw, level_out + (size_t)face * lw * lw * 4);
+                        if (!used) rc = -1;
+                        src += used; avail -= used;
+                        level_out += (size_t)6 * lw * lw * 4;
+                        lw = lw > 1 ? lw >> 1 : 1;
+                    }
+                }
             }
         }
     }
     free(d);
     return rc;
+}
+int or_load_dds_cube_rgba8(const char* path, uint8_t* rgba8, size_t capacity, uint32_t* dim) { return load_dds_cube(path, rgba8, capacity, dim, NULL, 0); }
+int or_load_dds_cube_rgba8_mips(const char* path, uint8_t* rgba8, size_t capacity, uint32_t* dim, uint32_t* mips)
+{
+    return load_dds_cube(path, rgba8, capacity, dim, mips, 1);
 }

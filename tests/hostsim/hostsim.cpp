@@ -304,7 +304,9 @@ void hs_light(const crychic_pass_constants* cb, const float* g0, const float* g1
     P.darkLights = light_dark_mask(P.Lights, numDirLights);
     P.unitLights = light_dark_lengths_ok(P.Lights, numDirLights) ? 1u : 0u;
     P.rcpW = rcp((float)W); P.rcpH = rcp((float)H);
+    P.cubeLevels = (flags >> 16) & 15u;                    // CRYCHIC_LIGHT_CUBE_LEVELS
     light_params_derive(P);
+    const bool chain = P.cubeLevels > 1u;
     const AllPointLights pl{ pointLights, numPointLights };
     const f4a* G0 = (const f4a*)g0; const f4a* G1 = (const f4a*)g1; const f4a* G2 = (const f4a*)g2;
     for (uint32_t y = row0; y < row0 + rows; ++y)
@@ -312,13 +314,24 @@ void hs_light(const crychic_pass_constants* cb, const float* g0, const float* g1
             const uint32_t idx = y * W + x;
             f4 lit;
             const bool fix = (flags & (CRYCHIC_FIX_Q1 | CRYCHIC_FIX_Q3 | CRYCHIC_FIX_Q4)) != 0;     // as launch_light picks the instantiation
-            if ((depth[idx] & 0x00FFFFFFu) < 0x00FFFFFFu) {
+            if (chain && (depth[idx] & 0x00FFFFFFu) < 0x00FFFFFFu) {
+                // light_kernel<.., MIPS>: the neighbours' reflection vectors arrive by lane exchange there, by recomputation here
+                auto shaded = [&](uint32_t xx, uint32_t yy) { return xx < W && yy < row0 + rows && (depth[yy * W + xx] & 0x00FFFFFFu) < 0x00FFFFFFu; };
+                const f3 r = reflection_dir(P, G0[idx], G2[idx]);
+                f3 ddx{ 0.0f, 0.0f, 0.0f }, ddy{ 0.0f, 0.0f, 0.0f };
+                if (shaded(x ^ 1u, y)) { const f3 n = reflection_dir(P, G0[y * W + (x ^ 1u)], G2[y * W + (x ^ 1u)]); ddx = (x & 1u) ? f3{ r.x - n.x, r.y - n.y, r.z - n.z } : f3{ n.x - r.x, n.y - r.y, n.z - r.z }; }
+                if (shaded(x, y ^ 1u)) { const f3 n = reflection_dir(P, G0[(y ^ 1u) * W + x], G2[(y ^ 1u) * W + x]); ddy = (y & 1u) ? f3{ r.x - n.x, r.y - n.y, r.z - n.z } : f3{ n.x - r.x, n.y - r.y, n.z - r.z }; }
+                const CubeChain cc{ cube_lod(P.cubeDim, P.cubeLevels, r, ddx, ddy) };
+                if (pcfSearchRadius == 0.0f) lit = light_pixel<true, AllPointLights, true, CubeChain>(P, G0[idx], G1[idx], G2[idx], ambient, (const uint32_t*)cube, pl, cc);
+                else lit = light_pixel<false, AllPointLights, true, CubeChain>(P, G0[idx], G1[idx], G2[idx], ambient, (const uint32_t*)cube, pl, cc);
+            }
+            else if ((depth[idx] & 0x00FFFFFFu) < 0x00FFFFFFu) {
                 if (pcfSearchRadius == 0.0f) lit = fix ? light_pixel<true, AllPointLights, true>(P, G0[idx], G1[idx], G2[idx], ambient, (const uint32_t*)cube, pl)
                                                        : light_pixel<true, AllPointLights, false>(P, G0[idx], G1[idx], G2[idx], ambient, (const uint32_t*)cube, pl);
                 else lit = fix ? light_pixel<false, AllPointLights, true>(P, G0[idx], G1[idx], G2[idx], ambient, (const uint32_t*)cube, pl)
                                : light_pixel<false, AllPointLights, false>(P, G0[idx], G1[idx], G2[idx], ambient, (const uint32_t*)cube, pl);
             }
-            else if (flags & CRYCHIC_LIGHT_SKY) lit = sky_pixel(P, (const uint32_t*)cube, x, y);
+            else if (flags & CRYCHIC_LIGHT_SKY) lit = chain ? sky_pixel_chain(P, (const uint32_t*)cube, x, y) : sky_pixel(P, (const uint32_t*)cube, x, y);
             else lit = f4{ 0.690196097f, 0.768627524f, 0.870588303f, 1.0f };
             if (radiance) { radiance[4 * idx] = lit.x; radiance[4 * idx + 1] = lit.y; radiance[4 * idx + 2] = lit.z; radiance[4 * idx + 3] = lit.w; }
             ((uint32_t*)out)[idx] = pack_rgba8(lit);

@@ -154,8 +154,9 @@ class HostSim:
         return {"depth": depth, "normal": normal.view(np.float16) if normal is not None else None, "g0": g[0], "g1": g[1], "g2": g[2], "tris": n}
 
     def light(self, cb, g0, g1, g2, depth_u32, ambient, shadow_u32, cube_u8, num_dir_lights, pcf_radius, flags=0,
-              want_radiance=False, point_lights=None):
+              want_radiance=False, point_lights=None, cube_dim=None, cube_levels=0):
         H, W = depth_u32.shape
+        flags = int(flags) | ((int(cube_levels) & 15) << 16)
         out = np.zeros((H, W, 4), dtype=np.uint8)
         rad = np.zeros((H, W, 4), dtype=np.float32) if want_radiance else None
         g0, g1, g2 = (np.ascontiguousarray(g) for g in (g0, g1, g2))
@@ -163,7 +164,7 @@ class HostSim:
         a = np.ascontiguousarray(ambient) if ambient is not None else None
         sh = (C.c_void_p * 4)(*[s[k].ctypes.data for k in range(4)])
         self.lib.hs_light(C.addressof(cb), g0.ctypes.data, g1.ctypes.data, g2.ctypes.data, d.ctypes.data,
-                          a.ctypes.data if a is not None else None, sh, s.shape[1], c.ctypes.data, c.shape[1],
+                          a.ctypes.data if a is not None else None, sh, s.shape[1], c.ctypes.data, int(cube_dim or c.shape[1]),
                           out.ctypes.data, rad.ctypes.data if rad is not None else None, W, H, 0, H, num_dir_lights,
                           pcf_radius, flags, C.addressof(point_lights) if point_lights is not None else None,
                           len(point_lights) if point_lights is not None else 0)

@@ -135,7 +135,8 @@ class Oracle:
         return a0
 
     def deferred_light(self, cb, g0, g1, g2, depth_u32, ambient, shadow_u32, cube_u8, num_dir_lights, pcf_radius,
-                       sky=False, want_radiance=False, row0=0, rows=None, point_lights=None, fixes=0):
+                       sky=False, want_radiance=False, row0=0, rows=None, point_lights=None, fixes=0, cube_dim=None, cube_levels=0):
+        """cube_levels > 1: cube_u8 is a flat mip chain (CRYCHIC_LIGHT_CUBE_LEVELS layout) of a cube map with cube_dim-texel faces."""
         H, W = depth_u32.shape
         rows = H - row0 if rows is None else rows
         out = np.zeros((H, W, 4), dtype=np.uint8)
@@ -145,9 +146,9 @@ class Oracle:
         a = _np(ambient, np.uint16) if ambient is not None else None
         sh = (C.c_void_p * 4)(*[s[k].ctypes.data for k in range(4)])
         self.lib.or_deferred_light_points(C.addressof(cb), g0.ctypes.data, g1.ctypes.data, g2.ctypes.data, d.ctypes.data,
-                                          a.ctypes.data if a is not None else None, sh, s.shape[1], c.ctypes.data, c.shape[1],
+                                          a.ctypes.data if a is not None else None, sh, s.shape[1], c.ctypes.data, int(cube_dim or c.shape[1]),
                                           out.ctypes.data, rad.ctypes.data if rad is not None else None, W, H, row0, rows,
-                                          num_dir_lights, pcf_radius, (1 if sky else 0) | int(fixes),
+                                          num_dir_lights, pcf_radius, (1 if sky else 0) | int(fixes) | ((int(cube_levels) & 15) << 16),
                                           C.addressof(point_lights) if point_lights is not None else None,
                                           len(point_lights) if point_lights is not None else 0)
         return (out, rad) if want_radiance else out

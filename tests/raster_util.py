@@ -15,8 +15,9 @@ def light_viewproj_t(consts, k):
 
 
 def oracle_frame(orc, consts, items, shadow_items, materials, textures, W, H, shadow_dim, cube, blur_count, num_dir_lights,
-                 pcf_radius, sky=True):
-    """The whole reference frame on the CPU: 4 shadow cascades, normals+depth, G-buffer, ComputeSsao, lighting."""
+                 pcf_radius, sky=True, cube_dim=None, cube_levels=0):
+    """The whole reference frame on the CPU: 4 shadow cascades, normals+depth, G-buffer, ComputeSsao, lighting.  cube_levels > 1:
+    `cube` is a flat mip chain of a cube map with cube_dim-texel faces."""
     view = np.array(consts.pass_cb.View, np.float32)
     vp = np.array(consts.pass_cb.ViewProj, np.float32)
     mats = materials.view(oracle_lib.MATERIAL_DT) if materials is not None else None
@@ -27,7 +28,8 @@ def oracle_frame(orc, consts, items, shadow_items, materials, textures, W, H, sh
     scb = oracle_lib.as_oracle_cb(consts.ssao_cb, oracle_lib.OrSsaoConstants)
     pcb = oracle_lib.as_oracle_cb(consts.pass_cb, oracle_lib.OrPassConstants)
     ao = orc.compute_ssao(scb, nd["normal"], nd["depth"], consts.randvec, blur_count) if blur_count >= 0 else None
-    rgba = orc.deferred_light(pcb, gb["g0"], gb["g1"], gb["g2"], nd["depth"], ao, shadow, cube, num_dir_lights, pcf_radius, sky=sky)
+    rgba = orc.deferred_light(pcb, gb["g0"], gb["g1"], gb["g2"], nd["depth"], ao, shadow, cube, num_dir_lights, pcf_radius, sky=sky,
+                              cube_dim=cube_dim, cube_levels=cube_levels)
     return {"shadow": shadow, "normal": nd["normal"], "depth": nd["depth"], "g0": gb["g0"], "g1": gb["g1"], "g2": gb["g2"], "ao": ao,
             "rgba8": rgba, "tris": nd["tris"]}
 

@@ -100,8 +100,11 @@ def test_veneer_full_scene_matches_oracle(built_lib, oracle, tmp_path):
 
 
 @pytest.mark.gpu
-def test_veneer_load_textures(built_lib, oracle, tmp_path):
-    """CRYCHIC::LoadTextures through the veneer: the six material textures (with their mip chains) and the sky cube map are read
+@pytest.mark.parametrize("cube_levels", [1, 5])
+def test_veneer_load_textures(built_lib, oracle, tmp_path, cube_levels):
+    """cube_levels = 5: the cube file carries its mip chain (16 .. 1), which LoadTextures binds whole as the reference does
+    (CRYCHIC.cpp:1148-1151) -- the frame is then the oracle's with trilinear cube lookups.
+    CRYCHIC::LoadTextures through the veneer: the six material textures (with their mip chains) and the sky cube map are read
     from DDS files in a directory laid out like the reference's Textures/, and the frame the veneer then renders -- G-buffer
     sampled anisotropically from those chains, sky and reflections from that cube map -- equals the all-CPU oracle frame fed with
     the oracle's own decode of the same files."""
@@ -122,7 +125,8 @@ def test_veneer_load_textures(built_lib, oracle, tmp_path):
         (tdir / name).write_bytes(mip_header(32, 32, len(levels), None, masks) + b"".join(np.ascontiguousarray(l[..., [2, 1, 0, 3]]).tobytes() for l in levels))
     rng = np.random.default_rng(3)
     faces = rng.integers(0, 256, (6, CD, CD, 4), dtype=np.uint8)
-    (tdir / "snowcube1024.dds").write_bytes(cube_header(CD, 1, None, masks) + faces.tobytes())
+    face_chains = [g.box_mips(faces[k])[:cube_levels] for k in range(6)]          # file order: face after face, each with its chain
+    (tdir / "snowcube1024.dds").write_bytes(cube_header(CD, cube_levels, None, masks) + b"".join(lv.tobytes() for fc in face_chains for lv in fc))
     np.zeros((6, CD, CD, 4), np.uint8).tofile(d + "/cube.bin")        # what SetCubeMap installs first: LoadTextures must replace it
     r = subprocess.run([exe, d, str(W), str(H), str(SD), str(CD), str(BC), str(NL), "scene", str(tdir)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
@@ -134,12 +138,17 @@ def test_veneer_load_textures(built_lib, oracle, tmp_path):
     tex = [oracle_load_mips(oracle, str(tdir / n)) for n in names]
     cube = oracle_cube(oracle, str(tdir / "snowcube1024.dds"))
     assert np.array_equal(cube, faces[..., [2, 1, 0, 3]])
+    chain_kw = {}
+    if cube_levels > 1:
+        chain, n = g.cube_mip_chain(cube, cube_levels)          # box-filtering commutes with the channel swizzle: == the file's chain
+        assert n == cube_levels and np.array_equal(chain, g.load_dds_cube_mips(str(tdir / "snowcube1024.dds"))[0])
+        cube, chain_kw = chain, dict(cube_dim=CD, cube_levels=cube_levels)
     ref = raster_util.oracle_frame(oracle, consts, items, shadow_items, g.reference_materials(), tex, W, H, SD, cube, BC, NL,
-                                   built_lib.lib.crychic_pcf_search_radius(SD, 1))
+                                   built_lib.lib.crychic_pcf_search_radius(SD, 1), **chain_kw)
     for i, k in enumerate(("g0", "g1", "g2")):
         assert np.array_equal(np.fromfile(d + "/g%d_out.bin" % i, np.uint32).reshape(H, W, 4), ref[k].view(np.uint32)), k
     assert np.array_equal(np.fromfile(d + "/out.bin", np.uint8).reshape(H, W, 4), ref["rgba8"])
     # the textures do change the frame: the same scene without them (the previous test) has other albedo
     flat = raster_util.oracle_frame(oracle, consts, items, shadow_items, g.reference_materials(), None, W, H, SD, cube, BC, NL,
-                                    built_lib.lib.crychic_pcf_search_radius(SD, 1))
+                                    built_lib.lib.crychic_pcf_search_radius(SD, 1), **chain_kw)
     assert not np.array_equal(flat["g1"], ref["g1"])

@@ -154,9 +154,10 @@ def test_bench_json_contract(built_lib):
     # N = 1 default: one frame at a time, with the labelled legs of the same run beside it
     cfg = out["config"]
     assert cfg["frames_in_flight"] == 1 and cfg["frame_ms_median_hipevent"] > 0
-    for name in ("throughput_3_in_flight", "pcf_intended", "camera_covered"):
+    for name in ("throughput_3_in_flight", "pcf_intended", "camera_covered", "cube_mip_chain"):
         assert cfg[name]["ms_per_frame"] > 0 and cfg[name]["Mpixels_per_s"] > 0 and 0 < cfg[name]["hbm_roofline_frac"] < 1, name
     assert cfg["camera_covered"]["covered_pixel_fraction"] > 0.999 and cfg["pcf_intended"]["light_ms"] > 0
+    assert cfg["cube_mip_chain"]["cube_levels"] == 7 and cfg["cube_mip_chain"]["light_ms"] > 0          # --cube-dim 64
     assert all(k["ms"] > 0 and k["achieved_GBs"] > 0 for k in rf["kernels"])
     cb = out["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "Mpixels/s" and isinstance(cb["sample"], str)

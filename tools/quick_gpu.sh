@@ -25,6 +25,6 @@ import json
 d = json.load(open("gpurun_out/${tag}_bench.json"))
 c = d["config"]
 print("value", d["value"], "ms", d["ms_per_step"], "median", c["frame_ms_median_hipevent"], "frac", d["roofline"]["frac"], "pass", c["pass_ms"])
-for k in ("throughput_3_in_flight", "pcf_intended", "camera_covered"):
+for k in ("throughput_3_in_flight", "pcf_intended", "camera_covered", "cube_mip_chain"):
     print(k, c.get(k))
 PY
