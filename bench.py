@@ -882,6 +882,7 @@ def main():
                        "throughput_3_in_flight": legs.get("throughput_3_in_flight"),
                        "pcf_intended": legs.get("pcf_intended"),
                        "camera_covered": legs.get("camera_covered"),
+                       "cube_mip_chain": legs.get("cube_mip_chain"),
                        "producer_passes_ms": producer_ms,
                        # what one rank spends on a frame end to end: its producers (shadow cascades whole, G-buffer for its strip) + the step
                        "frame_ms_incl_producers_rank0": (round(dt / args.steps * 1e3 + producer_ms["shadow_4x%d" % args.shadow_dim]

@@ -60,7 +60,7 @@ def main():
     wl = {"width": 3840, "height": 2160, "blur_count": 4, "lights": 3, "pcf": "literal", "shadow_dim": 4096, "camera": "reference"}
     passes = {"ssao": [("depth_pairs_kernel", 1), ("ssao_kernel<true, true, true, false>", 1)],
               "blur": [("blur_pair_kernel<true>", 1), ("blur_replay_chain_kernel", 1)],
-              "light": [("light_kernel<true, false>", 1)]}
+              "light": [("light_kernel<true, false, false>", 1)]}
     kernels = {}
     for name, kw in passes.items():
         t = agg(kw)
