@@ -492,7 +492,7 @@ __global__ __launch_bounds__(256) void light_kernel(LightParams P, const f4a* __
         const float lod = quad_reflection_lod(P, covered, r, x, y);
         if (!in) return;
         f4 lit;
-        if (covered) lit = light_pixel<ZERO_RADIUS, NoPointLights, FIX, CubeChain>(P, G0, g1[idx], G2, ambient, cube, NoPointLights(), CubeChain{ lod });
+        if (covered) lit = light_pixel<ZERO_RADIUS, NoPointLights, FIX, CubeChain>(P, G0, g1[idx], G2, ambient, cube, NoPointLights(), CubeChain{ lod, cube_chain_flat(lod) });
         else if (P.flags & CRYCHIC_LIGHT_SKY) lit = sky_pixel_chain(P, cube, x, y);
         else lit = f4{ 0.690196097f, 0.768627524f, 0.870588303f, 1.0f };
         if (radiance) radiance[idx] = f4a{ lit.x, lit.y, lit.z, lit.w };
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256) void light_points_kernel(LightParams P, const 
                 }
             }
         };
-        if (MIPS) lit = light_pixel<ZERO_RADIUS, decltype(culled), true, CubeChain>(P, G0, g1[idx], G2, ambient, cube, culled, CubeChain{ lod });
+        if (MIPS) lit = light_pixel<ZERO_RADIUS, decltype(culled), true, CubeChain>(P, G0, g1[idx], G2, ambient, cube, culled, CubeChain{ lod, cube_chain_flat(lod) });
         else lit = light_pixel<ZERO_RADIUS, decltype(culled), true>(P, G0, g1[idx], g2[idx], ambient, cube, culled);
     } else if (P.flags & CRYCHIC_LIGHT_SKY) {
         lit = MIPS ? sky_pixel_chain(P, cube, x, y) : sky_pixel(P, cube, x, y);

@@ -332,7 +332,9 @@ struct CubeFetch { TexelPair p0, p1; float fx, fy; };
 // The two rows of a footprint as loaded, before pair_at_clamped's picks: texels (cx, cx + 1) of rows y0, y1, and the column index
 // i0 the picks need (cube_pick).  cube_fetch issues the loads and nothing else touches them until cube_resolve.
 struct CubeRows { RawPair r0, r1; float fx, fy; int i0; };
-CRY_HD CubeRows cube_fetch(const uint32_t* __restrict__ cube, uint32_t dim, f3 r)
+// Where the two rows of a footprint start (texel indices into the cube map plane) and what the filter needs besides the texels.
+struct CubeAddr { uint32_t t0, t1; float fx, fy; int i0; };
+CRY_HD CubeAddr cube_address(uint32_t dim, f3 r)
 {
     const float ax = __builtin_fabsf(r.x), ay = __builtin_fabsf(r.y), az = __builtin_fabsf(r.z);
     // major axis (ties x >= y >= z) and the face's (sc, tc) by selects: a wave whose lanes look at different faces stays converged
@@ -358,7 +360,7 @@ CRY_HD CubeRows cube_fetch(const uint32_t* __restrict__ cube, uint32_t dim, f3 r
 #if defined(__HIP_DEVICE_COMPILE__)
     inside = __builtin_amdgcn_ballot_w64(!inside) == 0;
 #endif
-    CubeRows f;
+    CubeAddr f;
     uint32_t t0, t1;
     if (inside) {
         f.i0 = (int)flx;
@@ -380,10 +382,15 @@ CRY_HD CubeRows cube_fetch(const uint32_t* __restrict__ cube, uint32_t dim, f3 r
         f.fx = b.fx;
         f.fy = b.fy;
     }
-    f.r0 = load_pair(cube, t0);
-    f.r1 = load_pair(cube, t1);
+    f.t0 = t0;
+    f.t1 = t1;
     return f;
 }
+CRY_HD CubeRows cube_load(const uint32_t* __restrict__ cube, const CubeAddr& a)
+{
+    return CubeRows{ load_pair(cube, a.t0), load_pair(cube, a.t1), a.fx, a.fy, a.i0 };
+}
+CRY_HD CubeRows cube_fetch(const uint32_t* __restrict__ cube, uint32_t dim, f3 r) { return cube_load(cube, cube_address(dim, r)); }
 // pair_at_clamped's picks: texels clamp(i0) and clamp(i0 + 1) out of the loaded pair (cx, cx + 1), cx = clamp(i0, 0, dim - 2)
 CRY_HD CubeFetch cube_pick(const CubeRows& c, uint32_t dim)
 {
@@ -459,32 +466,58 @@ CRY_HD float cube_lod(uint32_t dim, uint32_t levels, f3 r, f3 ddx, f3 ddy)
     return lod < top ? lod : top;
 }
 CRY_HD uint32_t cube_level_dim(uint32_t dim, uint32_t level) { const uint32_t d = dim >> level; return d ? d : 1u; }
-// One level of the chain (dim and level may differ from lane to lane).  A 1 x 1 level is its face's texel.
-template <bool WANT_ALPHA>
-CRY_HD f4 cube_level_linear(const uint32_t* __restrict__ chain, uint32_t dim, uint32_t levels, uint32_t level, f3 r)
+// The footprint of a lookup at one level of the chain, for levels (and so level sizes) that differ from lane to lane: selects, no
+// branch, so that a caller can issue the loads of two levels together.  A 1 x 1 level is its face's texel: the pair loaded is
+// texels (min(face, 4), + 1) of the level -- inside it -- and `hiOnly` says which of the two is the face's (cube_level_pick); its
+// four "texels" being one, the filter weights (computed as for any level) do not matter unless they are non-finite, and then they
+// poison the result exactly as they do in the definition.
+struct CubeLevelAddr { uint32_t t0, t1; float fx, fy; int i0; uint32_t d; bool one, hiOnly; };
+CRY_HD CubeLevelAddr cube_level_address(uint32_t off, uint32_t d, f3 r)
 {
-    uint32_t off = 0;                                   // texels before `level`
-    for (uint32_t k = 0; k + 1u < levels; ++k) { const uint32_t d = cube_level_dim(dim, k); off += k < level ? 6u * d * d : 0u; }
-    const uint32_t d = cube_level_dim(dim, level);
-    if (d >= 2u) return cube_resolve<WANT_ALPHA>(cube_pick(cube_fetch(chain + off, d, r), d));
     const float ax = __builtin_fabsf(r.x), ay = __builtin_fabsf(r.y), az = __builtin_fabsf(r.z);
     const bool isx = (ax >= ay) & (ax >= az), isy = !isx & (ay >= az);
-    const uint32_t face = isx ? (r.x >= 0.0f ? 0u : 1u) : (isy ? (r.y >= 0.0f ? 2u : 3u) : (r.z >= 0.0f ? 4u : 5u));
-    const uint32_t t = chain[off + face];
-    const CubeFetch f{ TexelPair{ t, t }, TexelPair{ t, t }, 0.0f, 0.0f };
-    // bilinear_setup's weights on a 1 x 1 level are not 0, but all four texels are the one texel and lerp(t, t, w) == t for the
-    // unorm8 values a texel decodes to (t + w * (t - t)); a non-finite direction poisons the weights in the oracle alone -- and
-    // poisons the face selection the same way on both sides first (all comparisons false: face 5, -Z)
-    return cube_resolve<WANT_ALPHA>(f);
+    const bool px = r.x >= 0.0f, py = r.y >= 0.0f, pz = r.z >= 0.0f;
+    const float ma = isx ? ax : (isy ? ay : az);
+    const float sc = isx ? (px ? -r.z : r.z) : (isy ? r.x : (pz ? r.x : -r.x));
+    const float tc = isx ? -r.y : (isy ? (py ? r.z : -r.z) : -r.y);
+    const uint32_t face = isx ? (px ? 0u : 1u) : (isy ? (py ? 2u : 3u) : (pz ? 4u : 5u));
+    const float rma = rcp(ma);
+    const float u = fma(0.5f, sc * rma, 0.5f), v = fma(0.5f, tc * rma, 0.5f);
+    const Bilin b = bilinear_setup(u, v, d, d);
+    const uint32_t dd = d < 2u ? 2u : d;                // keeps the clamps in range for the 1 x 1 level, whose addresses are set below
+    const uint32_t y0 = (uint32_t)clampi(b.j0, 0, (int)dd - 1), y1 = (uint32_t)clampi(b.j0 + 1, 0, (int)dd - 1);
+    const uint32_t cx = (uint32_t)clampi(b.i0, 0, (int)dd - 2);
+    const uint32_t faceRow = face * d;
+    CubeLevelAddr a;
+    a.one = d < 2u;
+    a.hiOnly = face == 5u;
+    const uint32_t single = off + (face < 4u ? face : 4u);
+    a.t0 = a.one ? single : off + (faceRow + y0) * d + cx;
+    a.t1 = a.one ? single : off + (faceRow + y1) * d + cx;
+    a.fx = b.fx; a.fy = b.fy; a.i0 = b.i0; a.d = d;
+    return a;
 }
+CRY_HD CubeFetch cube_level_pick(const CubeLevelAddr& a, RawPair r0, RawPair r1)
+{
+    const CubeFetch f = cube_pick(CubeRows{ r0, r1, a.fx, a.fy, a.i0 }, a.d);
+    const uint32_t t = a.hiOnly ? r0.hi : r0.lo;
+    return a.one ? CubeFetch{ TexelPair{ t, t }, TexelPair{ t, t }, a.fx, a.fy } : f;
+}
+// The two levels of a trilinear lookup: both footprints addressed, then the four loads, then the filters and the mad.
 template <bool WANT_ALPHA>
 CRY_HD f4 cube_trilinear(const uint32_t* __restrict__ chain, uint32_t dim, uint32_t levels, f3 r, float lod)
 {
     const uint32_t l0 = (uint32_t)lod;
     const float frac = lod - (float)l0;
-    const uint32_t l1 = l0 + 1u < levels ? l0 + 1u : l0;
-    const f4 c0 = cube_level_linear<WANT_ALPHA>(chain, dim, levels, l0, r);
-    const f4 c1 = cube_level_linear<WANT_ALPHA>(chain, dim, levels, l1, r);       // l1 == l0 or frac == 0: the mad returns c0 (finite texels)
+    const uint32_t l1 = l0 + 1u < levels ? l0 + 1u : l0;       // l1 == l0 or frac == 0: the mad returns c0 (texels are finite)
+    uint32_t off0 = 0;                                          // texels before level l0
+    for (uint32_t k = 0; k + 1u < levels; ++k) { const uint32_t d = cube_level_dim(dim, k); off0 += k < l0 ? 6u * d * d : 0u; }
+    const uint32_t d0 = cube_level_dim(dim, l0), d1 = cube_level_dim(dim, l1);
+    const uint32_t off1 = off0 + (l1 > l0 ? 6u * d0 * d0 : 0u);
+    const CubeLevelAddr a0 = cube_level_address(off0, d0, r), a1 = cube_level_address(off1, d1, r);
+    const RawPair p00 = load_pair(chain, a0.t0), p01 = load_pair(chain, a0.t1), p10 = load_pair(chain, a1.t0), p11 = load_pair(chain, a1.t1);
+    const f4 c0 = cube_resolve<WANT_ALPHA>(cube_level_pick(a0, p00, p01));
+    const f4 c1 = cube_resolve<WANT_ALPHA>(cube_level_pick(a1, p10, p11));
     return f4{ fma(frac, c1.x - c0.x, c0.x), fma(frac, c1.y - c0.y, c0.y), fma(frac, c1.z - c0.z, c0.z), WANT_ALPHA ? fma(frac, c1.w - c0.w, c0.w) : 0.0f };
 }
 // How light_pixel looks the cube map up: level 0 alone (the fetch in flight with the pixel's other gathers) ...
@@ -493,13 +526,34 @@ struct CubeLevel0 {
     CRY_HD Fetch fetch(const LightParams& P, const uint32_t* __restrict__ cube, f3 r) const { return Fetch{ cube_fetch(cube, P.cubeDim, r) }; }
     CRY_HD f4 resolve(const LightParams& P, const uint32_t* __restrict__, const Fetch& f) const { return cube_resolve<false>(cube_pick(f.c, P.cubeDim)); }
 };
-// ... or the chain at the level of detail the caller derived from the pixel's quad (light_kernel<.., MIPS>)
+// ... or the chain at the level of detail the caller derived from the pixel's quad (light_kernel<.., MIPS>).  `flat`: every lane of the
+// wavefront that shades looks at level 0 alone (lod == 0 -- the lookup is magnified, which is most of a 4K frame): the mad with
+// frac == 0 returns the level-0 filter bit for bit, so the wavefront takes CubeLevel0's lookup, in flight with its other gathers.
 struct CubeChain {
     float lod;
-    struct Fetch { f3 r; };
-    CRY_HD Fetch fetch(const LightParams&, const uint32_t* __restrict__, f3 r) const { return Fetch{ r }; }
-    CRY_HD f4 resolve(const LightParams& P, const uint32_t* __restrict__ cube, const Fetch& f) const { return cube_trilinear<false>(cube, P.cubeDim, P.cubeLevels, f.r, lod); }
+    bool flat;
+    struct Fetch { CubeRows c; f3 r; };
+    CRY_HD Fetch fetch(const LightParams& P, const uint32_t* __restrict__ cube, f3 r) const
+    {
+        CubeAddr a{ 0u, 0u, 0.0f, 0.0f, 0 };
+        if (flat) a = cube_address(P.cubeDim, r);            // the vote picks the addresses; the loads follow the merge
+        return Fetch{ cube_load(cube, a), r };
+    }
+    CRY_HD f4 resolve(const LightParams& P, const uint32_t* __restrict__ cube, const Fetch& f) const
+    {
+        if (flat) return cube_resolve<false>(cube_pick(f.c, P.cubeDim));
+        return cube_trilinear<false>(cube, P.cubeDim, P.cubeLevels, f.r, lod);
+    }
 };
+// `flat` for a set of lanes: on the device a vote of the lanes that are active at the call, on the host the lane's own answer
+CRY_HD bool cube_chain_flat(float lod)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(lod != 0.0f) == 0;
+#else
+    return lod == 0.0f;
+#endif
+}
 
 // gsamLinearClamp on the half-res R16_UNORM ambient map  (CRYCHIC.cpp:2624-2629)
 struct AmbientFetch { uint16_t t00, t10, t01, t11; float fx, fy; };
@@ -947,7 +1001,9 @@ CRY_HD f4 sky_pixel_chain(const LightParams& P, const uint32_t* __restrict__ cub
     f3 ddx{ 0.0f, 0.0f, 0.0f }, ddy{ 0.0f, 0.0f, 0.0f };
     if ((x ^ 1u) < P.W) { const f3 n = sky_direction(P, x ^ 1u, y); ddx = (x & 1u) ? f3{ d.x - n.x, d.y - n.y, d.z - n.z } : f3{ n.x - d.x, n.y - d.y, n.z - d.z }; }
     if ((y ^ 1u) < P.H) { const f3 n = sky_direction(P, x, y ^ 1u); ddy = (y & 1u) ? f3{ d.x - n.x, d.y - n.y, d.z - n.z } : f3{ n.x - d.x, n.y - d.y, n.z - d.z }; }
-    return cube_trilinear<true>(cube, P.cubeDim, P.cubeLevels, d, cube_lod(P.cubeDim, P.cubeLevels, d, ddx, ddy));
+    const float lod = cube_lod(P.cubeDim, P.cubeLevels, d, ddx, ddy);
+    if (cube_chain_flat(lod)) return cube_linear(cube, P.cubeDim, d);           // magnified for every sky lane of the wavefront: level 0 as before
+    return cube_trilinear<true>(cube, P.cubeDim, P.cubeLevels, d, lod);
 }
 
 CRY_HD uint32_t pack_rgba8(f4 c)

@@ -321,7 +321,8 @@ void hs_light(const crychic_pass_constants* cb, const float* g0, const float* g1
                 f3 ddx{ 0.0f, 0.0f, 0.0f }, ddy{ 0.0f, 0.0f, 0.0f };
                 if (shaded(x ^ 1u, y)) { const f3 n = reflection_dir(P, G0[y * W + (x ^ 1u)], G2[y * W + (x ^ 1u)]); ddx = (x & 1u) ? f3{ r.x - n.x, r.y - n.y, r.z - n.z } : f3{ n.x - r.x, n.y - r.y, n.z - r.z }; }
                 if (shaded(x, y ^ 1u)) { const f3 n = reflection_dir(P, G0[(y ^ 1u) * W + x], G2[(y ^ 1u) * W + x]); ddy = (y & 1u) ? f3{ r.x - n.x, r.y - n.y, r.z - n.z } : f3{ n.x - r.x, n.y - r.y, n.z - r.z }; }
-                const CubeChain cc{ cube_lod(P.cubeDim, P.cubeLevels, r, ddx, ddy) };
+                const float lod = cube_lod(P.cubeDim, P.cubeLevels, r, ddx, ddy);
+                const CubeChain cc{ lod, cube_chain_flat(lod) };
                 if (pcfSearchRadius == 0.0f) lit = light_pixel<true, AllPointLights, true, CubeChain>(P, G0[idx], G1[idx], G2[idx], ambient, (const uint32_t*)cube, pl, cc);
                 else lit = light_pixel<false, AllPointLights, true, CubeChain>(P, G0[idx], G1[idx], G2[idx], ambient, (const uint32_t*)cube, pl, cc);
             }

@@ -201,6 +201,37 @@ def test_lit_frame_kernel_bodies_equal_oracle(oracle, hostsim, pcf, flags, point
     assert np.array_equal(one, flat)
 
 
+def noisy_normals(npl, seed=23):
+    """The scene's G-buffer with per-pixel random normals: neighbouring reflection vectors point anywhere, the level of detail runs
+    up to the 1 x 1 level."""
+    rng = np.random.default_rng(seed)
+    g2 = npl["g2"].copy()
+    g2[..., :3] = rng.normal(size=g2[..., :3].shape).astype(np.float32)
+    return g2
+
+
+def test_noise_normals_reach_the_last_level(oracle, hostsim):
+    """Random normals: lookups at every level including the 1 x 1 one (a face's single texel), kernel bodies == oracle; cutting
+    the chain's last level off changes the image, so it was used."""
+    import scene_util
+    from crychic_renderer_amd import geometry as g
+    W, H = 64, 48
+    planes = scene_util.cpu_scene(W, H, 256, 16)
+    npl = scene_util.np_planes(planes)
+    rng = np.random.default_rng(5)
+    cube = rng.integers(0, 256, (6, 16, 16, 4), dtype=np.uint8)           # a noisy cube map: its levels differ visibly
+    chain, levels = g.cube_mip_chain(cube)
+    assert levels == 5
+    g2 = noisy_normals(npl)
+    cb = planes["consts"].pass_cb
+    pcb = oracle_lib.as_oracle_cb(cb, oracle_lib.OrPassConstants)
+    got = hostsim.light(cb, npl["g0"], npl["g1"], g2, npl["depth"], None, npl["shadow"], chain, 3, 0.0, flags=1, cube_dim=16, cube_levels=levels)
+    ref = oracle.deferred_light(pcb, npl["g0"], npl["g1"], g2, npl["depth"], None, npl["shadow"], chain, 3, 0.0, sky=True, cube_dim=16, cube_levels=levels)
+    assert np.array_equal(got, ref)
+    short = oracle.deferred_light(pcb, npl["g0"], npl["g1"], g2, npl["depth"], None, npl["shadow"], chain, 3, 0.0, sky=True, cube_dim=16, cube_levels=levels - 1)
+    assert (short != ref).any()
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("W,H,points", [(96, 64, 0), (200, 90, 0), (70, 36, 6)])
 def test_chain_on_device(built_lib, oracle, W, H, points):
@@ -218,6 +249,8 @@ def test_chain_on_device(built_lib, oracle, W, H, points):
     pcb = oracle_lib.as_oracle_cb(cb, oracle_lib.OrPassConstants)
     amb = np.random.default_rng(3).integers(20000, 65535, (H // 2, W // 2)).astype(np.uint16)
     pl = scene.point_light_grid(points) if points else None
+    if W == 200:
+        npl["g2"] = noisy_normals(npl)            # every level of the chain, the 1 x 1 one included, and wavefronts that are not flat
     ctx = Context(0)
     try:
         def dev(a):
