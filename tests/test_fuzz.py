@@ -12,19 +12,31 @@ import oracle_lib
 EXTRA = int(os.environ.get("CRY_FUZZ_EXTRA", "0"))      # a soak run: CRY_FUZZ_EXTRA=400 python -m pytest tests/test_fuzz.py
 
 
-def oracle_frame(oracle, planes, c, knobs):
+def with_chain(planes, seed):
+    """Every other case binds the cube map's mip chain (trilinear lookups, level of detail from the pixel quads): the incoherent
+    planes put NaN / inf / zero-length normals next to each other, i.e. into the quad derivatives."""
+    if seed % 2 == 0:
+        return planes["cube"], {}
+    from crychic_renderer_amd import geometry as g
+    chain, levels = g.cube_mip_chain(planes["cube"])
+    return chain, dict(cube_dim=int(planes["cube"].shape[1]), cube_levels=levels)
+
+
+def oracle_frame(oracle, planes, c, knobs, cube=None, chain_kw=None):
     scb = oracle_lib.as_oracle_cb(c.ssao_cb, oracle_lib.OrSsaoConstants)
     pcb = oracle_lib.as_oracle_cb(c.pass_cb, oracle_lib.OrPassConstants)
     ao = oracle.compute_ssao(scb, planes["normal"], planes["depth"], planes["randvec"], knobs["blurCount"]) if knobs["ssao_on"] else None
-    out, rad = oracle.deferred_light(pcb, planes["g0"], planes["g1"], planes["g2"], planes["depth"], ao, planes["shadow"], planes["cube"],
-                                     knobs["numDirLights"], knobs["pcfSearchRadius"], sky=bool(knobs["sky"]), want_radiance=True)
+    out, rad = oracle.deferred_light(pcb, planes["g0"], planes["g1"], planes["g2"], planes["depth"], ao, planes["shadow"],
+                                     planes["cube"] if cube is None else cube, knobs["numDirLights"], knobs["pcfSearchRadius"], sky=bool(knobs["sky"]),
+                                     want_radiance=True, **(chain_kw or {}))
     return ao, out, rad
 
 
 @pytest.mark.parametrize("seed", range(6 + EXTRA // 8))
 def test_fuzz_kernel_bodies(built_lib, oracle, hostsim, seed):
     W, H, planes, c, knobs = fuzz_util.random_case(seed, built_lib)
-    ao, out, rad = oracle_frame(oracle, planes, c, knobs)
+    cube, chain_kw = with_chain(planes, seed)
+    ao, out, rad = oracle_frame(oracle, planes, c, knobs, cube, chain_kw)
     if knobs["ssao_on"]:
         got, edge = hostsim.ssao(c.ssao_cb, planes["normal"], planes["depth"], planes["randvec"],
                                  int(built_lib.lib.crychic_edge_plane_bytes(W, H)))
@@ -32,8 +44,8 @@ def test_fuzz_kernel_bodies(built_lib, oracle, hostsim, seed):
             got = hostsim.blur(c.ssao_cb, edge, got, W, H, True)
             got = hostsim.blur(c.ssao_cb, edge, got, W, H, False)
         assert np.array_equal(got, ao), knobs
-    o2, r2 = hostsim.light(c.pass_cb, planes["g0"], planes["g1"], planes["g2"], planes["depth"], ao, planes["shadow"], planes["cube"],
-                           knobs["numDirLights"], knobs["pcfSearchRadius"], flags=knobs["sky"], want_radiance=True)
+    o2, r2 = hostsim.light(c.pass_cb, planes["g0"], planes["g1"], planes["g2"], planes["depth"], ao, planes["shadow"], cube,
+                           knobs["numDirLights"], knobs["pcfSearchRadius"], flags=knobs["sky"], want_radiance=True, **chain_kw)
     assert np.array_equal(o2, out), knobs
     assert fuzz_util.same_floats(r2, rad), knobs
 
@@ -44,7 +56,8 @@ def test_fuzz_device(built_lib, oracle, seed):
     import torch
     from crychic_renderer_amd import Context, Crychic
     W, H, planes, c, knobs = fuzz_util.random_case(1000 + seed, built_lib)
-    ao, out, rad = oracle_frame(oracle, planes, c, knobs)
+    cube, chain_kw = with_chain(planes, seed)
+    ao, out, rad = oracle_frame(oracle, planes, c, knobs, cube, chain_kw)
     ctx = Context(0)
     try:
         dev = {k: torch.from_numpy(np.ascontiguousarray(v).view(np.int32) if v.dtype == np.uint32 else np.ascontiguousarray(v)).to(ctx.device)
@@ -64,12 +77,13 @@ def test_fuzz_device(built_lib, oracle, seed):
         o = torch.zeros((H, W, 4), dtype=torch.uint8, device=ctx.device)
         r = torch.zeros((H, W, 4), dtype=torch.float32, device=ctx.device)
         sh = (C.c_void_p * 4)(*[dev["shadow"][k].data_ptr() for k in range(4)])
+        dcube = torch.from_numpy(np.ascontiguousarray(cube)).to(ctx.device)
         check(lib.crychic_deferred_light(ctx.handle, C.byref(c.pass_cb), C.c_void_p(dev["g0"].data_ptr()), C.c_void_p(dev["g1"].data_ptr()),
                                          C.c_void_p(dev["g2"].data_ptr()), C.c_void_p(dev["depth"].data_ptr()),
                                          C.c_void_p(a0.data_ptr()) if knobs["ssao_on"] else None, sh, planes["shadow"].shape[1],
-                                         C.c_void_p(dev["cube"].data_ptr()), planes["cube"].shape[1], C.c_void_p(o.data_ptr()),
+                                         C.c_void_p(dcube.data_ptr()), planes["cube"].shape[1], C.c_void_p(o.data_ptr()),
                                          C.c_void_p(r.data_ptr()), W, H, 0, H, knobs["numDirLights"], knobs["pcfSearchRadius"],
-                                         knobs["sky"], st))
+                                         knobs["sky"] | (chain_kw.get("cube_levels", 0) << 16), st))
         torch.cuda.synchronize()
         got = o.cpu().numpy()
         assert np.array_equal(got, out), "%s: %d channels differ" % (knobs, (got != out).sum())
