@@ -95,7 +95,12 @@ int ssao_compute_impl(const crychic_ssao_constants* cb, const void* normal, cons
     const uint32_t stamp = next_stamp();
     // (gathering from the raw D24 plane with the coarse maps alone was measured too: the depth pass drops from 20 to 7 us and the
     // SSAO kernel gains 15: the pairs plane stays)
-    const bool usePairs = edge != nullptr;
+    // A small strip of a multi-GPU frame (few wavefronts: its SSAO pass is a chain of round trips, not arithmetic) skips the pairs plane:
+    // the depth pass writes the coarse maps only and the taps gather from the raw plane -- the same bits, 1.6 us less for a 1/8 strip of
+    // the 4K frame, where the whole frame gains 8 us from the plane (profiles/r04_experiments.txt).  CRYCHIC_STRIP_PAIRS=1: always the plane.
+    static const bool stripPairs = getenv("CRYCHIC_STRIP_PAIRS") != nullptr;
+    const bool smallStrip = rn < h2 && ((W / 2u + 63u) / 64u) * rn < 4096u;
+    const bool usePairs = edge != nullptr && (stripPairs || !smallStrip);
     if (edge) CRY_HIP(cry::launch_depth_pairs(*cb, depth, edge, W, H, stamp, usePairs, r0, rn, stream));
     CRY_HIP(cry::launch_ssao(*cb, normal, depth, randvec, planes[cry::blur_chain_ssao_plane(blurCount)], edge, W, H, r0, rn, true, usePairs,
                              edge ? stamp : 0u, stream));

@@ -199,10 +199,14 @@ __global__ __launch_bounds__(256) void ssao_kernel(crychic_ssao_constants cb, co
     if (EMIT_AO) {
         uint32_t v;
         const ZminMap zm{ edge.zcull, zmin_map_cols(W) };
-        if (ROWS) {      // PAIRS && MAPS
+        if (ROWS && PAIRS) {      // && MAPS
             const DepthPairsRows dr{ dp, dd, prep.j0lo, prep.nj };
             if (cullEnabled) v = ssao_pixel(cb, c, dr, randvec, W, H, x, y, hs, sparseProjTex != 0, ZminMapRows{ zm, prep.j0lo, prep.nj });
             else v = ssao_pixel(cb, c, dr, randvec, W, H, x, y, hs, sparseProjTex != 0);
+        }
+        else if (ROWS) {          // MAPS without the pairs plane: the taps gather from the raw plane, the culling map is the strip's
+            if (cullEnabled) v = ssao_pixel(cb, c, dd, randvec, W, H, x, y, hs, sparseProjTex != 0, ZminMapRows{ zm, prep.j0lo, prep.nj });
+            else v = ssao_pixel(cb, c, dd, randvec, W, H, x, y, hs, sparseProjTex != 0);
         }
         else if (PAIRS && MAPS && cullEnabled) v = ssao_pixel(cb, c, dp, randvec, W, H, x, y, hs, sparseProjTex != 0, zm);
         else if (PAIRS) v = ssao_pixel(cb, c, dp, randvec, W, H, x, y, hs, sparseProjTex != 0);
@@ -669,15 +673,17 @@ hipError_t launch_ssao(const crychic_ssao_constants& cb, const void* normal, con
     // what launch_depth_pairs prepared for these rows: everything, or footprint rows j0 with 8 c0 <= j0 + 2 < 8 (c0 + cn)
     uint32_t c0, cn;
     depth_pass_cell_rows(H, row0, rows, &c0, &cn, depth_margin());
-    const bool limited = maps && use_pairs && (c0 > 0u || c0 + cn < zmin_map_rows(H));
+    const bool limitedRows = maps && (c0 > 0u || c0 + cn < zmin_map_rows(H));
+    const bool limited = limitedRows && use_pairs;
     const PrepRows prep{ 8 * (int)c0 - 2, 8u * cn };
-    if (limited) {                      // geometry-map cells are known for the texel rows the pass visited (8 entry rows per cell row)
+    if (limitedRows) {                  // geometry-map cells are known for the texel rows the pass visited (8 entry rows per cell row)
         sky.y0 = 8 * (int)c0 - 2 < 0 ? 0 : 8 * (int)c0 - 2;
         sky.y1 = 8 * (int)(c0 + cn) - 2 > (int)H ? (int)H : 8 * (int)(c0 + cn) - 2;
     }
 #define CRY_LAUNCH_SSAO(K) hipLaunchKernelGGL(K, grid, dim3(256), 0, stream, cb, (const u2*)normal, depth, (const uint32_t*)randvec, ambient, e, W, H, row0, row0 + rows, SX, SY, sparse, sky, stamp, cull, prep, half_res_scale(W, H))
     if (!emit_ao) CRY_LAUNCH_SSAO((ssao_kernel<false, false, false, false>));
     else if (limited) CRY_LAUNCH_SSAO((ssao_kernel<true, true, true, true>));
+    else if (limitedRows) CRY_LAUNCH_SSAO((ssao_kernel<true, false, true, true>));
     else if (use_pairs && maps) CRY_LAUNCH_SSAO((ssao_kernel<true, true, true, false>));
     else if (use_pairs) CRY_LAUNCH_SSAO((ssao_kernel<true, true, false, false>));
     else if (maps) CRY_LAUNCH_SSAO((ssao_kernel<true, false, true, false>));
